@@ -1,0 +1,83 @@
+// Shared device helpers for libihmr_hip (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ihmr_hip.h"
+
+#define NV IHMR_NUM_VERTS      // 778
+#define NF IHMR_NUM_FACES      // 1538
+#define NJ IHMR_NUM_JOINTS     // 16
+#define NV3 (NV * 3)           // 2334
+#define NPF 135                // pose-feature length (15 joints x 9)
+#define NFP 1600               // faces padded to a multiple of 64 (SoA row length)
+#define SDF_G IHMR_SDF_GRID    // 32
+#define SDF_NVOX (SDF_G * SDF_G * SDF_G)
+#define WAVE 64
+
+#define HIP_TRY(expr)                         \
+    do {                                      \
+        hipError_t _e = (expr);               \
+        if (_e != hipSuccess) return (int)_e; \
+    } while (0)
+
+// dot product in the fixed order of the SDF arithmetic spec: fma(z, fma(y, x*x'))
+#define DOT3(ax, ay, az, bx, by, bz) __builtin_fmaf((az), (bz), __builtin_fmaf((ay), (by), (ax) * (bx)))
+
+struct ihmr_mano {
+    // device pointers (fp32 unless stated)
+    float* v_template;    // [2334]
+    float* shapedirs_t;   // [10][2334]
+    float* posedirs;      // [135][2334]
+    float* J_template;    // [48]   = J_regressor . v_template
+    float* J_shapedirs;   // [48][10] = J_regressor . shapedirs
+    float* weights;       // [778][16]
+    float* pose_mean;     // [48]
+    int32_t* parents;     // [16]
+    int32_t* depth;       // [16] depth in the kinematic tree (root = 0)
+    int32_t* tip_ids;     // [5]
+    int32_t* wj_start;    // [17]  CSR by joint of the non-zero skinning weights
+    int32_t* wj_vert;     // [nnz]
+    float* wj_w;          // [nnz]
+    int32_t* faces;       // [3][NFP] SoA, padded with face 0
+    float* J_regressor;   // [16][778] (host-side precompute source, kept for update_shapedirs)
+    int max_depth;
+    int nnz;
+};
+
+__device__ __forceinline__ float wave_reduce_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// fixed-order butterfly sum: every lane ends with the same value, bit-reproducible run to run
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_reduce_xor(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v ^= (unsigned)__shfl_xor((int)v, o);
+    return v;
+}
+
+// block-wide fixed-order sum through LDS (buf holds >= blockDim.x floats); result broadcast
+__device__ __forceinline__ float block_reduce_sum(float v, float* buf) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    buf[tid] = v;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (tid < s) buf[tid] += buf[tid + s];
+        __syncthreads();
+    }
+    const float r = buf[0];
+    __syncthreads();
+    return r;
+}

@@ -1,0 +1,277 @@
+// libihmr_hip.so -- C ABI (include/ihmr_hip.h) over the gfx950 kernels.  Single translation unit.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC ihmr_hip.hip -o libihmr_hip.so
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "ihmr_common.h"
+#include "mano_lbs.h"
+#include "sdf_collision.h"
+#include "refine.h"
+
+static ihmr_kernel_timer* g_timer = nullptr;
+struct TimedPair { hipEvent_t a, b; double flops; };
+static std::vector<TimedPair> g_pending;
+
+// ------------------------------------------------------------------------------------------ model
+template <typename T>
+static int upload(T** dst, const std::vector<T>& src) {
+    HIP_TRY(hipMalloc((void**)dst, src.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static void derive_shape_constants(const float* Jreg, const float* v_template, const float* shapedirs,
+                                   std::vector<float>& sd_t, std::vector<float>& J_t, std::vector<float>& J_sd) {
+    sd_t.assign((size_t)10 * NV3, 0.f);
+    for (int v = 0; v < NV; ++v)
+        for (int k = 0; k < 3; ++k)
+            for (int l = 0; l < 10; ++l) sd_t[(size_t)l * NV3 + 3 * v + k] = shapedirs[(v * 3 + k) * 10 + l];
+    J_t.assign(48, 0.f);
+    J_sd.assign(480, 0.f);
+    for (int j = 0; j < NJ; ++j)
+        for (int k = 0; k < 3; ++k) {
+            double acc = 0.0;
+            for (int v = 0; v < NV; ++v) acc += (double)Jreg[j * NV + v] * (double)v_template[3 * v + k];
+            J_t[j * 3 + k] = (float)acc;
+            for (int l = 0; l < 10; ++l) {
+                double a2 = 0.0;
+                for (int v = 0; v < NV; ++v) a2 += (double)Jreg[j * NV + v] * (double)shapedirs[(v * 3 + k) * 10 + l];
+                J_sd[(j * 3 + k) * 10 + l] = (float)a2;
+            }
+        }
+}
+
+extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
+    if (!h || !out) return -1;
+    ihmr_mano* m = new ihmr_mano();
+    memset(m, 0, sizeof(*m));
+    std::vector<float> vt(h->v_template, h->v_template + NV3), pd(h->posedirs, h->posedirs + (size_t)NPF * NV3),
+        wts(h->lbs_weights, h->lbs_weights + NV * NJ), jr(h->J_regressor, h->J_regressor + NJ * NV);
+    std::vector<float> sd_t, J_t, J_sd;
+    derive_shape_constants(h->J_regressor, h->v_template, h->shapedirs, sd_t, J_t, J_sd);
+    std::vector<float> pm(48, 0.f);
+    for (int i = 0; i < 45; ++i) pm[3 + i] = h->hands_mean[i];
+    std::vector<int32_t> par(h->parents, h->parents + NJ), depth(NJ, 0), tips(h->tip_ids, h->tip_ids + IHMR_NUM_TIPS);
+    int maxd = 0;
+    for (int j = 1; j < NJ; ++j) {
+        if (par[j] < 0 || par[j] >= j) { delete m; return -1; }
+        depth[j] = depth[par[j]] + 1;
+        if (depth[j] > maxd) maxd = depth[j];
+    }
+    std::vector<int32_t> start(NJ + 1, 0), wv;
+    std::vector<float> ww;
+    for (int j = 0; j < NJ; ++j) {
+        for (int v = 0; v < NV; ++v)
+            if (wts[v * NJ + j] != 0.f) { wv.push_back(v); ww.push_back(wts[v * NJ + j]); }
+        start[j + 1] = (int32_t)wv.size();
+    }
+    std::vector<int32_t> fsoa((size_t)3 * NFP, 0);
+    for (int f = 0; f < NFP; ++f)
+        for (int k = 0; k < 3; ++k) {
+            const int32_t id = h->faces[(f < NF ? f : 0) * 3 + k];
+            if (id < 0 || id >= NV) { delete m; return -1; }
+            fsoa[(size_t)k * NFP + f] = id;
+        }
+    int rc = 0;
+    rc |= upload(&m->v_template, vt); rc |= upload(&m->shapedirs_t, sd_t); rc |= upload(&m->posedirs, pd);
+    rc |= upload(&m->J_template, J_t); rc |= upload(&m->J_shapedirs, J_sd); rc |= upload(&m->weights, wts);
+    rc |= upload(&m->pose_mean, pm); rc |= upload(&m->parents, par); rc |= upload(&m->depth, depth);
+    rc |= upload(&m->tip_ids, tips); rc |= upload(&m->wj_start, start); rc |= upload(&m->wj_vert, wv);
+    rc |= upload(&m->wj_w, ww); rc |= upload(&m->faces, fsoa); rc |= upload(&m->J_regressor, jr);
+    m->max_depth = maxd;
+    m->nnz = (int)wv.size();
+    if (rc) return rc;
+    *out = m;
+    return 0;
+}
+
+extern "C" int ihmr_mano_destroy(ihmr_mano* m) {
+    if (!m) return 0;
+    void* ptrs[] = {m->v_template, m->shapedirs_t, m->posedirs, m->J_template, m->J_shapedirs, m->weights, m->pose_mean,
+                    m->parents, m->depth, m->tip_ids, m->wj_start, m->wj_vert, m->wj_w, m->faces, m->J_regressor};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete m;
+    return 0;
+}
+
+extern "C" int ihmr_mano_update_shapedirs(ihmr_mano* m, const float* shapedirs_host) {
+    if (!m || !shapedirs_host) return -1;
+    std::vector<float> jr((size_t)NJ * NV), vt(NV3), sd_t, J_t, J_sd;
+    HIP_TRY(hipMemcpy(jr.data(), m->J_regressor, jr.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(vt.data(), m->v_template, vt.size() * 4, hipMemcpyDeviceToHost));
+    derive_shape_constants(jr.data(), vt.data(), shapedirs_host, sd_t, J_t, J_sd);
+    HIP_TRY(hipMemcpy(m->shapedirs_t, sd_t.data(), sd_t.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->J_shapedirs, J_sd.data(), J_sd.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ seam A
+extern "C" int ihmr_mano_lbs_fwd(const ihmr_mano* m, const float* orient, const float* pose, const float* betas, int N,
+                                 float* verts, float* joints, float* v_posed_ws, void* stream) {
+    if (!m || N <= 0) return -1;
+    hipLaunchKernelGGL(lbs_fwd_kernel<false>, dim3(N), dim3(LBS_THREADS), 0, (hipStream_t)stream, *m, orient, pose, betas,
+                       (const float*)nullptr, 0, verts, joints, v_posed_ws);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_mano_lbs_bwd(const ihmr_mano* m, const float* orient, const float* pose, const float* betas, int N,
+                                 const float* v_posed_ws, const float* d_verts, const float* d_joints, float* d_orient,
+                                 float* d_pose, float* d_betas, int need_mask, void* stream) {
+    if (!m || N <= 0) return -1;
+    hipLaunchKernelGGL(lbs_bwd_kernel<false>, dim3(N), dim3(LBS_THREADS), 0, (hipStream_t)stream, *m, orient, pose, betas,
+                       0, v_posed_ws, d_verts, d_joints, d_orient, d_pose, d_betas, (float*)nullptr, need_mask);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ seam B
+extern "C" size_t ihmr_sdf_workspace_bytes(int B) { return sdf_ws_bytes(2 * B) + (size_t)2 * NFP * 3 * 4 + 256; }
+
+#define SDF_EVAL_CHUNKS 16
+
+static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const int32_t* faces_l_soa, int B, SdfWorkspace ws,
+                      float robustifier, float* loss, float* per_vert, float* origin, float* dval, float* gverts,
+                      const float* gscale, hipStream_t st) {
+    hipLaunchKernelGGL(sdf_prep_kernel<false>, dim3(2 * B), dim3(SDF_THREADS), 0, st, vl, faces_r_soa, faces_l_soa, ws);
+    TimedPair tp;
+    const bool timed = g_timer != nullptr;
+    if (timed) {
+        HIP_TRY(hipEventCreate(&tp.a));
+        HIP_TRY(hipEventCreate(&tp.b));
+        HIP_TRY(hipEventRecord(tp.a, st));
+    }
+    hipLaunchKernelGGL(sdf_eval_kernel, dim3(SDF_EVAL_CHUNKS, 2 * B), dim3(SDF_THREADS), 0, st, ws, 0);
+    if (timed) {
+        HIP_TRY(hipEventRecord(tp.b, st));
+        tp.flops = 0.0;
+        g_pending.push_back(tp);
+    }
+    hipLaunchKernelGGL(sdf_sample_kernel, dim3(B), dim3(SDF_THREADS), 0, st, vl, ws, robustifier, loss, per_vert, origin,
+                       dval, gverts, B, gscale);
+    return (int)hipGetLastError();
+}
+
+// seam-B callers hand over (F,3) int32 AoS faces on the device; the SoA copy lives in the workspace tail
+__global__ void faces_to_soa_kernel(const int32_t* __restrict__ aos, int32_t* __restrict__ soa) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= NFP) return;
+    const int s = f < NF ? f : 0;
+    for (int k = 0; k < 3; ++k) soa[k * NFP + f] = aos[s * 3 + k];
+}
+
+extern "C" int ihmr_sdf_collision(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
+                                  float robustifier, float* loss, float* per_vert, float* origin_scale, float* dval,
+                                  void* workspace, void* stream) {
+    if (!workspace || B <= 0) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    SdfWorkspace ws = sdf_carve(workspace, 2 * B);
+    int32_t* soa = (int32_t*)((char*)workspace + sdf_ws_bytes(2 * B));
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa);
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP);
+    VertLayout vl{hand_verts, (long)2 * NV3, (long)NV3};
+    return sdf_launch(vl, soa, soa + 3 * NFP, B, ws, robustifier, loss, per_vert, origin_scale, dval, nullptr, nullptr, st);
+}
+
+extern "C" int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
+                                   float* phi, void* workspace, void* stream) {
+    if (!workspace || B <= 0) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    SdfWorkspace ws = sdf_carve(workspace, 2 * B);
+    int32_t* soa = (int32_t*)((char*)workspace + sdf_ws_bytes(2 * B));
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa);
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP);
+    VertLayout vl{hand_verts, (long)2 * NV3, (long)NV3};
+    hipLaunchKernelGGL(sdf_prep_kernel<true>, dim3(2 * B), dim3(SDF_THREADS), 0, st, vl, soa, soa + 3 * NFP, ws);
+    hipLaunchKernelGGL(sdf_eval_kernel, dim3(64, 2 * B), dim3(SDF_THREADS), 0, st, ws, 0);
+    HIP_TRY(hipMemcpyAsync(phi, ws.phi, (size_t)2 * B * SDF_NVOX * 4, hipMemcpyDeviceToDevice, st));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ seam C
+extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
+
+static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
+                       const ihmr_opt_weights& w, hipStream_t st) {
+    hipLaunchKernelGGL(lbs_fwd_kernel<true>, dim3(2 * B), dim3(LBS_THREADS), 0, st, *m, (const float*)io->orient,
+                       (const float*)io->pose, (const float*)io->shape, (const float*)io->trans, B, io->verts,
+                       wk.joints_raw, wk.v_posed);
+    hipLaunchKernelGGL(opt_loss_kernel, dim3(B), dim3(LOSS_THREADS), 0, st, *io, wk, B, w);
+    SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
+    VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
+    // loss_batch[2] = collision loss per sample; masking by hand type is applied through gscale / below
+    return sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, B, ws, 0.f, io->loss_batch + 2 * B, io->coll_per_vert, io->coll_origin_scale,
+                      nullptr, wk.g_verts, wk.gscale, st);
+}
+
+__global__ void opt_mask_collision_kernel(ihmr_opt_io io, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
+    io.loss_batch[2 * B + b] *= mask;  // loss_utils.py:186-188
+}
+
+extern "C" int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                                       const ihmr_opt_weights* w, void* stream) {
+    if (!m || !io || !w || B <= 0) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    OptWork wk = opt_carve(io->workspace, B);
+    int rc = opt_forward(m, m_left, io, wk, B, *w, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(opt_mask_collision_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, int group,
+                                  const ihmr_opt_weights* w, float lr, int n_iters, int save_freq, float filter_factor_j3d, float filter_factor_coll,
+                                  int select_on_collision, void* stream) {
+    if (!m || !io || !w || B <= 0 || group < 0 || group > 3 || n_iters <= 0 || save_freq <= 0) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    OptWork wk = opt_carve(io->workspace, B);
+    HIP_TRY(hipMemsetAsync(io->adam_m, 0, (size_t)B * OPT_PMAX * 4, st));
+    HIP_TRY(hipMemsetAsync(io->adam_v, 0, (size_t)B * OPT_PMAX * 4, st));
+    const int P = group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
+    const int need_mask = group == IHMR_GROUP_TRANS ? 8 : (group == IHMR_GROUP_ORIENT ? 1 : (group == IHMR_GROUP_POSE ? 2 : 4));
+    int S = 0;
+    for (int it = 0; it < n_iters; ++it) {
+        int rc = opt_forward(m, m_left, io, wk, B, *w, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(opt_mask_collision_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B);
+        hipLaunchKernelGGL(lbs_bwd_kernel<true>, dim3(2 * B), dim3(LBS_THREADS), 0, st, *m, (const float*)io->orient,
+                           (const float*)io->pose, (const float*)io->shape, B, (const float*)wk.v_posed,
+                           (const float*)wk.g_verts, (const float*)wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape,
+                           wk.g_trans, need_mask);
+        const int snap = (it % save_freq == 0) ? S++ : -1;
+        const double t = (double)(it + 1);
+        const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
+        const float step_size = (float)((double)lr / bc1), bc2s = (float)sqrt(bc2);
+        hipLaunchKernelGGL(opt_adam_kernel, dim3((B * P + 255) / 256), dim3(256), 0, st, *io, wk, B, group, w->shape_reg,
+                           step_size, bc2s, snap);
+    }
+    hipLaunchKernelGGL(opt_select_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B, group, S, filter_factor_j3d,
+                       filter_factor_coll, select_on_collision);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ misc
+extern "C" int ihmr_set_kernel_timer(ihmr_kernel_timer* t) {
+    g_timer = t;
+    return 0;
+}
+
+extern "C" int ihmr_flush_kernel_timer(void) {
+    for (auto& p : g_pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(p.b));
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        if (g_timer) { g_timer->ms_sdf_eval += ms; g_timer->n_sdf_eval += 1; }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    g_pending.clear();
+    return 0;
+}
+
+extern "C" const char* ihmr_version(void) { return "ihmr_hip 0.1 (gfx950)"; }

@@ -1,0 +1,308 @@
+// IHMR-OPT refinement step pieces: joint / translation / finger losses with their analytic
+// gradients, the Adam update (+ snapshot), and the per-stage snapshot filter / argmin select.
+//
+// Reference: models/optimize_model.py:276-330 (__compute_loss), models/loss_utils.py:82-171,
+// models/transform_utils.py:47-54, torch.optim.Adam as created at optimize_model.py:344,
+// utils/opt_utils.py:70-153 (gather / filter / select).
+#pragma once
+#include "ihmr_common.h"
+
+#define LOSS_THREADS 64
+#define OPT_PMAX 90  // largest parameter group: 2 x 45 finger pose
+
+struct OptWork {  // carved from ihmr_opt_io.workspace
+    float* v_posed;     // (2B,778,3)
+    float* joints_raw;  // (B,42,3)
+    float* g_verts;     // (2,B,778,3)
+    float* g_joints;    // (B,42,3)
+    float* g_trans_direct;  // (B,3)
+    float* g_orient;    // (2,B,3)
+    float* g_pose;      // (2,B,45)
+    float* g_shape;     // (2,B,10)
+    float* g_trans;     // (B,3)
+    float* gscale;      // (B)
+    void* sdf_ws;
+};
+
+static inline size_t opt_ws_bytes(int B) {
+    size_t n = 0;
+    n += (size_t)2 * B * NV3 * 4 * 2;     // v_posed, g_verts
+    n += (size_t)B * 42 * 3 * 4 * 2;      // joints_raw, g_joints
+    n += (size_t)B * (3 + 6 + 90 + 20 + 3 + 1) * 4;
+    n = (n + 255) & ~(size_t)255;
+    n += 4096;
+    return n + sdf_ws_bytes(2 * B);
+}
+
+static inline OptWork opt_carve(void* ws, int B) {
+    OptWork w;
+    char* p = (char*)ws;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    w.v_posed = (float*)take((size_t)2 * B * NV3 * 4);
+    w.g_verts = (float*)take((size_t)2 * B * NV3 * 4);
+    w.joints_raw = (float*)take((size_t)B * 42 * 3 * 4);
+    w.g_joints = (float*)take((size_t)B * 42 * 3 * 4);
+    w.g_trans_direct = (float*)take((size_t)B * 3 * 4);
+    w.g_orient = (float*)take((size_t)B * 6 * 4);
+    w.g_pose = (float*)take((size_t)B * 90 * 4);
+    w.g_shape = (float*)take((size_t)B * 20 * 4);
+    w.g_trans = (float*)take((size_t)B * 3 * 4);
+    w.gscale = (float*)take((size_t)B * 4);
+    w.sdf_ws = (void*)p;
+    return w;
+}
+
+// finger table of loss_utils.py:139-145: [a, b, c, tip] for index, middle, little, ring, thumb
+__constant__ int c_finger_ids[20] = {1, 2, 3, 17, 4, 5, 6, 18, 7, 8, 9, 20, 10, 11, 12, 19, 13, 14, 15, 16};
+
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// root of loss_utils.py:90-98: weight > 0.5 -> joint 0, weight < 1e-7 -> joint 21, else no alignment
+__device__ __forceinline__ int align_root(float w) { return w > 0.5f ? 0 : (w < 1e-7f ? 21 : -1); }
+
+// grid = B, block = 64: thread j < 42 owns joint j.
+__global__ __launch_bounds__(LOSS_THREADS) void opt_loss_kernel(ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w) {
+    __shared__ float raw[42][3], p1[42][3], p2[42][3], g2[42][3], acc[8][LOSS_THREADS], gsum[2][3];
+    const int b = blockIdx.x, j = threadIdx.x;
+    const bool act = j < 42;
+    const float* cam = io.cam + b * 3;
+    const float cs = cam[0], ctx = cam[1], cty = cam[2];
+    float r[3] = {0.f, 0.f, 0.f};
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r[k] = wk.joints_raw[(b * 42 + j) * 3 + k]; raw[j][k] = r[k]; }
+    }
+    __syncthreads();
+
+    // ---- 2D: projection of the un-aligned joints (transform_utils.py:47-54, optimize_model.py:263)
+    float l2d_p = 0.f, l2d_gt = 0.f, g_raw[3] = {0.f, 0.f, 0.f};
+    if (act) {
+        const float px = (r[0] + ctx) * cs, py = (r[1] + cty) * cs;
+        io.joints_2d[(b * 42 + j) * 2] = px;
+        io.joints_2d[(b * 42 + j) * 2 + 1] = py;
+        const float* t = io.init_joints_2d + (b * 42 + j) * 3;
+        const float* tg = io.gt_joints_2d + (b * 42 + j) * 3;
+        const float dx = t[0] - px, dy = t[1] - py;
+        l2d_p = (fabsf(dx) + fabsf(dy)) * t[2];
+        l2d_gt = (fabsf(tg[0] - px) + fabsf(tg[1] - py)) * tg[2];
+        const float s2 = w.joints_2d / (float)(B * 42 * 2);
+        // d|t - p|/dp = -sign(t - p); dp/dX = cam scale
+        const float sx = dx > 0.f ? -1.f : (dx < 0.f ? 1.f : 0.f), sy = dy > 0.f ? -1.f : (dy < 0.f ? 1.f : 0.f);
+        g_raw[0] = s2 * sx * t[2] * cs;
+        g_raw[1] = s2 * sy * t[2] * cs;
+    }
+
+    // ---- 3D: two successive in-place root alignments (GT weights first, then init weights)
+    const int root1 = align_root(io.gt_joints_3d[(b * 42) * 4 + 3]);
+    const int root2 = align_root(io.init_joints_3d[(b * 42) * 4 + 3]);
+    float a1[3], a2[3], l3d_gt = 0.f, l3d_p = 0.f;
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { a1[k] = root1 >= 0 ? r[k] - raw[root1][k] : r[k]; p1[j][k] = a1[k]; }
+    }
+    __syncthreads();
+    if (act) {
+        const float* tg = io.gt_joints_3d + (b * 42 + j) * 4;
+        const float* tg0 = io.gt_joints_3d + (b * 42 + (root1 >= 0 ? root1 : 0)) * 4;
+        const float* ti = io.init_joints_3d + (b * 42 + j) * 4;
+        const float* ti0 = io.init_joints_3d + (b * 42 + (root2 >= 0 ? root2 : 0)) * 4;
+        const float s3 = w.joints_3d / (float)(B * 42 * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a2[k] = root2 >= 0 ? a1[k] - p1[root2][k] : a1[k];
+            p2[j][k] = a2[k];
+            const float gg = (root1 >= 0 ? tg[k] - tg0[k] : tg[k]) - a1[k];
+            l3d_gt += gg * gg * tg[3];
+            const float gi = (root2 >= 0 ? ti[k] - ti0[k] : ti[k]) - a2[k];
+            l3d_p += gi * gi * ti[3];
+            g2[j][k] = -2.0f * s3 * gi * ti[3];
+            io.joints_3d[(b * 42 + j) * 3 + k] = a2[k];
+        }
+    }
+    __syncthreads();
+
+    // ---- finger regulariser on the aligned joints (loss_utils.py:138-171); thread f < 10 owns a finger
+    float lfin = 0.f;
+    if (j < 10) {
+        const int off = j < 5 ? 0 : 21, fi = j % 5;
+        const int ia = c_finger_ids[4 * fi] + off, ib = c_finger_ids[4 * fi + 1] + off, ic = c_finger_ids[4 * fi + 2] + off,
+                  it = c_finger_ids[4 * fi + 3] + off;
+        float f0[3], f1[3], f2[3], n1[3], n2[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { f0[k] = p2[ia][k] - p2[ib][k]; f1[k] = p2[ib][k] - p2[ic][k]; f2[k] = p2[ic][k] - p2[it][k]; }
+        cross3(f0, f1, n1);
+        cross3(f1, f2, n2);
+        const float C1 = f2[0] * n1[0] + f2[1] * n1[1] + f2[2] * n1[2];
+        const float C2 = n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2];
+        lfin = fabsf(C1) - fminf(0.f, C2);
+        if (w.finger_reg != 0.f) {
+            const float sf = w.finger_reg / (float)B;
+            const float k1 = sf * (C1 > 0.f ? 1.f : (C1 < 0.f ? -1.f : 0.f));
+            const float k2 = C2 < 0.f ? -sf : 0.f;
+            // dC1/df0 = f1 x f2 = n2, dC1/df1 = f2 x f0, dC1/df2 = n1
+            // dC2/df0 = f1 x n2, dC2/df1 = n2 x f0 + f2 x n1, dC2/df2 = n1 x f1
+            float t1[3], t2[3], t3[3], t4[3], t5[3];
+            cross3(f2, f0, t1);
+            cross3(f1, n2, t2);
+            cross3(n2, f0, t3);
+            cross3(f2, n1, t4);
+            cross3(n1, f1, t5);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float d0 = k1 * n2[k] + k2 * t2[k];
+                const float d1 = k1 * t1[k] + k2 * (t3[k] + t4[k]);
+                const float d2 = k1 * n1[k] + k2 * t5[k];
+                // every joint belongs to exactly one finger, so these writes never collide
+                g2[ia][k] += d0;
+                g2[ib][k] += d1 - d0;
+                g2[ic][k] += d2 - d1;
+                g2[it][k] += -d2;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- back through the two alignments: g_in = g_out - [j == root] * sum_j g_out
+    if (j < 3) {
+        float s = 0.f;
+        for (int q = 0; q < 42; ++q) s += g2[q][j];
+        gsum[0][j] = s;
+    }
+    __syncthreads();
+    float g1[3];
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            g1[k] = g2[j][k] - ((root2 >= 0 && j == root2) ? gsum[0][k] : 0.f);
+            p1[j][k] = g1[k];  // reuse as scratch for the second sum
+        }
+    }
+    __syncthreads();
+    if (j < 3) {
+        float s = 0.f;
+        for (int q = 0; q < 42; ++q) s += p1[q][j];
+        gsum[1][j] = s;
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float g0 = g1[k] - ((root1 >= 0 && j == root1) ? gsum[1][k] : 0.f);
+            wk.g_joints[(b * 42 + j) * 3 + k] = g0 + g_raw[k];
+        }
+    }
+
+    // ---- per-sample reductions (fixed order: thread 0 sums 42 entries)
+    acc[0][j] = l2d_p; acc[1][j] = l3d_p; acc[2][j] = lfin; acc[3][j] = l2d_gt; acc[4][j] = l3d_gt;
+    __syncthreads();
+    if (j < 5) {
+        float s = 0.f;
+        const int n = j == 2 ? 10 : 42;
+        for (int q = 0; q < n; ++q) s += acc[j][q];
+        if (j == 0) io.loss_batch[0 * B + b] = s / 84.f * w.joints_2d;
+        if (j == 1) io.loss_batch[1 * B + b] = s / 126.f * w.joints_3d;
+        if (j == 2) io.loss_batch[3 * B + b] = s;
+        if (j == 3) io.loss_batch[4 * B + b] = s / 84.f;
+        if (j == 4) io.loss_batch[5 * B + b] = s / 126.f;
+    }
+    // ---- translation loss (loss_utils.py:114-118) and the collision gradient scale
+    if (j == 5) {
+        const float* tp = io.init_hand_trans_j + b * 4;
+        const float* tg = io.gt_hand_trans + b * 4;
+        const float* tr = io.trans + b * 3;
+        float lp = 0.f, lg = 0.f;
+        const float st = w.trans / (float)(B * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float d = tp[k] - tr[k];
+            lp += d * d * tp[3];
+            wk.g_trans_direct[b * 3 + k] = -2.0f * st * d * tp[3];
+            const float dg = tg[k] - tr[k];
+            lg += dg * dg * tg[3];
+        }
+        io.loss_batch[6 * B + b] = lp / 3.f;
+        io.loss_batch[7 * B + b] = lg / 3.f;
+        const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
+        wk.gscale[b] = w.collision * mask / (4.0f * (float)B);
+    }
+}
+
+// Adds the direct (non-MANO) gradient terms, takes the snapshot (before the step, as
+// optimize_model.py:401-403) and applies torch.optim.Adam's single-tensor update.
+// grid = ceil(B*P/256); element (b, e): e < P, hand = e / D, d = e % D.
+__global__ void opt_adam_kernel(ihmr_opt_io io, OptWork wk, int B, int group, float w_shape_reg, float step_size,
+                                float bc2_sqrt, int snap_idx) {
+    const int P = group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
+    const int D = group == IHMR_GROUP_TRANS ? 3 : P / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * P) return;
+    const int b = idx / P, e = idx % P, hnd = e / D, d = e % D;
+    float* p;
+    float g;
+    if (group == IHMR_GROUP_TRANS) {
+        p = io.trans + b * 3 + d;
+        g = wk.g_trans[b * 3 + d] + wk.g_trans_direct[b * 3 + d];
+    } else if (group == IHMR_GROUP_ORIENT) {
+        p = io.orient + ((size_t)hnd * B + b) * 3 + d;
+        g = wk.g_orient[((size_t)hnd * B + b) * 3 + d];
+    } else if (group == IHMR_GROUP_POSE) {
+        p = io.pose + ((size_t)hnd * B + b) * 45 + d;
+        g = wk.g_pose[((size_t)hnd * B + b) * 45 + d];
+    } else {
+        p = io.shape + ((size_t)hnd * B + b) * 10 + d;
+        g = wk.g_shape[((size_t)hnd * B + b) * 10 + d];
+        // shape regulariser mean((beta_r - beta_l)^2) (loss_utils.py:121-128)
+        const float diff = io.shape[(size_t)b * 10 + d] - io.shape[((size_t)B + b) * 10 + d];
+        const float gr = 2.0f * w_shape_reg / (float)(B * 10) * diff;
+        g += hnd == 0 ? gr : -gr;
+    }
+    const float x = *p;
+    if (snap_idx >= 0) {
+        io.snap_params[((size_t)snap_idx * B + b) * OPT_PMAX + e] = x;
+        if (e == 0) {
+            io.snap_loss[((size_t)snap_idx * 2 + 0) * B + b] = io.loss_batch[1 * B + b];
+            io.snap_loss[((size_t)snap_idx * 2 + 1) * B + b] = io.loss_batch[2 * B + b];
+        }
+    }
+    float m = io.adam_m[b * OPT_PMAX + e], v = io.adam_v[b * OPT_PMAX + e];
+    m = m + 0.1f * (g - m);                  // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * 0.999f;                          // exp_avg_sq.mul_(beta2)
+    v = v + (0.001f * g) * g;                //            .addcmul_(grad, grad, value = 1 - beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + 1e-8f;
+    io.adam_m[b * OPT_PMAX + e] = m;
+    io.adam_v[b * OPT_PMAX + e] = v;
+    *p = x + (-step_size) * (m / denom);     // param.addcdiv_(exp_avg, denom, value = -step_size)
+}
+
+// utils/opt_utils.py:104-153: validity filter, 1e11 for invalid rows, row 0 restored, first argmin,
+// selected parameters written back.  grid = ceil(B/64), one thread per sample.
+__global__ void opt_select_kernel(ihmr_opt_io io, int B, int group, int S, float fac_j3d, float fac_coll,
+                                  int select_on_collision) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int P = group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
+    const int D = group == IHMR_GROUP_TRANS ? 3 : P / 2;
+    const float j0 = io.snap_loss[(size_t)0 * B + b], c0 = io.snap_loss[(size_t)1 * B + b];
+    const float bar_j = j0 * fac_j3d, bar_c = c0 * fac_coll;
+    int best = 0;
+    float best_v = select_on_collision ? c0 : j0;
+    for (int s = 1; s < S; ++s) {
+        const float js = io.snap_loss[((size_t)s * 2) * B + b], cs = io.snap_loss[((size_t)s * 2 + 1) * B + b];
+        const bool valid = (js <= bar_j) && (cs <= bar_c);
+        const float key = valid ? (select_on_collision ? cs : js) : 100000000000.0f;
+        if (key < best_v) { best_v = key; best = s; }
+    }
+    io.selected[b] = best;
+    for (int e = 0; e < P; ++e) {
+        const float x = io.snap_params[((size_t)best * B + b) * OPT_PMAX + e];
+        const int hnd = e / D, d = e % D;
+        if (group == IHMR_GROUP_TRANS) io.trans[b * 3 + d] = x;
+        else if (group == IHMR_GROUP_ORIENT) io.orient[((size_t)hnd * B + b) * 3 + d] = x;
+        else if (group == IHMR_GROUP_POSE) io.pose[((size_t)hnd * B + b) * 45 + d] = x;
+        else io.shape[((size_t)hnd * B + b) * 10 + d] = x;
+    }
+}

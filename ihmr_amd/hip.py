@@ -1,0 +1,155 @@
+"""ctypes binding of ``libihmr_hip.so`` (C ABI declared in ``include/ihmr_hip.h``).
+
+The library is the product: every compute entry point of this package goes through it and there is
+NO CPU fallback -- if the shared object is missing (and cannot be built with hipcc) or no GPU is
+visible, the calls raise.  PyTorch is used only for device memory and streams: tensors are passed as
+raw device pointers, the launch stream is ``torch.cuda.current_stream()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import os.path as osp
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = osp.dirname(osp.abspath(__file__))
+LIB_PATH = osp.join(_HERE, "libihmr_hip.so")
+SRC_DIR = osp.join(_HERE, "csrc")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"]
+
+NUM_VERTS, NUM_FACES, NUM_JOINTS, OPT_PMAX = 778, 1538, 16, 90
+GROUP_TRANS, GROUP_ORIENT, GROUP_POSE, GROUP_SHAPE = 0, 1, 2, 3
+
+# every symbol include/ihmr_hip.h declares (checked by the CPU test-suite against the built library)
+EXPORTED_SYMBOLS = [
+    "ihmr_mano_create", "ihmr_mano_destroy", "ihmr_mano_update_shapedirs", "ihmr_mano_lbs_fwd", "ihmr_mano_lbs_bwd",
+    "ihmr_sdf_workspace_bytes", "ihmr_sdf_collision", "ihmr_sdf_dense_grid", "ihmr_opt_workspace_bytes",
+    "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
+]
+
+
+class ManoArrays(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "parents",
+                                          "hands_mean", "faces", "tip_ids")]
+
+
+class OptIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "cam", "trans", "orient", "pose", "shape",
+        "init_joints_2d", "init_joints_3d", "init_hand_trans_j", "gt_joints_2d", "gt_joints_3d", "gt_hand_trans",
+        "hand_type_array",
+        "verts", "joints_3d", "joints_2d", "loss_batch", "coll_per_vert", "coll_origin_scale",
+        "snap_params", "snap_loss", "selected", "adam_m", "adam_v", "workspace")]
+
+
+class OptWeights(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("joints_2d", "joints_3d", "trans", "shape_reg", "collision", "finger_reg")]
+
+
+class KernelTimer(C.Structure):
+    _fields_ = [("ms_sdf_eval", C.c_double), ("n_sdf_eval", C.c_long), ("algo_flops_sdf_eval", C.c_double)]
+
+
+def sources():
+    return sorted(osp.join(SRC_DIR, f) for f in os.listdir(SRC_DIR) if f.endswith((".hip", ".h"))) + [
+        osp.join(osp.dirname(_HERE), "include", "ihmr_hip.h")]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc cross-compiles for gfx950 without a GPU (seconds)."""
+    if not force and osp.isfile(LIB_PATH) and all(osp.getmtime(LIB_PATH) >= osp.getmtime(s) for s in sources()):
+        return LIB_PATH
+    cmd = ["hipcc"] + HIPCC_FLAGS + [osp.join(SRC_DIR, "ihmr_hip.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    """Load (building on demand when hipcc is present).  Raises if unavailable -- never falls back."""
+    global _LIB
+    if _LIB is None:
+        if not osp.isfile(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        vp, i, f = C.c_void_p, C.c_int, C.c_float
+        L.ihmr_mano_create.argtypes = [C.POINTER(ManoArrays), C.POINTER(vp)]
+        L.ihmr_mano_destroy.argtypes = [vp]
+        L.ihmr_mano_update_shapedirs.argtypes = [vp, vp]
+        L.ihmr_mano_lbs_fwd.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp]
+        L.ihmr_mano_lbs_bwd.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, vp]
+        L.ihmr_sdf_workspace_bytes.argtypes = [i]
+        L.ihmr_sdf_workspace_bytes.restype = C.c_size_t
+        L.ihmr_sdf_collision.argtypes = [vp, vp, vp, i, f, vp, vp, vp, vp, vp, vp]
+        L.ihmr_sdf_dense_grid.argtypes = [vp, vp, vp, i, vp, vp, vp]
+        L.ihmr_opt_workspace_bytes.argtypes = [i]
+        L.ihmr_opt_workspace_bytes.restype = C.c_size_t
+        L.ihmr_opt_run_stage.argtypes = [vp, vp, C.POINTER(OptIO), i, i, C.POINTER(OptWeights), f, i, i, f, f, i, vp]
+        L.ihmr_opt_forward_losses.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), vp]
+        L.ihmr_set_kernel_timer.argtypes = [C.POINTER(KernelTimer)]
+        L.ihmr_flush_kernel_timer.argtypes = []
+        L.ihmr_version.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"libihmr_hip: {what} failed with code {rc}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("ihmr_amd needs an MI355X (gfx950) GPU: the hot path has no CPU fallback")
+
+
+def ptr(t: torch.Tensor | None):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class ManoHandle:
+    """Device-resident MANO constants (``ihmr_mano_create``)."""
+
+    def __init__(self, arrays: dict, tip_ids=(744, 320, 443, 554, 671)):
+        require_gpu()
+        self._keep = dict(
+            v_template=np.ascontiguousarray(arrays["v_template"], np.float32),
+            shapedirs=np.ascontiguousarray(arrays["shapedirs"], np.float32),
+            posedirs=np.ascontiguousarray(arrays["posedirs"], np.float32),
+            J_regressor=np.ascontiguousarray(arrays["J_regressor"], np.float32),
+            lbs_weights=np.ascontiguousarray(arrays["lbs_weights"], np.float32),
+            parents=np.ascontiguousarray(arrays["parents"], np.int32),
+            hands_mean=np.ascontiguousarray(arrays["hands_mean"], np.float32),
+            faces=np.ascontiguousarray(arrays["faces"], np.int32),
+            tip_ids=np.ascontiguousarray(tip_ids, np.int32),
+        )
+        a = ManoArrays(**{k: v.ctypes.data for k, v in self._keep.items()})
+        h = C.c_void_p()
+        check(lib().ihmr_mano_create(C.byref(a), C.byref(h)), "ihmr_mano_create")
+        self.handle = h
+
+    def update_shapedirs(self, shapedirs: np.ndarray):
+        sd = np.ascontiguousarray(shapedirs, np.float32)
+        check(lib().ihmr_mano_update_shapedirs(self.handle, sd.ctypes.data), "ihmr_mano_update_shapedirs")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib().ihmr_mano_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

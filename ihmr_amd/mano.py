@@ -1,0 +1,95 @@
+"""Seam A -- drop-in for ``smplx.create(model_path, 'mano', use_pca=False, is_rhand=..., batch_size=...)``
+as the reference calls it (``src/models/optimize_model.py:105-106``, ``baseline_model.py:141-142``,
+``mlp_model.py:108-109``).
+
+``MANO`` is an ``nn.Module`` exposing what the reference touches: ``.shapedirs`` (778,3,10) tensor that
+callers mutate in place (``optimize_model.py:109-113``), ``.faces`` (np.ndarray (1538,3)), ``.J_regressor``
+(16,778), ``.cuda()``, and ``__call__(global_orient=(N,3), hand_pose=(N,45), betas=(N,10))`` returning
+an object with ``.vertices (N,778,3)`` and ``.joints (N,16,3)``, differentiable w.r.t. all three
+inputs.  Forward and backward are the hand-written HIP kernels behind ``ihmr_mano_lbs_fwd`` /
+``ihmr_mano_lbs_bwd``; there is no PyTorch/CPU implementation here.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .assets import get_mano_arrays
+
+ManoOutput = namedtuple("ManoOutput", ["vertices", "joints", "betas", "global_orient", "hand_pose"])
+
+
+class _LbsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, orient, pose, betas, module):
+        hip.require_gpu()
+        orient, pose, betas = (t.contiguous().float() for t in (orient, pose, betas))
+        N = orient.shape[0]
+        dev = orient.device
+        verts = torch.empty(N, 778, 3, device=dev)
+        joints = torch.empty(N, 16, 3, device=dev)
+        v_posed = torch.empty(N, 778, 3, device=dev)
+        hip.check(hip.lib().ihmr_mano_lbs_fwd(module._handle().handle, hip.ptr(orient), hip.ptr(pose), hip.ptr(betas), N,
+                                              hip.ptr(verts), hip.ptr(joints), hip.ptr(v_posed), hip.stream_ptr()),
+                  "ihmr_mano_lbs_fwd")
+        ctx.save_for_backward(orient, pose, betas, v_posed)
+        ctx.module = module
+        return verts, joints
+
+    @staticmethod
+    def backward(ctx, d_verts, d_joints):
+        orient, pose, betas, v_posed = ctx.saved_tensors
+        N = orient.shape[0]
+        dev = orient.device
+        d_verts = torch.zeros(N, 778, 3, device=dev) if d_verts is None else d_verts.contiguous().float()
+        d_joints = torch.zeros(N, 16, 3, device=dev) if d_joints is None else d_joints.contiguous().float()
+        d_orient, d_pose, d_betas = torch.zeros_like(orient), torch.zeros_like(pose), torch.zeros_like(betas)
+        mask = (1 if ctx.needs_input_grad[0] else 0) | (2 if ctx.needs_input_grad[1] else 0) | (4 if ctx.needs_input_grad[2] else 0)
+        hip.check(hip.lib().ihmr_mano_lbs_bwd(ctx.module._handle().handle, hip.ptr(orient), hip.ptr(pose), hip.ptr(betas), N,
+                                              hip.ptr(v_posed), hip.ptr(d_verts), hip.ptr(d_joints), hip.ptr(d_orient),
+                                              hip.ptr(d_pose), hip.ptr(d_betas), mask, hip.stream_ptr()),
+                  "ihmr_mano_lbs_bwd")
+        return (d_orient if mask & 1 else None, d_pose if mask & 2 else None, d_betas if mask & 4 else None, None)
+
+
+class MANO(nn.Module):
+    def __init__(self, arrays: dict, is_rhand: bool = True, batch_size: int = 1):
+        super().__init__()
+        self.is_rhand = is_rhand
+        self.batch_size = batch_size
+        self._arrays = {k: np.array(v, copy=True) for k, v in arrays.items()}
+        self.faces = self._arrays["faces"].astype(np.int64)
+        self.register_buffer("shapedirs", torch.tensor(self._arrays["shapedirs"], dtype=torch.float32))
+        self.register_buffer("J_regressor", torch.tensor(self._arrays["J_regressor"], dtype=torch.float32))
+        self.register_buffer("v_template", torch.tensor(self._arrays["v_template"], dtype=torch.float32))
+        self.register_buffer("hand_mean", torch.tensor(self._arrays["hands_mean"], dtype=torch.float32))
+        self._dev_handle = None
+        self._shapedirs_version = None
+
+    def _handle(self) -> hip.ManoHandle:
+        """Device constants; re-uploaded when a caller has mutated ``.shapedirs`` in place."""
+        if self._dev_handle is None:
+            arrays = dict(self._arrays)
+            arrays["shapedirs"] = self.shapedirs.detach().cpu().numpy()
+            self._dev_handle = hip.ManoHandle(arrays)
+            self._shapedirs_version = self.shapedirs._version
+        elif self.shapedirs._version != self._shapedirs_version:
+            self._dev_handle.update_shapedirs(self.shapedirs.detach().cpu().numpy())
+            self._shapedirs_version = self.shapedirs._version
+        return self._dev_handle
+
+    def forward(self, betas=None, global_orient=None, hand_pose=None, **kwargs):
+        verts, joints = _LbsFunction.apply(global_orient, hand_pose, betas, self)
+        return ManoOutput(vertices=verts, joints=joints, betas=betas, global_orient=global_orient, hand_pose=hand_pose)
+
+
+def create(model_path, model_type="mano", use_pca=False, is_rhand=True, batch_size=1, **kwargs):
+    """Same call shape as ``smplx.create``; reads a real MANO pkl when ``model_path`` exists, otherwise
+    the deterministic synthetic asset (``ihmr_amd.assets``)."""
+    if model_type != "mano" or use_pca:
+        raise ValueError("only model_type='mano', use_pca=False is on the IHMR hot path")
+    return MANO(get_mano_arrays(model_path, is_rhand), is_rhand=is_rhand, batch_size=batch_size)

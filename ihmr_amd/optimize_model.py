@@ -1,0 +1,222 @@
+"""Seam C -- ``OptimizeModel``: IHMR-OPT on the fused HIP path, with the call surface of the reference's
+``src/models/optimize_model.py`` so that a loop written like ``src/optimize.py:61-71`` runs unchanged:
+
+    model = OptimizeModel(opt); model.set_input(data); model.init_optimize()
+    model.optimize(iter_id, num_iter); pred = model.get_pred_result()
+
+``opt`` is a plain namespace with the reference's option names (``options/base_options.py``,
+``opt_options.py``): ``batchSize, inputSize, num_joints, total_params_dim, cam_params_dim,
+pose_params_dim, shape_params_dim, trans_params_dim, model_root, strategy, save_mid_freq, optimizer,
+process_rank`` (+ ``opt_epoch`` to re-parameterise the per-stage iteration count).
+
+The whole refinement (MANO LBS forward/backward for 2B hands, joint / translation / finger / shape
+losses, sparse voxel-SDF collision, Adam, snapshots, filter + argmin select) runs in the kernels
+behind ``ihmr_opt_run_stage`` -- one C call per stage, no host synchronisation inside a stage and no
+GPU->CPU bounce like the reference's ``_finger_reg_loss`` (``loss_utils.py:155,164``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os.path as osp
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import hip
+from . import mano as mano_shim
+from .strategies import OPT_DEFAULT_LOSS_WEIGHTS, get_strategy
+
+_GROUPS = {
+    ("pred_hand_trans",): hip.GROUP_TRANS,
+    ("pred_left_orient", "pred_right_orient"): hip.GROUP_ORIENT,
+    ("pred_left_pose_params", "pred_right_pose_params"): hip.GROUP_POSE,
+    ("pred_left_shape_params", "pred_right_shape_params"): hip.GROUP_SHAPE,
+}
+
+
+def _filter_factor(criterion: str) -> float:
+    """utils/opt_utils.py:104-114: bar = origin * (1 + (float(c) + 0.1) / 100), evaluated in float32."""
+    assert criterion[0] in "+-"
+    return float(np.float32(1 + (float(criterion) + 0.1) / 100))
+
+
+def stage_to_args(stage):
+    names = tuple(sorted(stage["update_params"]))
+    if names not in _GROUPS:
+        raise ValueError(f"unsupported update_params {stage['update_params']}")
+    filt = dict(stage["filter_loss"])
+    for k in filt:
+        if k not in ("joints_3d_loss_p", "collision_loss"):
+            raise ValueError(f"unsupported filter loss {k}")
+    if stage["select_loss"] not in ("joints_3d_loss_p", "collision_loss"):
+        raise ValueError(f"unsupported select loss {stage['select_loss']}")
+    big = float(np.float32(3.0e38))  # "no filter on this loss"
+    return dict(group=_GROUPS[names],
+                fac_j3d=_filter_factor(filt["joints_3d_loss_p"]) if "joints_3d_loss_p" in filt else big,
+                fac_coll=_filter_factor(filt["collision_loss"]) if "collision_loss" in filt else big,
+                select_on_collision=int(stage["select_loss"] == "collision_loss"))
+
+
+def _weights(w) -> hip.OptWeights:
+    return hip.OptWeights(w["joints_2d_loss"], w["joints_3d_loss"], w["trans_loss_weight"], w["shape_reg_loss_weight"],
+                          w["collision_loss_weight"], w["finger_reg_loss_weight"])
+
+
+class OptimizeModel:
+    name = "OptimizeModel"
+
+    def __init__(self, opt):
+        hip.require_gpu()
+        self.opt = opt
+        self.process_rank = getattr(opt, "process_rank", -1)
+        self.inputSize = opt.inputSize
+        self.batch_size = opt.batchSize
+        assert opt.total_params_dim == opt.cam_params_dim + opt.trans_params_dim + opt.pose_params_dim + opt.shape_params_dim
+        assert getattr(opt, "optimizer", "adam") == "adam", "the fused refinement step implements Adam (the reference default)"
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.load_mano_model()
+        epoch = getattr(opt, "opt_epoch", None)
+        self.strategy = get_strategy(opt.strategy, epoch)
+        self.default_loss_weights = dict(OPT_DEFAULT_LOSS_WEIGHTS)
+        assert abs(self.default_loss_weights["collision_loss_weight"] - 1.0) < 1e-7  # optimize_model.py:93-94
+        self.save_mid_freq = getattr(opt, "save_mid_freq", 1)
+        self._alloc(self.batch_size)
+        self.selected_history = []
+
+    # optimize_model.py:97-117
+    def load_mano_model(self):
+        root = getattr(self.opt, "model_root", "") or ""
+        models = {}
+        for hand_type in ["left", "right"]:
+            f = osp.join(root, f"MANO_{hand_type.upper()}.pkl")
+            models[hand_type] = mano_shim.create(f, "mano", use_pca=False, is_rhand=(hand_type == "right"),
+                                                 batch_size=self.batch_size * 2)
+        diff = torch.mean(torch.abs(models["left"].shapedirs[:, 0, :] - models["right"].shapedirs[:, 0, :]))
+        if diff < 1e-7:
+            models["left"].shapedirs[:, 0, :] *= -1
+        self.mano_models = {k: m.to(self.device) for k, m in models.items()}
+
+    def _alloc(self, B):
+        dev = self.device
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        self.S_max = max(st["epoch"] // self.save_mid_freq + 1 for st in self.strategy)
+        self.buf = dict(
+            cam=z(B, 3), trans=z(B, 3), orient=z(2, B, 3), pose=z(2, B, 45), shape=z(2, B, 10),
+            init_joints_2d=z(B, 42, 3), init_joints_3d=z(B, 42, 4), init_hand_trans_j=z(B, 4),
+            gt_joints_2d=z(B, 42, 3), gt_joints_3d=z(B, 42, 4), gt_hand_trans=z(B, 4), hand_type_array=z(B, 2),
+            verts=z(2, B, 778, 3), joints_3d=z(B, 42, 3), joints_2d=z(B, 42, 2), loss_batch=z(8, B),
+            coll_per_vert=z(B, 1556), coll_origin_scale=z(B, 1556),
+            snap_params=z(self.S_max, B, hip.OPT_PMAX), snap_loss=z(self.S_max, 2, B),
+            selected=torch.zeros(B, device=dev, dtype=torch.int32), adam_m=z(B, hip.OPT_PMAX), adam_v=z(B, hip.OPT_PMAX),
+            workspace=torch.empty(hip.lib().ihmr_opt_workspace_bytes(B), device=dev, dtype=torch.uint8),
+        )
+        self.io = hip.OptIO(**{k: v.data_ptr() for k, v in self.buf.items()})
+        self.mano_params_weight = z(B, 2)
+        self.init = {}
+
+    # optimize_model.py:120-168
+    def set_input(self, input):
+        B = self.batch_size
+        dev = self.device
+        g = lambda k: input[k].to(dev, dtype=torch.float32, non_blocking=True)
+        assert input["init_cam"].shape[0] == B, "batch size is fixed at construction (opt.batchSize)"
+        self.buf["hand_type_array"].copy_(g("hand_type_array"))
+        self.buf["gt_joints_2d"].copy_(g("joints_2d"))
+        self.buf["gt_joints_3d"].copy_(g("joints_3d"))
+        self.buf["gt_hand_trans"].copy_(g("hand_trans").reshape(B, 4))
+        self.mano_params_weight.copy_(g("mano_params_weight"))
+        self.buf["init_joints_2d"].copy_(g("init_joints_2d"))
+        self.buf["init_joints_3d"].copy_(g("init_joints_3d"))
+        self.buf["init_hand_trans_j"].copy_(g("init_hand_trans_j").reshape(B, 4))
+        self.init = dict(cam=g("init_cam"), pose=g("init_pose_params"), shape=g("init_shape_params"),
+                         trans=g("init_hand_trans").reshape(B, -1)[:, :3])
+        self.gt_pose_params = g("mano_pose")
+        self.gt_shape_params = g("mano_betas")
+
+    # optimize_model.py:235-251
+    def init_optimize(self):
+        b, i = self.buf, self.init
+        b["cam"].copy_(i["cam"])
+        b["trans"].copy_(i["trans"])
+        b["orient"][0].copy_(i["pose"][:, 0:3])
+        b["orient"][1].copy_(i["pose"][:, 48:51])
+        b["pose"][0].copy_(i["pose"][:, 3:48])
+        b["pose"][1].copy_(i["pose"][:, 51:96])
+        b["shape"][0].copy_(i["shape"][:, :10])
+        b["shape"][1].copy_(i["shape"][:, 10:])
+
+    def _mano_handles(self):
+        return self.mano_models["right"]._handle().handle, self.mano_models["left"]._handle().handle
+
+    # optimize_model.py:254-330 with explicit weights (forward + __compute_loss)
+    def forward_losses(self, loss_weights=None):
+        w = _weights(loss_weights or self.default_loss_weights)
+        mr, ml = self._mano_handles()
+        hip.check(hip.lib().ihmr_opt_forward_losses(mr, ml, C.byref(self.io), self.batch_size, C.byref(w), hip.stream_ptr()),
+                  "ihmr_opt_forward_losses")
+
+    def run_stage(self, stage):
+        a = stage_to_args(stage)
+        w = _weights(stage["loss_weights"])
+        mr, ml = self._mano_handles()
+        hip.check(hip.lib().ihmr_opt_run_stage(mr, ml, C.byref(self.io), self.batch_size, a["group"], C.byref(w),
+                                               float(stage["lr"]), int(stage["epoch"]) + 1, int(self.save_mid_freq),
+                                               a["fac_j3d"], a["fac_coll"], a["select_on_collision"], hip.stream_ptr()),
+                  "ihmr_opt_run_stage")
+
+    # optimize_model.py:390-415
+    def optimize(self, iter_id=0, num_iter=1, verbose=False):
+        self.selected_history = []
+        for stage_id, stage in enumerate(self.strategy):
+            self.run_stage(stage)
+            self.selected_history.append(self.buf["selected"].clone())
+            if verbose and self.process_rank <= 0:
+                print(f"iter:{iter_id + 1:04d}/{num_iter:04d}, stage-{stage_id:02d} completes")
+                sys.stdout.flush()
+        self.forward_losses(self.default_loss_weights)
+
+    # reference-named views of the state
+    @property
+    def pred_cam_params(self): return self.buf["cam"]
+    @property
+    def pred_hand_trans(self): return self.buf["trans"].view(-1, 1, 3)
+    @property
+    def pred_shape_params(self): return torch.cat([self.buf["shape"][0], self.buf["shape"][1]], dim=1)
+    @property
+    def pred_pose_params(self):
+        b = self.buf
+        return torch.cat([b["orient"][0], b["pose"][0], b["orient"][1], b["pose"][1]], dim=1)
+    @property
+    def pred_right_hand_verts(self): return self.buf["verts"][0]
+    @property
+    def pred_left_hand_verts(self): return self.buf["verts"][1]
+    @property
+    def pred_joints_3d(self): return self.buf["joints_3d"]
+    @property
+    def pred_joints_2d(self): return self.buf["joints_2d"]
+    @property
+    def collision_loss_batch(self): return self.buf["loss_batch"][2]
+    @property
+    def collision_loss_origin_scale(self): return self.buf["coll_origin_scale"]
+    @property
+    def joints_3d_loss_p_batch(self): return self.buf["loss_batch"][1]
+
+    # optimize_model.py:418-435
+    def get_pred_result(self):
+        n = lambda t: t.detach().cpu().numpy()
+        return OrderedDict(
+            pred_cam_params=n(self.pred_cam_params), pred_hand_trans=n(self.pred_hand_trans),
+            pred_shape_params=n(self.pred_shape_params), pred_pose_params=n(self.pred_pose_params),
+            pred_right_hand_verts=n(self.pred_right_hand_verts), pred_left_hand_verts=n(self.pred_left_hand_verts),
+            mano_params_weight=n(self.mano_params_weight), pred_joints_3d=n(self.pred_joints_3d),
+            gt_joints_3d=n(self.buf["gt_joints_3d"]), collision_loss=n(self.collision_loss_batch),
+            collision_loss_origin_scale=n(self.collision_loss_origin_scale),
+            do_flip=np.zeros(self.batch_size).astype(np.int32), pred_hand_type=np.ones(self.batch_size).astype(np.int32))
+
+    # optimize_model.py:437-455 (means of the per-sample values)
+    def get_current_errors(self):
+        lb = self.buf["loss_batch"].mean(dim=1).cpu().numpy()
+        return OrderedDict(joints_2d_loss=float(lb[4]), joints_3d_loss=float(lb[5]) * 1000, hand_trans_loss=float(lb[7]) * 10,
+                           collision_loss=float(lb[2]), joints_3d_loss_p=float(lb[1]))

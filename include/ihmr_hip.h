@@ -1,0 +1,151 @@
+/*
+ * ihmr_hip.h -- C ABI of libihmr_hip.so, the MI355X (gfx950) implementation of the IHMR hot path.
+ *
+ * The reference (penincillin/IHMR) is pure Python and has NO native ABI of its own; its two native
+ * seams are third-party Python modules.  Each entry point below therefore cites the reference
+ * call site / Python interface it stands behind (file:line under /root/reference/src), and
+ * INTEGRATION.md shows the Python-side (ctypes) binding a maintainer would add.
+ *
+ * Conventions:
+ *   - extern "C", returns int: 0 = ok, otherwise a hipError_t value (or -1 for a bad argument);
+ *     never throws.
+ *   - every data pointer is a DEVICE pointer owned by the caller (PyTorch), row-major contiguous
+ *     fp32 unless stated; faces / ids are int32.
+ *   - asynchronous on the given hipStream_t (passed as void*); no allocation, no synchronisation,
+ *     graph-capture safe.  The only allocating calls are *_create / *_destroy (model constants).
+ *   - workspaces are caller-provided; their sizes come from the *_workspace_bytes queries.
+ */
+#ifndef IHMR_HIP_H
+#define IHMR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IHMR_NUM_VERTS 778
+#define IHMR_NUM_FACES 1538
+#define IHMR_NUM_JOINTS 16
+#define IHMR_NUM_TIPS 5
+#define IHMR_SDF_GRID 32
+
+/* ------------------------------------------------------------------ MANO model constants */
+/* HOST pointers; replaces the arrays smplx 0.1.28 `MANO.__init__` registers as buffers when the
+ * reference calls smplx.create(...) (models/optimize_model.py:105-106, baseline_model.py:141-142,
+ * mlp_model.py:108-109). */
+typedef struct ihmr_mano_arrays {
+    const float* v_template;   /* (778,3) */
+    const float* shapedirs;    /* (778,3,10) */
+    const float* posedirs;     /* (135, 2334): row = (joint-1)*9 + 3r + c, col = 3v + k */
+    const float* J_regressor;  /* (16,778) */
+    const float* lbs_weights;  /* (778,16) */
+    const int32_t* parents;    /* (16), parents[0] = -1 */
+    const float* hands_mean;   /* (45) */
+    const int32_t* faces;      /* (1538,3) */
+    const int32_t* tip_ids;    /* (5): optimize_model.py:99 [744,320,443,554,671] */
+} ihmr_mano_arrays;
+
+typedef struct ihmr_mano ihmr_mano;
+
+int ihmr_mano_create(const ihmr_mano_arrays* host, ihmr_mano** out);
+int ihmr_mano_destroy(ihmr_mano* m);
+/* callers mutate `.shapedirs` in place (optimize_model.py:109-113): re-upload (778,3,10) host data */
+int ihmr_mano_update_shapedirs(ihmr_mano* m, const float* shapedirs_host);
+
+/* ------------------------------------------------------------------ seam A: the MANO layer */
+/* forward of `mano_model(global_orient=(N,3), hand_pose=(N,45), betas=(N,10))`
+ * (optimize_model.py:194-198; smplx MANO.forward + lbs): verts (N,778,3), joints (N,16,3).
+ * v_posed_ws (N,778,3) is saved for the backward. */
+int ihmr_mano_lbs_fwd(const ihmr_mano* m, const float* orient, const float* pose, const float* betas, int N,
+                      float* verts, float* joints, float* v_posed_ws, void* stream);
+/* backward of the above: d_verts (N,778,3), d_joints (N,16,3) -> d_orient (N,3), d_pose (N,45),
+ * d_betas (N,10).  need_mask bit0 = orient, bit1 = pose, bit2 = betas. */
+int ihmr_mano_lbs_bwd(const ihmr_mano* m, const float* orient, const float* pose, const float* betas, int N,
+                      const float* v_posed_ws, const float* d_verts, const float* d_joints,
+                      float* d_orient, float* d_pose, float* d_betas, int need_mask, void* stream);
+
+/* ------------------------------------------------------------------ seam B: the collision module */
+/* `SDFLoss(faces_right, faces_left, robustifier)(hand_verts (B,2,778,3), return_per_vert_loss=True,
+ * return_origin_scale_loss=True)` (models/loss_utils.py:38,181-182).
+ * Outputs: loss (B), per_vert (B,1556), origin_scale (B,1556), dval (B,1556,3) = d per_vert / d(query
+ * vertex) (the query vertex of entry h*778+v is hand_verts[b, 1-h, v]).  robustifier <= 0 = off. */
+size_t ihmr_sdf_workspace_bytes(int B);
+int ihmr_sdf_collision(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
+                       float robustifier, float* loss, float* per_vert, float* origin_scale, float* dval,
+                       void* workspace, void* stream);
+/* diagnostic: dense phi grid (B,2,32,32,32) built with the product kernels (every voxel evaluated);
+ * compared bit-for-bit with the oracle's grid in tests. */
+int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
+                        float* phi, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ seam C: IHMR-OPT refinement */
+/* Everything OptimizeModel.optimize() touches per batch (models/optimize_model.py:120-168, 235-251,
+ * 390-415).  All device pointers, caller-owned.  Hand index 0 = right, 1 = left, in the reference's
+ * own (un-mirrored) parametrisation. */
+typedef struct ihmr_opt_io {
+    /* refined parameters (updated in place) */
+    float* cam;     /* (B,3)    pred_cam_params */
+    float* trans;   /* (B,3)    pred_hand_trans */
+    float* orient;  /* (2,B,3)  pred_{right,left}_orient */
+    float* pose;    /* (2,B,45) pred_{right,left}_pose_params */
+    float* shape;   /* (2,B,10) pred_{right,left}_shape_params */
+    /* targets (set_input) */
+    const float* init_joints_2d;    /* (B,42,3) */
+    const float* init_joints_3d;    /* (B,42,4) */
+    const float* init_hand_trans_j; /* (B,4) */
+    const float* gt_joints_2d;      /* (B,42,3) */
+    const float* gt_joints_3d;      /* (B,42,4) */
+    const float* gt_hand_trans;     /* (B,4) */
+    const float* hand_type_array;   /* (B,2) */
+    /* outputs of forward()/__compute_loss */
+    float* verts;        /* (2,B,778,3) final right / left vertices */
+    float* joints_3d;    /* (B,42,3) root-aligned twice, as get_pred_result exports (:428) */
+    float* joints_2d;    /* (B,42,2) projection taken before the alignment (:263) */
+    float* loss_batch;   /* (8,B): 0 joints_2d_loss_p, 1 joints_3d_loss_p (both x stage weight), 2 collision
+                            (masked, unweighted), 3 finger_reg, 4 gt joints_2d, 5 gt joints_3d, 6 trans_p, 7 gt trans */
+    float* coll_per_vert;     /* (B,1556) */
+    float* coll_origin_scale; /* (B,1556) */
+    /* snapshot ring (S_max, B, *) and stage selection */
+    float* snap_params;  /* (S_max, B, 90) active parameters, right hand first */
+    float* snap_loss;    /* (S_max, 2, B): joints_3d_loss_p_batch, collision_loss_batch */
+    int32_t* selected;   /* (B) argmin index of the last stage */
+    /* Adam state, zeroed by ihmr_opt_stage_begin */
+    float* adam_m;       /* (B,90) */
+    float* adam_v;       /* (B,90) */
+    void* workspace;     /* ihmr_opt_workspace_bytes(B) */
+} ihmr_opt_io;
+
+typedef struct ihmr_opt_weights { /* strategies/opt_default.py loss_weights */
+    float joints_2d, joints_3d, trans, shape_reg, collision, finger_reg;
+} ihmr_opt_weights;
+
+enum { IHMR_GROUP_TRANS = 0, IHMR_GROUP_ORIENT = 1, IHMR_GROUP_POSE = 2, IHMR_GROUP_SHAPE = 3, IHMR_GROUP_NONE = 4 };
+
+size_t ihmr_opt_workspace_bytes(int B);
+/* `m` = right-hand model (used for both hands, optimize_model.py:194); `m_left` supplies only the left
+ * faces for the collision term (loss_utils.py:34-38), NULL = use the right faces.
+ * one stage of optimize() (:393-407): `n_iters` = epoch+1 iterations of forward -> losses ->
+ * snapshot (every save_freq, before the step) -> backward -> Adam(lr, 0.9, 0.999, eps 1e-8).
+ * Then (:377-387) filter (loss <= origin * factor for both criteria) + per-sample argmin of the
+ * joints_3d_loss_p snapshots, and write the selected parameters back. */
+int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, int group,
+                       const ihmr_opt_weights* w, float lr, int n_iters, int save_freq, float filter_factor_j3d, float filter_factor_coll,
+                       int select_on_collision, void* stream);
+/* forward() + __compute_loss(weights) only (:413-414), no step */
+int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                            const ihmr_opt_weights* w, void* stream);
+
+/* per-kernel timing hook for bench.py: when non-NULL, the library records hipEvents around the
+ * dominant kernel on `stream` and accumulates (count, ms) here; host pointer, read after sync */
+typedef struct ihmr_kernel_timer { double ms_sdf_eval; long n_sdf_eval; double algo_flops_sdf_eval; } ihmr_kernel_timer;
+int ihmr_set_kernel_timer(ihmr_kernel_timer* t);
+int ihmr_flush_kernel_timer(void);
+
+const char* ihmr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IHMR_HIP_H */

@@ -1,0 +1,269 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes, ``ihmr_amd.hip``), against
+the CPU oracle on the same seeded inputs.  Tolerances are written next to each check.
+
+    python -m pytest tests -m gpu -x -q          (on the MI355X box)
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _report(name, got, ref, atol, rtol=0.0):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    err = np.abs(got - ref)
+    lim = atol + rtol * np.abs(ref)
+    worst = float((err - lim).max())
+    print(f"[parity] {name}: max|err|={err.max():.3e} max|ref|={np.abs(ref).max():.3e} (atol {atol:g}, rtol {rtol:g})")
+    assert worst <= 0, f"{name}: max err {err.max():.3e} exceeds tolerance (atol {atol}, rtol {rtol})"
+
+
+# ----------------------------------------------------------------------------------- seam A (MANO LBS)
+def _rand_mano_inputs(N, seed):
+    g = torch.Generator().manual_seed(seed)
+    orient = torch.randn(N, 3, generator=g) * 0.8
+    pose = torch.randn(N, 45, generator=g) * 0.3
+    betas = torch.randn(N, 10, generator=g) * 0.8
+    return orient, pose, betas
+
+
+def test_lbs_forward_matches_oracle(mano_arrays):
+    from ihmr_amd import mano
+    from oracle.mano_ref import ManoRef
+    right, _ = mano_arrays
+    N = 7
+    orient, pose, betas = _rand_mano_inputs(N, 0)
+    ref = ManoRef(right)(global_orient=orient, hand_pose=pose, betas=betas)
+    m = mano.MANO(right).to(_dev())
+    out = m(global_orient=orient.cuda(), hand_pose=pose.cuda(), betas=betas.cuda())
+    # metres; fp32 round-off of a ~0.2 m mesh -- 1e-6 is 5 ulp-ish, far inside the 1e-4 bar
+    _report("lbs verts", out.vertices.cpu(), ref.vertices, atol=2e-6)
+    _report("lbs joints", out.joints.cpu(), ref.joints, atol=2e-6)
+
+
+def test_lbs_zero_pose_is_template(mano_arrays):
+    """KAT: zero pose & betas with zero hands_mean => verts == v_template, joints == J_regressor v_template."""
+    from ihmr_amd import mano
+    right, _ = mano_arrays
+    arr = dict(right)
+    arr["hands_mean"] = np.zeros(45, np.float32)
+    m = mano.MANO(arr).to(_dev())
+    z = lambda d: torch.zeros(2, d, device=_dev())
+    out = m(global_orient=z(3), hand_pose=z(45), betas=z(10))
+    _report("template verts", out.vertices[0].cpu(), arr["v_template"], atol=1e-7)
+    _report("template joints", out.joints[0].cpu(), arr["J_regressor"] @ arr["v_template"], atol=1e-7)
+
+
+@pytest.mark.parametrize("which", ["orient", "pose", "betas", "all"])
+def test_lbs_backward_matches_autograd(mano_arrays, which):
+    from ihmr_amd import mano
+    from oracle.mano_ref import ManoRef
+    right, _ = mano_arrays
+    N = 5
+    orient, pose, betas = _rand_mano_inputs(N, 1)
+    g = torch.Generator().manual_seed(2)
+    gv = torch.randn(N, 778, 3, generator=g)
+    gj = torch.randn(N, 16, 3, generator=g)
+    need = dict(orient=which in ("orient", "all"), pose=which in ("pose", "all"), betas=which in ("betas", "all"))
+
+    def run(module, dev):
+        o, p, b = (t.clone().to(dev).requires_grad_(need[k]) for t, k in ((orient, "orient"), (pose, "pose"), (betas, "betas")))
+        out = module(global_orient=o, hand_pose=p, betas=b)
+        loss = (out.vertices * gv.to(dev)).sum() + (out.joints * gj.to(dev)).sum()
+        loss.backward()
+        return {k: (t.grad.cpu() if t.grad is not None else None) for k, t in (("orient", o), ("pose", p), ("betas", b))}
+
+    ref = run(ManoRef(right), "cpu")
+    got = run(mano.MANO(right).to(_dev()), _dev())
+    for k in ref:
+        if need[k]:
+            scale = float(ref[k].abs().max())
+            # gradients are sums over 778 vertices of O(1) terms: relative-to-max tolerance 2e-5
+            _report(f"lbs d{k} [{which}]", got[k], ref[k], atol=2e-5 * scale)
+
+
+# ----------------------------------------------------------------------------------- seam B (collision)
+def _two_hand_verts(mano_arrays, B, seed):
+    """(B,2,778,3) penetrating hand pairs from the oracle forward on the synthetic batch."""
+    from oracle.opt_ref import OptimizeRef
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    right, left = mano_arrays
+    orc = OptimizeRef(right, left, B, [], save_mid_freq=1)
+
+    def fwd(pose, shape, trans):
+        orc.pred_right_orient, orc.pred_left_orient = pose[:, :3], pose[:, 48:51]
+        orc.pred_right_pose_params, orc.pred_left_pose_params = pose[:, 3:48], pose[:, 51:]
+        orc.pred_right_shape_params, orc.pred_left_shape_params = shape[:, :10], shape[:, 10:]
+        orc.pred_hand_trans = trans.view(-1, 1, 3)
+        fwd.out = orc.get_mano_output()
+        return fwd.out[2]
+
+    batch = synthetic_opt_batch(B, fwd, seed=seed)
+    fwd(batch["init_pose_params"], batch["init_shape_params"], batch["init_hand_trans"][:, 0, :3])
+    rv, lv, _ = fwd.out
+    return torch.stack([rv, lv], dim=1).contiguous(), batch
+
+
+def test_sdf_dense_grid_bit_exact(mano_arrays):
+    """The product kernels evaluated on EVERY voxel reproduce the oracle's dense 32^3 grid bit for bit
+    (same operation order, contraction off) -- inside/outside decisions and distances alike."""
+    import ctypes as C
+    from ihmr_amd import hip
+    from oracle import sdf_ref
+    right, left = mano_arrays
+    B = 2
+    hv, _ = _two_hand_verts(mano_arrays, B, 77)
+    centre, scale = sdf_ref.hand_boxes(hv)
+    vn = (hv - centre) / scale
+    fr = torch.tensor(right["faces"].astype(np.int32))
+    fl = torch.tensor(left["faces"].astype(np.int32))
+    ref = torch.stack([sdf_ref.sdf_grid(vn[:, 0].contiguous(), fr), sdf_ref.sdf_grid(vn[:, 1].contiguous(), fl)], dim=1)
+    dev = _dev()
+    phi = torch.empty(B, 2, 32, 32, 32, device=dev)
+    ws = torch.empty(hip.lib().ihmr_sdf_workspace_bytes(B), dtype=torch.uint8, device=dev)
+    hip.check(hip.lib().ihmr_sdf_dense_grid(hip.ptr(fr.to(dev)), hip.ptr(fl.to(dev)), hip.ptr(hv.to(dev)), B, hip.ptr(phi),
+                                            hip.ptr(ws), hip.stream_ptr()), "dense_grid")
+    torch.cuda.synchronize()
+    got = phi.cpu()
+    n_in_ref, n_in_got = int((ref > 0).sum()), int((got > 0).sum())
+    mism = int(((ref > 0) != (got > 0)).sum())
+    print(f"[parity] dense grid: inside voxels ref={n_in_ref} got={n_in_got} inside/outside mismatches={mism} "
+          f"max|diff|={float((ref - got).abs().max()):.3e}")
+    assert mism == 0
+    assert torch.equal(ref, got), "phi grid differs from the oracle bit pattern"
+
+
+def test_sdf_collision_matches_oracle(mano_arrays):
+    from ihmr_amd.sdf import SDFLoss
+    from oracle.sdf_ref import SDFLossRef
+    right, left = mano_arrays
+    B = 6
+    hv, _ = _two_hand_verts(mano_arrays, B, 5)
+    ref_mod = SDFLossRef(right["faces"], left["faces"])
+    hv_ref = hv.clone().requires_grad_(True)
+    l_ref, pv_ref, os_ref = ref_mod(hv_ref, return_per_vert_loss=True, return_origin_scale_loss=True)
+    w = torch.linspace(0.5, 1.5, B)
+    (l_ref * w).sum().backward()
+
+    mod = SDFLoss(right["faces"], left["faces"]).to(_dev())
+    hv_g = hv.clone().to(_dev()).requires_grad_(True)
+    l, pv, os_ = mod(hv_g, return_per_vert_loss=True, return_origin_scale_loss=True)
+    (l * w.to(_dev())).sum().backward()
+    print("[parity] collision loss per sample (ref):", l_ref.detach().numpy().round(4))
+    assert int((pv_ref > 0).sum()) > 50, "test batch must actually penetrate"
+    # phi is bit-exact; the trilinear blend differs only by summation order: 1e-6 of a O(0.1) value
+    _report("sdf per_vert", pv.detach().cpu(), pv_ref.detach(), atol=1e-6)
+    _report("sdf origin_scale [m]", os_.detach().cpu(), os_ref.detach(), atol=1e-7)
+    _report("sdf loss", l.detach().cpu(), l_ref.detach(), atol=1e-5, rtol=1e-6)
+    _report("sdf d/dverts", hv_g.grad.cpu(), hv_ref.grad, atol=1e-4 * float(hv_ref.grad.abs().max()))
+
+
+def test_sdf_disjoint_hands_zero(mano_arrays):
+    from ihmr_amd.sdf import SDFLoss
+    right, left = mano_arrays
+    v = torch.tensor(right["v_template"])
+    far = v.clone()
+    far[:, 0] = -far[:, 0] - 0.5
+    hv = torch.stack([v, far])[None].to(_dev())
+    l, pv, os_ = SDFLoss(right["faces"], left["faces"]).to(_dev())(hv, return_per_vert_loss=True, return_origin_scale_loss=True)
+    assert float(l.abs().max()) == 0.0 and float(pv.abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------------- seam C (OPT loop)
+def _make_opt(B, strategy="opt_default", epoch=4, save_mid_freq=2):
+    import types
+    return types.SimpleNamespace(isTrain=False, dist=False, process_rank=-1, batchSize=B, inputSize=224, num_joints=42,
+                                 total_params_dim=122, cam_params_dim=3, pose_params_dim=96, shape_params_dim=20,
+                                 trans_params_dim=3, model_root="", strategy=strategy, save_mid_freq=save_mid_freq,
+                                 optimizer="adam", opt_epoch=epoch)
+
+
+def _oracle_and_model(mano_arrays, B, epoch, freq, seed=1234, record=True):
+    from ihmr_amd.optimize_model import OptimizeModel
+    from ihmr_amd.strategies import make_opt_strategy
+    from oracle.opt_ref import OptimizeRef
+    right, left = mano_arrays
+    _, batch = _two_hand_verts(mano_arrays, B, seed)
+    orc = OptimizeRef(right, left, B, make_opt_strategy(epoch), save_mid_freq=freq, record=record)
+    model = OptimizeModel(_make_opt(B, epoch=epoch, save_mid_freq=freq))
+    return orc, model, batch
+
+
+def test_opt_forward_losses_match_oracle(mano_arrays):
+    B = 4
+    orc, model, batch = _oracle_and_model(mano_arrays, B, 2, 1)
+    orc.set_input(batch); orc.init_optimize(); orc.forward(); orc.compute_loss(orc.default_loss_weights)
+    model.set_input(batch); model.init_optimize(); model.forward_losses()
+    torch.cuda.synchronize()
+    r, g = orc.get_pred_result(), model.get_pred_result()
+    _report("fwd right verts", g["pred_right_hand_verts"], r["pred_right_hand_verts"], atol=2e-6)
+    _report("fwd left verts", g["pred_left_hand_verts"], r["pred_left_hand_verts"], atol=2e-6)
+    _report("fwd joints_3d (aligned)", g["pred_joints_3d"], r["pred_joints_3d"], atol=2e-6)
+    _report("fwd joints_2d", model.pred_joints_2d.cpu(), orc.pred_joints_2d.detach(), atol=2e-5)
+    _report("collision_loss_batch", g["collision_loss"], r["collision_loss"], atol=1e-5, rtol=1e-5)
+    _report("collision origin scale", g["collision_loss_origin_scale"], r["collision_loss_origin_scale"], atol=1e-6)
+    _report("joints_3d_loss_p_batch", model.joints_3d_loss_p_batch.cpu(), orc.joints_3d_loss_p_batch.detach(), atol=1e-6, rtol=1e-4)
+    _report("finger_reg_batch", model.buf["loss_batch"][3].cpu(), orc.finger_reg_loss_batch.detach(), atol=1e-9, rtol=1e-3)
+    print("[parity] MPJPE-style joint delta (mm):", float(np.abs(g["pred_joints_3d"] - r["pred_joints_3d"]).max() * 1000))
+
+
+@pytest.mark.parametrize("stage_id", [0, 1, 2, 3])
+def test_opt_single_step_gradients(mano_arrays, stage_id):
+    """One iteration of one stage from identical state: Adam's first moment after step 1 is
+    0.1 * grad, so the analytic HIP gradient of the WHOLE loss is compared with autograd."""
+    from ihmr_amd.strategies import make_opt_strategy
+    B = 4
+    orc, model, batch = _oracle_and_model(mano_arrays, B, 0, 1)
+    stage = make_opt_strategy(0)[stage_id]
+    orc.strategy = [stage]
+    orc.set_input(batch); orc.init_optimize(); orc.optimize()
+    model.set_input(batch); model.init_optimize(); model.run_stage(stage)
+    torch.cuda.synchronize()
+    grads = orc.trace[0]["grads"]
+    names = sorted(stage["update_params"])  # left first, then right (or trans)
+    m = model.buf["adam_m"].cpu().numpy() / 0.1
+    if stage_id == 0:
+        got = {"pred_hand_trans": m[:, :3].reshape(B, 1, 3)}
+    else:
+        D = {1: 3, 2: 45, 3: 10}[stage_id]
+        got = {names[1]: m[:, :D], names[0]: m[:, D:2 * D]}  # right block first in the 90-vector
+    for n in names:
+        ref = grads[n]
+        scale = float(np.abs(ref).max())
+        _report(f"stage{stage_id} dL/d{n}", got[n], ref, atol=3e-4 * scale)
+
+
+def test_opt_trajectory_matches_oracle(mano_arrays):
+    """Full 4-stage refinement (5 iterations per stage, snapshot every 2): snapshots, selection indices
+    and exported results against the CPU oracle.  Adam normalises gradients, so per-step parameter
+    differences stay at fp32 round-off x lr; bars: parameters 2e-4 (lr 1e-2, 5 steps), vertices 1e-4 m,
+    per-vertex penetration depth 1e-4 m (BASELINE.json tolerance)."""
+    B, epoch, freq = 4, 4, 2
+    orc, model, batch = _oracle_and_model(mano_arrays, B, epoch, freq)
+    orc.set_input(batch); orc.init_optimize(); orc.optimize()
+    model.set_input(batch); model.init_optimize(); model.optimize()
+    torch.cuda.synchronize()
+    r, g = orc.get_pred_result(), model.get_pred_result()
+    sel_ref = np.stack(orc.selected)
+    sel_got = torch.stack(model.selected_history).cpu().numpy()
+    agree = float((sel_ref == sel_got).mean())
+    print(f"[parity] selection indices ref={sel_ref.tolist()} got={sel_got.tolist()} agreement={agree:.2f}")
+    assert agree == 1.0
+    _report("traj pose", g["pred_pose_params"], r["pred_pose_params"], atol=2e-4)
+    _report("traj shape", g["pred_shape_params"], r["pred_shape_params"], atol=2e-4)
+    _report("traj trans", g["pred_hand_trans"], r["pred_hand_trans"], atol=2e-5)
+    _report("traj right verts [m]", g["pred_right_hand_verts"], r["pred_right_hand_verts"], atol=1e-4)
+    _report("traj left verts [m]", g["pred_left_hand_verts"], r["pred_left_hand_verts"], atol=1e-4)
+    _report("traj joints [m]", g["pred_joints_3d"], r["pred_joints_3d"], atol=1e-4)
+    _report("traj penetration depth [m]", g["collision_loss_origin_scale"], r["collision_loss_origin_scale"], atol=1e-4)
+    mean_pen_ref = float(r["collision_loss_origin_scale"].mean())
+    mean_pen_got = float(g["collision_loss_origin_scale"].mean())
+    print(f"[parity] mean penetration depth ref={mean_pen_ref:.6e} got={mean_pen_got:.6e}")
+    assert abs(mean_pen_ref - mean_pen_got) < 1e-4
