@@ -128,7 +128,8 @@ def test_sdf_dense_grid_bit_exact(mano_arrays):
     dev = _dev()
     phi = torch.empty(B, 2, 32, 32, 32, device=dev)
     ws = torch.empty(hip.lib().ihmr_sdf_workspace_bytes(B), dtype=torch.uint8, device=dev)
-    hip.check(hip.lib().ihmr_sdf_dense_grid(hip.ptr(fr.to(dev)), hip.ptr(fl.to(dev)), hip.ptr(hv.to(dev)), B, hip.ptr(phi),
+    fr_d, fl_d, hv_d = fr.to(dev), fl.to(dev), hv.to(dev)  # keep the device buffers alive across the async call
+    hip.check(hip.lib().ihmr_sdf_dense_grid(hip.ptr(fr_d), hip.ptr(fl_d), hip.ptr(hv_d), B, hip.ptr(phi),
                                             hip.ptr(ws), hip.stream_ptr()), "dense_grid")
     torch.cuda.synchronize()
     got = phi.cpu()
