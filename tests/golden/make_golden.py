@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE ITSELF
+(``/root/reference/src``, imported with CPU stubs -- see ``_ref_import.py``) in the build container.
+
+    python tests/golden/make_golden.py        # writes tests/golden/*.npz  (small, committed)
+
+Only inputs and expected outputs are stored -- no reference source text.  The reference cannot run
+its two third-party seams (``smplx`` MANO layer, ``sdf`` collision module: absent, see SURVEY.md
+8(c)); there this build's CPU restatements (``oracle/mano_ref.py``, ``oracle/sdf_ref.py``) are
+injected, so the fixtures pin everything AROUND those seams: loss terms and their gradients,
+Rodrigues / projection, snapshot filter + select, the full ``OptimizeModel.optimize()`` trajectory
+logic, the ResNet-50 encoder + IEF head, the MLP refinement head, and the evaluator metrics.
+"""
+import os
+import os.path as osp
+import sys
+
+HERE = osp.dirname(osp.abspath(__file__))
+ROOT = osp.dirname(osp.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.path.insert(0, osp.dirname(HERE))
+
+import numpy as np
+import torch
+
+from _ref_import import import_reference, make_opt
+
+
+def t2n(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def gen_losses(ns):
+    """LossUtil._* on random B=4 inputs, values + gradients (loss_utils.py)."""
+    B = 4
+    g = torch.Generator().manual_seed(11)
+    opt = make_opt(B)
+    lu = ns.loss_utils.LossUtil(opt, _mano_models(ns, B))
+    out = {}
+    R = lambda *s: torch.randn(*s, generator=g)
+    # joints 2d
+    gt2, pr2 = R(B, 42, 2), R(B, 42, 2).requires_grad_(True)
+    w2 = (torch.rand(B, 42, 1, generator=g) > 0.2).float()
+    l, lb = lu._joints_2d_loss(gt2, pr2, w2)
+    l.backward()
+    out.update(j2d_gt=gt2, j2d_pred=pr2, j2d_w=w2, j2d_loss=l, j2d_loss_batch=lb, j2d_grad=pr2.grad)
+    # joints 3d with the three alignment cases: right present / absent / in-between weight
+    gt3 = R(B, 42, 3) * 0.1
+    pr3_in = (R(B, 42, 3) * 0.1)
+    w3 = (torch.rand(B, 42, 1, generator=g) > 0.2).float()
+    w3[0, 0, 0], w3[1, 0, 0], w3[2, 0, 0], w3[3, 0, 0] = 1.0, 0.0, 0.3, 1.0
+    leaf = pr3_in.clone().requires_grad_(True)
+    pr3 = leaf * 1.0
+    gt3c = gt3.clone()
+    l, lb = lu._joints_3d_loss(gt3c, pr3, w3)
+    l.backward()
+    out.update(j3d_gt=gt3, j3d_pred=pr3_in, j3d_w=w3, j3d_loss=l, j3d_loss_batch=lb, j3d_grad=leaf.grad,
+               j3d_gt_aligned=gt3c, j3d_pred_aligned=pr3)
+    # hand trans
+    gtt, prt = R(B, 1, 3) * 0.05, (R(B, 1, 3) * 0.05).requires_grad_(True)
+    wt = torch.tensor([1.0, 0.0, 1.0, 1.0]).view(B, 1, 1)
+    l = lu._hand_trans_loss(gtt, prt, wt)
+    l.backward()
+    out.update(tr_gt=gtt, tr_pred=prt, tr_w=wt, tr_loss=l, tr_grad=prt.grad)
+    # shape reg
+    sh = R(B, 20).requires_grad_(True)
+    l = lu._shape_reg_loss(sh)
+    l.backward()
+    out.update(sh=sh, sh_loss=l, sh_grad=sh.grad)
+    # finger reg
+    j = (R(B, 42, 3) * 0.05).requires_grad_(True)
+    l, lb = lu._finger_reg_loss(j)
+    l.backward()
+    out.update(fin_j=j, fin_loss=l, fin_loss_batch=lb, fin_grad=j.grad)
+    # train-only losses on the path's "next" list: values only
+    mp, pmp = R(B, 48) * 0.4, R(B, 48) * 0.4
+    wmp = torch.tensor([1.0, 1.0, 0.0, 1.0]).view(B, 1)
+    out.update(mp=mp, pmp=pmp, wmp=wmp, mano_pose_loss=lu._mano_pose_loss(mp, pmp, wmp),
+               mano_shape_loss=lu._mano_shape_loss(sh.detach()[:, :10], sh.detach()[:, 10:], wmp),
+               shape_residual_loss=lu._shape_residual_loss(sh.detach(), sh.detach() * 0.5))
+    ht_gt = (torch.rand(B, 2, generator=g) > 0.5).float()
+    ht_pr = torch.rand(B, 2, generator=g) * 0.98 + 0.01
+    out.update(ht_gt=ht_gt, ht_pred=ht_pr, ht_valid=torch.tensor([1.0, 1.0, 0.0, 1.0]).view(B, 1),
+               hand_type_loss=lu._hand_type_loss(ht_gt, ht_pr, torch.tensor([1.0, 1.0, 0.0, 1.0]).view(B, 1)))
+    # transforms
+    rv = R(10, 3)
+    rv[0] = 0.0
+    cam = torch.cat([torch.rand(B, 1, generator=g) * 5 + 1, R(B, 2) * 0.1], 1)
+    X = R(B, 42, 3) * 0.1
+    out.update(rod_in=rv, rod_out=ns.transform_utils.batch_rodrigues(_with_device(rv)), proj_X=X, proj_cam=cam,
+               proj_out=ns.transform_utils.batch_orthogonal_project(X, cam))
+    np.savez_compressed(osp.join(HERE, "losses.npz"), **t2n(out))
+    print("losses.npz", len(out), "arrays")
+
+
+def _with_device(t):
+    """reference batch_rodrigues calls ``pose_params.get_device()`` inside ``torch.cuda.device(...)``:
+    on CPU get_device() is -1; make the context manager a no-op for the call."""
+    import contextlib
+    torch.cuda.device = lambda *a, **k: contextlib.nullcontext()
+    return t
+
+
+def _mano_models(ns, B):
+    import smplx
+    models = {h: smplx.create("", "mano", use_pca=False, is_rhand=(h == "right"), batch_size=2 * B) for h in ("left", "right")}
+    return models
+
+
+def gen_select(ns):
+    """filter_by_losses + select_params on random (S=7, B=6) tables incl. ties and the no-candidate case."""
+    S, B = 7, 6
+    g = torch.Generator().manual_seed(5)
+    j3d = torch.rand(S, B, generator=g) + 0.5
+    col = torch.rand(S, B, generator=g) + 0.5
+    j3d[:, 0] = j3d[0, 0] * 2            # sample 0: nothing passes the filter -> index 0
+    j3d[3, 1] = j3d[5, 1] = 0.01         # sample 1: exact tie between rows 3 and 5
+    col[1:, 1] = col[0, 1] * 0.5
+    col[:, 2] = 0.0                      # sample 2: zero collision everywhere (0 <= 0 * 0.901 passes)
+    j3d[4, 3] = j3d[0, 3] * 1.0005       # sample 3: inside the +0.1 % band
+    col[4, 3] = col[0, 3] * 0.85
+    params = {"pred_left_pose_params": torch.randn(S, B, 45, generator=g), "pred_right_pose_params": torch.randn(S, B, 45, generator=g)}
+    out = dict(j3d=j3d.clone(), col=col.clone(), **{k: v.clone() for k, v in params.items()})
+    for tag, filt, sel in (("a", [("joints_3d_loss_p", "+0"), ("collision_loss", "-10")], "joints_3d_loss_p"),
+                           ("b", [("joints_3d_loss_p", "+0"), ("collision_loss", "+0")], "collision_loss")):
+        losses = {"joints_3d_loss_p": j3d.clone(), "collision_loss": col.clone()}
+        upd = ns.opt_utils.filter_by_losses(losses, filt)
+        selp = ns.opt_utils.select_params({k: v.clone() for k, v in params.items()}, upd, sel)
+        out[f"{tag}_filtered_j3d"] = upd["joints_3d_loss_p"]
+        out[f"{tag}_filtered_col"] = upd["collision_loss"]
+        out[f"{tag}_idx"] = torch.argmin(upd[sel], dim=0)
+        for k, v in selp.items():
+            out[f"{tag}_{k}"] = v
+    np.savez_compressed(osp.join(HERE, "select.npz"), **t2n(out))
+    print("select.npz")
+
+
+def gen_opt_traj(ns):
+    """Full reference OptimizeModel.optimize() on the synthetic asset: B=3, 4 stages x 4 iterations,
+    snapshot every 2.  Stores the input batch, per-stage selected parameters and the final export."""
+    from ihmr_amd.strategies import make_opt_strategy
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    from oracle.opt_ref import OptimizeRef
+    from ihmr_amd.assets import synthetic_mano
+    B, epoch, freq = 3, 3, 2
+    ns.strategies.strategies["golden_small"] = make_opt_strategy(epoch)
+    ns.optimize_model.strategies["golden_small"] = ns.strategies.strategies["golden_small"]
+    opt = make_opt(B, strategy="golden_small", save_mid_freq=freq)
+    ref = ns.optimize_model.OptimizeModel(opt)
+    helper = OptimizeRef(synthetic_mano(True), synthetic_mano(False), B, [], save_mid_freq=1)
+
+    def fwd(pose, shape, trans):
+        helper.pred_right_orient, helper.pred_left_orient = pose[:, :3], pose[:, 48:51]
+        helper.pred_right_pose_params, helper.pred_left_pose_params = pose[:, 3:48], pose[:, 51:]
+        helper.pred_right_shape_params, helper.pred_left_shape_params = shape[:, :10], shape[:, 10:]
+        helper.pred_hand_trans = trans.view(-1, 1, 3)
+        return helper.get_mano_output()[2]
+
+    batch = synthetic_opt_batch(B, fwd, seed=2024)
+    # exercise the "no right wrist" alignment branch on the last sample (weights of joint 0 = 0)
+    batch["init_joints_3d"][2, 0, 3] = 0.0
+    batch["joints_3d"][2, 0, 3] = 0.0
+    ref.set_input(batch)
+    ref.init_optimize()
+    ref.optimize(0, 1)
+    res = ref.get_pred_result()
+    out = {f"in_{k}": v for k, v in batch.items()}
+    out.update({f"out_{k}": v for k, v in res.items()})
+    out["out_pred_joints_2d"] = ref.pred_joints_2d.detach()
+    out["out_joints_3d_loss_p_batch"] = ref.joints_3d_loss_p_batch.detach()
+    out["out_joints_2d_loss_p_batch"] = ref.joints_2d_loss_p_batch.detach()
+    out["out_loss"] = ref.loss.detach()
+    out["meta_epoch_freq"] = np.array([epoch, freq])
+    np.savez_compressed(osp.join(HERE, "opt_traj.npz"), **t2n(out))
+    print("opt_traj.npz", {k: np.asarray(v).shape for k, v in res.items() if k.startswith("pred_")})
+
+
+from helpers import seeded_state_dict  # tests/helpers.py (shared with the tests)
+
+
+def gen_encoder(ns):
+    """InterHandEncoder (ResNet-50 trunk + fc + IEF regressor + hand classifier, networks.py:45-80,
+    resnet.py:97-156) in eval mode on a seeded 2 x 3 x 224 x 224 image with a seeded state_dict."""
+    ns.networks.get_model = lambda arch: getattr(ns.resnet, arch)(pretrained=False, num_classes=512)
+    opt = make_opt(2)
+    rng = np.random.RandomState(3)
+    mean_params = torch.tensor(rng.normal(0, 0.2, (1, 122)), dtype=torch.float32)
+    mean_params[0, 0] = 5.0
+    enc = ns.networks.InterHandEncoder(opt, mean_params.repeat(2, 1))
+    enc.load_state_dict(seeded_state_dict(enc, 100))
+    enc.eval()
+    img = torch.tensor(np.random.RandomState(7).uniform(-1, 1, (2, 3, 224, 224)), dtype=torch.float32)
+    with torch.no_grad():
+        feat = enc.main_encoder(img)
+        params, hand_class = enc(img)
+        x = enc.main_encoder.maxpool(enc.main_encoder.relu(enc.main_encoder.bn1(enc.main_encoder.conv1(img))))
+        l1 = enc.main_encoder.layer1(x)
+    out = dict(mean_params=mean_params, main_feat=feat, params=params, hand_class=hand_class,
+               stem_sample=x[:, :, ::8, ::8], layer1_sample=l1[:, ::16, ::8, ::8],
+               state_keys=np.array(list(enc.state_dict().keys())))
+    np.savez_compressed(osp.join(HERE, "encoder.npz"), **t2n(out))
+    print("encoder.npz", params.shape, hand_class)
+
+
+def gen_mlp_head(ns):
+    """InterHandSubNetwork (networks.py:83-105) with seeded weights on a seeded input."""
+    opt = make_opt(3)
+    out = {}
+    for k in (3, 90):
+        net = ns.networks.InterHandSubNetwork(opt, 1024 + 122, k)
+        net.load_state_dict(seeded_state_dict(net, 500 + k))
+        x = torch.tensor(np.random.RandomState(9 + k).normal(0, 0.5, (3, 1146)), dtype=torch.float32)
+        with torch.no_grad():
+            out[f"x_{k}"] = x
+            out[f"y_{k}"] = net(x.clone())
+    np.savez_compressed(osp.join(HERE, "mlp_head.npz"), **t2n(out))
+    print("mlp_head.npz")
+
+
+def gen_metrics(ns):
+    """metric_utils.get_single_joints_error / get_single_pa_inter_joints_error (no rotation) and the
+    evaluator's collision statistics on seeded predictions."""
+    rng = np.random.RandomState(21)
+    mu = ns.metric_utils
+    out = {}
+    for i in range(4):
+        pred = rng.normal(0, 0.05, (42, 3)).astype(np.float32)
+        gt = (pred + rng.normal(0, 0.01, (42, 3))).astype(np.float32)
+        valid = (rng.uniform(size=(42, 1)) > 0.15).astype(np.float32)
+        if i == 1:
+            valid[0] = 0.0      # right wrist missing
+        if i == 2:
+            valid[21] = 0.0     # left wrist missing
+        scale = [1.0, 1.0, 0.8, 1.3][i]
+        out[f"pred_{i}"], out[f"gt_{i}"], out[f"valid_{i}"], out[f"scale_{i}"] = pred, gt, valid, np.float32(scale)
+        out[f"j3d_err_{i}"] = np.array(mu.get_single_joints_error(pred, gt, valid, scale), dtype=np.float64)
+        out[f"pa_err_{i}"] = np.array(mu.get_single_pa_inter_joints_error(pred, gt, valid, scale, use_rot=False), dtype=np.float64)
+    np.savez_compressed(osp.join(HERE, "metrics.npz"), **out)
+    print("metrics.npz")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ns = import_reference()
+    which = sys.argv[1:] or ["losses", "select", "opt_traj", "encoder", "mlp_head", "metrics"]
+    for w in which:
+        globals()[f"gen_{w}"](ns)
