@@ -148,6 +148,9 @@ class ManoHandle:
 
     def __del__(self):
         try:
+            import sys
+            if sys is None or sys.is_finalizing():
+                return  # the HIP runtime may already be gone at interpreter shutdown
             if getattr(self, "handle", None):
                 lib().ihmr_mano_destroy(self.handle)
                 self.handle = None
