@@ -136,16 +136,24 @@ def main():
     # gathered in an untimed replay of the same workload (see DESIGN.md "Measurement")
     roofline = None
     if rank == 0:
-        stats = model.collect_sdf_stats(batch) if hasattr(model, "collect_sdf_stats") else None
+        # counters at the end state and at the initial state of the refinement, averaged
+        st_end = model.collect_sdf_stats()
+        model.set_input(batch)
+        model.init_optimize()
+        st_ini = model.collect_sdf_stats()
+        stats = {k: 0.5 * (st_ini[k] + st_end[k]) for k in st_ini}
+        # flops per unit of work (DESIGN.md "Measurement"): ray test 11, exact point-triangle distance 75,
+        # per inside voxel 2 sphere passes x 1538 triangles x 9
+        stats["flops_per_launch"] = 11.0 * stats["ray_tests"] + 75.0 * stats["dist_evals"] + 2 * 1538 * 9.0 * stats["inside_voxels"]
         avg_ms = timer.ms_sdf_eval / max(timer.n_sdf_eval, 1)
-        if stats is not None and avg_ms > 0:
+        if avg_ms > 0:
             flops = stats["flops_per_launch"]
             ach = flops / (avg_ms * 1e-3) / 1e12
             roofline = dict(bound="mfma", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS,
                             traffic=None, kernel="sdf_eval_kernel", avg_launch_ms=avg_ms, launches=int(timer.n_sdf_eval),
                             note="fp32 VALU kernel (no GEMM shape): priced against the fp32 peak, which is the same "
                                  "157.3 TFLOP/s for vector and f32-input MFMA on gfx950",
-                            algorithmic_flops_per_launch=flops)
+                            algorithmic_flops_per_launch=flops, work_per_launch=stats)
         else:
             roofline = dict(bound="mfma", achieved=None, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=None, traffic=None,
                             kernel="sdf_eval_kernel", avg_launch_ms=avg_ms, launches=int(timer.n_sdf_eval))

@@ -11,6 +11,7 @@
 #define NV3 (NV * 3)           // 2334
 #define NPF 135                // pose-feature length (15 joints x 9)
 #define NFP 1600               // faces padded to a multiple of 64 (SoA row length)
+#define NVP 832                // vertices padded to a multiple of 64 (float4 basis rows)
 #define SDF_G IHMR_SDF_GRID    // 32
 #define SDF_NVOX (SDF_G * SDF_G * SDF_G)
 #define WAVE 64
@@ -29,6 +30,9 @@ struct ihmr_mano {
     float* v_template;    // [2334]
     float* shapedirs_t;   // [10][2334]
     float* posedirs;      // [135][2334]
+    float4* pd4;          // [135][NVP]  posedirs as (x,y,z,0) per vertex: one coalesced 16 B load per lane
+    float4* sd4;          // [10][NVP]   shapedirs likewise
+    float4* vt4;          // [NVP]       v_template likewise
     float* J_template;    // [48]   = J_regressor . v_template
     float* J_shapedirs;   // [48][10] = J_regressor . shapedirs
     float* weights;       // [778][16]

@@ -44,6 +44,20 @@ static void derive_shape_constants(const float* Jreg, const float* v_template, c
         }
 }
 
+static void pack4(const float* src_rows /*[rows][2334]*/, int rows, std::vector<float>& dst) {
+    dst.assign((size_t)rows * NVP * 4, 0.f);
+    for (int r = 0; r < rows; ++r)
+        for (int v = 0; v < NV; ++v)
+            for (int k = 0; k < 3; ++k) dst[((size_t)r * NVP + v) * 4 + k] = src_rows[(size_t)r * NV3 + 3 * v + k];
+}
+
+template <typename T>
+static int upload_as(T** dst, const std::vector<float>& src) {
+    HIP_TRY(hipMalloc((void**)dst, src.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
 extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
     if (!h || !out) return -1;
     ihmr_mano* m = new ihmr_mano();
@@ -75,7 +89,12 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
             if (id < 0 || id >= NV) { delete m; return -1; }
             fsoa[(size_t)k * NFP + f] = id;
         }
+    std::vector<float> pd4, sd4, vt4;
+    pack4(pd.data(), NPF, pd4);
+    pack4(sd_t.data(), 10, sd4);
+    pack4(vt.data(), 1, vt4);
     int rc = 0;
+    rc |= upload_as(&m->pd4, pd4); rc |= upload_as(&m->sd4, sd4); rc |= upload_as(&m->vt4, vt4);
     rc |= upload(&m->v_template, vt); rc |= upload(&m->shapedirs_t, sd_t); rc |= upload(&m->posedirs, pd);
     rc |= upload(&m->J_template, J_t); rc |= upload(&m->J_shapedirs, J_sd); rc |= upload(&m->weights, wts);
     rc |= upload(&m->pose_mean, pm); rc |= upload(&m->parents, par); rc |= upload(&m->depth, depth);
@@ -91,7 +110,7 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
 extern "C" int ihmr_mano_destroy(ihmr_mano* m) {
     if (!m) return 0;
     void* ptrs[] = {m->v_template, m->shapedirs_t, m->posedirs, m->J_template, m->J_shapedirs, m->weights, m->pose_mean,
-                    m->parents, m->depth, m->tip_ids, m->wj_start, m->wj_vert, m->wj_w, m->faces, m->J_regressor};
+                    m->parents, m->depth, m->tip_ids, m->wj_start, m->wj_vert, m->wj_w, m->faces, m->J_regressor, m->pd4, m->sd4, m->vt4};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -106,36 +125,77 @@ extern "C" int ihmr_mano_update_shapedirs(ihmr_mano* m, const float* shapedirs_h
     derive_shape_constants(jr.data(), vt.data(), shapedirs_host, sd_t, J_t, J_sd);
     HIP_TRY(hipMemcpy(m->shapedirs_t, sd_t.data(), sd_t.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->J_shapedirs, J_sd.data(), J_sd.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> sd4;
+    pack4(sd_t.data(), 10, sd4);
+    HIP_TRY(hipMemcpy(m->sd4, sd4.data(), sd4.size() * 4, hipMemcpyHostToDevice));
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------ seam A
+extern "C" size_t ihmr_mano_workspace_bytes(int N) { return lbs_ws_bytes(N); }
+
+static void lbs_forward_launch(const ihmr_mano* m, bool two_hand, const float* orient, const float* pose, const float* betas,
+                               const float* trans, int N, int B, float* verts, float* joints, const LbsWork& wk, hipStream_t st) {
+    const dim3 skin_grid(4, (N + LBS_HG - 1) / LBS_HG);
+    if (two_hand) {
+        hipLaunchKernelGGL(lbs_skel_kernel<true>, dim3(N), dim3(192), 0, st, *m, orient, pose, betas, trans, B, wk.skel, joints);
+        hipLaunchKernelGGL(lbs_skin_kernel<true>, skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
+                           joints, wk.v_posed);
+    } else {
+        hipLaunchKernelGGL(lbs_skel_kernel<false>, dim3(N), dim3(192), 0, st, *m, orient, pose, betas, trans, B, wk.skel, joints);
+        hipLaunchKernelGGL(lbs_skin_kernel<false>, skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
+                           joints, wk.v_posed);
+    }
+}
+
+static void lbs_backward_launch(const ihmr_mano* m, bool two_hand, int N, int B, const float* d_verts, const float* d_joints,
+                                float* d_orient, float* d_pose, float* d_betas, float* d_trans, int need_mask, const LbsWork& wk,
+                                hipStream_t st) {
+    if (two_hand)
+        hipLaunchKernelGGL(lbs_bwd1_kernel<true>, dim3(N), dim3(LBS_THREADS), 0, st, *m, wk, B, d_verts, d_joints, d_orient,
+                           d_betas, d_trans, need_mask);
+    else
+        hipLaunchKernelGGL(lbs_bwd1_kernel<false>, dim3(N), dim3(LBS_THREADS), 0, st, *m, wk, B, d_verts, d_joints, d_orient,
+                           d_betas, d_trans, need_mask);
+    if (need_mask & 2) {
+        const size_t lds = (size_t)(NPF * (LBS_CHUNK + 1) + LBS_HG * LBS_CHUNK) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {  // 110 KB of the CU's 160 KB LDS: above the default dynamic-LDS cap
+            (void)hipFuncSetAttribute((const void*)lbs_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(lbs_bwd2_kernel, dim3(LBS_NCHUNK, (N + LBS_HG - 1) / LBS_HG), dim3(LBS_THREADS), lds, st, *m, wk, N);
+        if (two_hand) hipLaunchKernelGGL(lbs_bwd3_kernel<true>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
+        else hipLaunchKernelGGL(lbs_bwd3_kernel<false>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
+    }
+}
+
 extern "C" int ihmr_mano_lbs_fwd(const ihmr_mano* m, const float* orient, const float* pose, const float* betas, int N,
-                                 float* verts, float* joints, float* v_posed_ws, void* stream) {
-    if (!m || N <= 0) return -1;
-    hipLaunchKernelGGL(lbs_fwd_kernel<false>, dim3(N), dim3(LBS_THREADS), 0, (hipStream_t)stream, *m, orient, pose, betas,
-                       (const float*)nullptr, 0, verts, joints, v_posed_ws);
+                                 float* verts, float* joints, void* workspace, void* stream) {
+    if (!m || N <= 0 || !workspace) return -1;
+    lbs_forward_launch(m, false, orient, pose, betas, nullptr, N, 0, verts, joints, lbs_carve(workspace, N), (hipStream_t)stream);
     return (int)hipGetLastError();
 }
 
-extern "C" int ihmr_mano_lbs_bwd(const ihmr_mano* m, const float* orient, const float* pose, const float* betas, int N,
-                                 const float* v_posed_ws, const float* d_verts, const float* d_joints, float* d_orient,
-                                 float* d_pose, float* d_betas, int need_mask, void* stream) {
-    if (!m || N <= 0) return -1;
-    hipLaunchKernelGGL(lbs_bwd_kernel<false>, dim3(N), dim3(LBS_THREADS), 0, (hipStream_t)stream, *m, orient, pose, betas,
-                       0, v_posed_ws, d_verts, d_joints, d_orient, d_pose, d_betas, (float*)nullptr, need_mask);
+extern "C" int ihmr_mano_lbs_bwd(const ihmr_mano* m, int N, const void* workspace, const float* d_verts, const float* d_joints,
+                                 float* d_orient, float* d_pose, float* d_betas, int need_mask, void* stream) {
+    if (!m || N <= 0 || !workspace) return -1;
+    lbs_backward_launch(m, false, N, 0, d_verts, d_joints, d_orient, d_pose, d_betas, nullptr, need_mask,
+                        lbs_carve(const_cast<void*>(workspace), N), (hipStream_t)stream);
     return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------ seam B
 extern "C" size_t ihmr_sdf_workspace_bytes(int B) { return sdf_ws_bytes(2 * B) + (size_t)2 * NFP * 3 * 4 + 256; }
 
-#define SDF_EVAL_CHUNKS 16
+static int g_collect_stats = 0;
 
 static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const int32_t* faces_l_soa, int B, SdfWorkspace ws,
                       float robustifier, float* loss, float* per_vert, float* origin, float* dval, float* gverts,
                       const float* gscale, hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(ws.inside_count, 0, sizeof(int), st));
     hipLaunchKernelGGL(sdf_prep_kernel<false>, dim3(2 * B), dim3(SDF_THREADS), 0, st, vl, faces_r_soa, faces_l_soa, ws);
+    hipLaunchKernelGGL(sdf_parity_kernel, dim3(SDF_EVAL_CHUNKS, 2 * B), dim3(SDF_THREADS), 0, st, ws, g_collect_stats);
     TimedPair tp;
     const bool timed = g_timer != nullptr;
     if (timed) {
@@ -143,7 +203,7 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
         HIP_TRY(hipEventCreate(&tp.b));
         HIP_TRY(hipEventRecord(tp.a, st));
     }
-    hipLaunchKernelGGL(sdf_eval_kernel, dim3(SDF_EVAL_CHUNKS, 2 * B), dim3(SDF_THREADS), 0, st, ws, 0);
+    hipLaunchKernelGGL(sdf_dist_kernel, dim3(SDF_DIST_BLOCKS), dim3(SDF_THREADS), 0, st, ws, g_collect_stats);
     if (timed) {
         HIP_TRY(hipEventRecord(tp.b, st));
         tp.flops = 0.0;
@@ -184,8 +244,10 @@ extern "C" int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* fa
     hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa);
     hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP);
     VertLayout vl{hand_verts, (long)2 * NV3, (long)NV3};
+    HIP_TRY(hipMemsetAsync(ws.inside_count, 0, sizeof(int), st));
     hipLaunchKernelGGL(sdf_prep_kernel<true>, dim3(2 * B), dim3(SDF_THREADS), 0, st, vl, soa, soa + 3 * NFP, ws);
-    hipLaunchKernelGGL(sdf_eval_kernel, dim3(64, 2 * B), dim3(SDF_THREADS), 0, st, ws, 0);
+    hipLaunchKernelGGL(sdf_parity_kernel, dim3(SDF_EVAL_CHUNKS, 2 * B), dim3(SDF_THREADS), 0, st, ws, 0);
+    hipLaunchKernelGGL(sdf_dist_kernel, dim3(SDF_DIST_BLOCKS), dim3(SDF_THREADS), 0, st, ws, 0);
     HIP_TRY(hipMemcpyAsync(phi, ws.phi, (size_t)2 * B * SDF_NVOX * 4, hipMemcpyDeviceToDevice, st));
     return (int)hipGetLastError();
 }
@@ -195,9 +257,7 @@ extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
 
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
                        const ihmr_opt_weights& w, hipStream_t st) {
-    hipLaunchKernelGGL(lbs_fwd_kernel<true>, dim3(2 * B), dim3(LBS_THREADS), 0, st, *m, (const float*)io->orient,
-                       (const float*)io->pose, (const float*)io->shape, (const float*)io->trans, B, io->verts,
-                       wk.joints_raw, wk.v_posed);
+    lbs_forward_launch(m, true, io->orient, io->pose, io->shape, io->trans, 2 * B, B, io->verts, wk.joints_raw, wk.lbs, st);
     hipLaunchKernelGGL(opt_loss_kernel, dim3(B), dim3(LOSS_THREADS), 0, st, *io, wk, B, w);
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
     VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
@@ -239,10 +299,8 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
         int rc = opt_forward(m, m_left, io, wk, B, *w, st);
         if (rc) return rc;
         hipLaunchKernelGGL(opt_mask_collision_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B);
-        hipLaunchKernelGGL(lbs_bwd_kernel<true>, dim3(2 * B), dim3(LBS_THREADS), 0, st, *m, (const float*)io->orient,
-                           (const float*)io->pose, (const float*)io->shape, B, (const float*)wk.v_posed,
-                           (const float*)wk.g_verts, (const float*)wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape,
-                           wk.g_trans, need_mask);
+        lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
+                            wk.lbs, st);
         const int snap = (it % save_freq == 0) ? S++ : -1;
         const double t = (double)(it + 1);
         const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
@@ -253,6 +311,28 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     hipLaunchKernelGGL(opt_select_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B, group, S, filter_factor_j3d,
                        filter_factor_coll, select_on_collision);
     return (int)hipGetLastError();
+}
+
+// diagnostics (synchronises): one forward + losses with the SDF work counters switched on.
+// out[0] = (voxel, triangle) ray tests, out[1] = exact point-triangle distances, out[2] = inside voxels,
+// out[3] = needed voxels -- totals of ONE sdf_eval_kernel launch.
+extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                                  const ihmr_opt_weights* w, unsigned long long* out4, void* stream) {
+    if (!m || !io || !w || !out4 || B <= 0) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    OptWork wk = opt_carve(io->workspace, B);
+    SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
+    HIP_TRY(hipMemsetAsync(ws.stats, 0, 64, st));
+    ihmr_kernel_timer* keep = g_timer;
+    g_timer = nullptr;
+    g_collect_stats = 1;
+    int rc = opt_forward(m, m_left, io, wk, B, *w, st);
+    g_collect_stats = 0;
+    g_timer = keep;
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(out4, ws.stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------ misc

@@ -1,4 +1,4 @@
-// MANO linear blend skinning -- forward and analytic backward, one workgroup per hand.
+// MANO linear blend skinning -- forward and analytic backward.
 //
 // Replaces smplx 0.1.28 `MANO.forward` + `lbs()` as the reference calls it
 // (models/optimize_model.py:194-198) and, in TWO_HAND mode, the whole of
@@ -6,27 +6,62 @@
 // model on 2B hands, 5 fingertip vertices appended (:201-202), x-negation of the left outputs
 // (:210-211), left hand shifted by hand_trans + (right wrist - left wrist) (:222-228).
 //
-// Layout: the skeleton state (16 rotations, rest joints, chain transforms) lives in LDS; posedirs
-// (1.26 MB) / shapedirs are streamed from L2 with lane <-> consecutive (vertex,coord) so every
-// wave-load is a contiguous 768 B run.  J = J_template + J_shapedirs.beta is precomputed
-// algebra (J_regressor is linear), which removes the 16x778 regression from the per-iteration path.
+// MI355X decomposition (hands are independent, the 1.3 MB pose-blend basis is shared by all of them):
+//   skel  : one small workgroup per hand -- Rodrigues, J = J_template + J_shapedirs.beta (the joint
+//           regression folded into constants), kinematic chain by tree level, skinning transforms A_j,
+//           pose feature; 3 KB record per hand in HBM, reused by the backward of the same iteration.
+//   skin  : workgroup = 8 hands x 195 vertices, lane <-> vertex.  Each float4 of the pose/shape basis is
+//           loaded ONCE (coalesced 16 B/lane) and applied to all 8 hands from LDS-broadcast coefficients,
+//           so the basis is streamed from L2 N/8 times instead of N times.
+//   bwd1  : one workgroup per hand -- d v_posed, the 16x12 transform gradients as fixed-order CSR-by-joint
+//           sums, chain backward by tree level, orient / shape / translation gradients.
+//   bwd2  : (finger-pose stage only) d pose_feature = posedirs . d v_posed as an LDS-tiled product,
+//           workgroup = 8 hands x 192 basis columns, partial sums per column chunk (deterministic).
+//   bwd3  : (finger-pose stage only) chunk reduction + Rodrigues backward.
 #pragma once
 #include "ihmr_common.h"
 
 #define LBS_THREADS 256
+#define LBS_HG 8          // hands per skin / bwd2 workgroup
+#define LBS_TILE_V 195    // vertices per skin workgroup (4 x 195 = 780 >= 778)
+#define LBS_NCHUNK 13     // 13 x 192 = 2496 >= 2334 basis columns
+#define LBS_CHUNK 192
 
-struct LbsShared {
-    float pose[48];     // full pose (+ mean), mirrored for left hands in TWO_HAND mode
-    float beta[10];
-    float R[NJ][9];
-    float J[NJ][3];
-    float G[NJ][12];    // world transform rows [R | t]
-    float A[NJ][12];    // skinning transform [G.R | G.t - G.R J]
-    float pf[NPF];
-    float tip[IHMR_NUM_TIPS][3];
-    float shift[3];
-    float red[LBS_THREADS];
+// skeleton record (floats), one per hand
+#define SK_R 0        // [16][9]
+#define SK_J 144      // [16][3]
+#define SK_G 192      // [16][12] world transforms [R | t]
+#define SK_A 384      // [16][12] skinning transforms [G.R | G.t - G.R J]
+#define SK_PF 576     // [136] pose feature (135 used)
+#define SK_POSE 712   // [48] full pose (+ mean), mirrored for left hands
+#define SK_BETA 760   // [10]
+#define SK_SHIFT 770  // [3] TWO_HAND left-hand shift
+#define SK_STRIDE 784
+
+struct LbsWork {       // carved from the caller's workspace
+    float* skel;       // [N][SK_STRIDE]
+    float* v_posed;    // [N][2334]
+    float* dvp;        // [N][2334]
+    float* chain;      // [N][192]: dR [16][9] from the chain, dJ [16][3]
+    float* dpf_part;   // [LBS_NCHUNK][N][136]
 };
+
+static inline size_t lbs_ws_bytes(int N) {
+    size_t n = (size_t)N * (SK_STRIDE + 2 * NV3 + 192 + LBS_NCHUNK * 136) * sizeof(float);
+    return ((n + 255) & ~(size_t)255) + 5 * 256;
+}
+
+static inline LbsWork lbs_carve(void* ws, int N) {
+    LbsWork w;
+    char* p = (char*)ws;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return (float*)r; };
+    w.skel = take((size_t)N * SK_STRIDE * 4);
+    w.v_posed = take((size_t)N * NV3 * 4);
+    w.dvp = take((size_t)N * NV3 * 4);
+    w.chain = take((size_t)N * 192 * 4);
+    w.dpf_part = take((size_t)LBS_NCHUNK * N * 136 * 4);
+    return w;
+}
 
 // smplx batch_rodrigues: angle = ||r + 1e-8||, R = I + sin K + (1 - cos) K^2, K = skew(r / angle)
 __device__ __forceinline__ void rodrigues_fwd(const float* r, float* R) {
@@ -55,7 +90,6 @@ __device__ __forceinline__ void rodrigues_bwd(const float* r, const float* dR, f
     const float n[3] = {r[0] * inva, r[1] * inva, r[2] * inva};
     const float s = sinf(a), c = cosf(a), c1 = 1.0f - c;
     const float nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
-    // K = skew(n)
     const float K[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
     float ds = 0.f, dc1 = 0.f;
 #pragma unroll
@@ -68,7 +102,6 @@ __device__ __forceinline__ void rodrigues_bwd(const float* r, const float* dR, f
         }
     // d/dn of  s*K(n) + c1*(n n^T - (n.n) I)
     float dn[3];
-    // from K: dn_x = dK[2][1] - dK[1][2], dn_y = dK[0][2] - dK[2][0], dn_z = dK[1][0] - dK[0][1]
     dn[0] = s * (dR[7] - dR[5]);
     dn[1] = s * (dR[2] - dR[6]);
     dn[2] = s * (dR[3] - dR[1]);
@@ -87,66 +120,229 @@ __device__ __forceinline__ void rodrigues_bwd(const float* r, const float* dR, f
     dr[2] = dn[2] * inva + da * ez * inva;
 }
 
-// Skeleton set-up shared by forward and backward: fills sh.pose/beta/R/J/pf/G/A.
-// `mirror`: negate the y,z components of every axis-angle triple (left hand through the right model).
-__device__ __forceinline__ void lbs_skeleton(const ihmr_mano& m, LbsShared& sh, const float* orient, const float* pose,
-                                             const float* betas, bool mirror) {
-    const int tid = threadIdx.x;
+// ------------------------------------------------------------------------------------- skeleton
+// grid = N hands, block = 192.  TWO_HAND: hands [0,B) right, [B,2B) left of sample (h - B); joints out
+// is (B,42,3) (posed joints only; the 5 tips are written by the skin kernel), else (N,16,3).
+template <bool TWO_HAND>
+__global__ __launch_bounds__(192) void lbs_skel_kernel(ihmr_mano m, const float* __restrict__ orient,
+                                                       const float* __restrict__ pose, const float* __restrict__ betas,
+                                                       const float* __restrict__ trans, int B, float* __restrict__ skel,
+                                                       float* __restrict__ joints) {
+    __shared__ float sk[SK_STRIDE];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const bool left = TWO_HAND && h >= B;
+    float* sR = sk + SK_R; float* sJ = sk + SK_J; float* sG = sk + SK_G; float* sA = sk + SK_A;
+    float* sPF = sk + SK_PF; float* sPose = sk + SK_POSE; float* sBeta = sk + SK_BETA; float* sShift = sk + SK_SHIFT;
     if (tid < 48) {
-        float v = tid < 3 ? orient[tid] : pose[tid - 3];
-        if (mirror && (tid % 3) != 0) v = -v;
-        sh.pose[tid] = v + m.pose_mean[tid];
+        float v = tid < 3 ? orient[h * 3 + tid] : pose[h * 45 + tid - 3];
+        if (left && (tid % 3) != 0) v = -v;  // optimize_model.py:180-188
+        sPose[tid] = v + m.pose_mean[tid];
     }
-    if (tid >= 64 && tid < 74) sh.beta[tid - 64] = betas[tid - 64];
+    if (tid >= 64 && tid < 74) sBeta[tid - 64] = betas[h * 10 + tid - 64];
+    if (tid >= 128 && tid < 142) sk[SK_SHIFT + tid - 128] = 0.f;  // shift + padding
+    if (tid == 150) sPF[135] = 0.f;
     __syncthreads();
-    if (tid < NJ) rodrigues_fwd(&sh.pose[3 * tid], sh.R[tid]);
+    if (tid < NJ) rodrigues_fwd(&sPose[3 * tid], &sR[9 * tid]);
     if (tid >= 64 && tid < 64 + 48) {
         const int e = tid - 64;
         float acc = m.J_template[e];
 #pragma unroll
-        for (int l = 0; l < 10; ++l) acc = __builtin_fmaf(m.J_shapedirs[e * 10 + l], sh.beta[l], acc);
-        sh.J[e / 3][e % 3] = acc;
+        for (int l = 0; l < 10; ++l) acc = __builtin_fmaf(m.J_shapedirs[e * 10 + l], sBeta[l], acc);
+        sJ[e] = acc;
     }
     __syncthreads();
     if (tid < NPF) {
         const int j = 1 + tid / 9, e = tid % 9;
-        sh.pf[tid] = sh.R[j][e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+        sPF[tid] = sR[9 * j + e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
     }
-    // kinematic chain, level by level (MANO: depth <= 3); 12 lanes per joint
-    if (tid < 12) {
-        const int r = tid / 4, c = tid % 4;
-        sh.G[0][tid] = c < 3 ? sh.R[0][3 * r + c] : sh.J[0][r];
+    if (tid >= 160 && tid < 172) {
+        const int e = tid - 160, r = e / 4, c = e % 4;
+        sG[e] = c < 3 ? sR[3 * r + c] : sJ[r];
+    }
+    if (TWO_HAND && left && tid >= 176 && tid < 179) {
+        // right wrist of the same sample: J_r[0] = J_template[0] + J_shapedirs[0] . beta_right
+        const int k = tid - 176;
+        const float* br = betas + (h - B) * 10;
+        float jr = m.J_template[k];
+#pragma unroll
+        for (int l = 0; l < 10; ++l) jr = __builtin_fmaf(m.J_shapedirs[k * 10 + l], br[l], jr);
+        const float jl = k == 0 ? -sJ[0] : sJ[k];  // mirrored left wrist
+        sShift[k] = trans[(h - B) * 3 + k] + (jr - jl);
     }
     __syncthreads();
+    // kinematic chain, level by level (MANO: depth <= 3); 12 lanes per joint
     for (int d = 1; d <= m.max_depth; ++d) {
-        if (tid < NJ * 12) {
-            const int j = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
-            if (m.depth[j] == d) {
-                const int p = m.parents[j];
-                const float* Gp = sh.G[p];
-                float acc;
-                if (c < 3) {
-                    acc = Gp[4 * r + 0] * sh.R[j][c] + Gp[4 * r + 1] * sh.R[j][3 + c] + Gp[4 * r + 2] * sh.R[j][6 + c];
-                } else {
-                    const float rx = sh.J[j][0] - sh.J[p][0], ry = sh.J[j][1] - sh.J[p][1], rz = sh.J[j][2] - sh.J[p][2];
-                    acc = Gp[4 * r + 0] * rx + Gp[4 * r + 1] * ry + Gp[4 * r + 2] * rz + Gp[4 * r + 3];
-                }
-                sh.G[j][e] = acc;
+        const int j = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
+        if (m.depth[j] == d) {
+            const int p = m.parents[j];
+            const float* Gp = sG + 12 * p;
+            float acc;
+            if (c < 3) {
+                acc = Gp[4 * r + 0] * sR[9 * j + c] + Gp[4 * r + 1] * sR[9 * j + 3 + c] + Gp[4 * r + 2] * sR[9 * j + 6 + c];
+            } else {
+                const float rx = sJ[3 * j] - sJ[3 * p], ry = sJ[3 * j + 1] - sJ[3 * p + 1], rz = sJ[3 * j + 2] - sJ[3 * p + 2];
+                acc = Gp[4 * r + 0] * rx + Gp[4 * r + 1] * ry + Gp[4 * r + 2] * rz + Gp[4 * r + 3];
             }
+            sG[12 * j + e] = acc;
         }
         __syncthreads();
     }
-    if (tid < NJ * 12) {
+    {
         const int j = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
-        const float* G = sh.G[j];
-        sh.A[j][e] = c < 3 ? G[e]
-                           : G[4 * r + 3] - (G[4 * r + 0] * sh.J[j][0] + G[4 * r + 1] * sh.J[j][1] + G[4 * r + 2] * sh.J[j][2]);
+        const float* G = sG + 12 * j;
+        sA[12 * j + e] = c < 3 ? G[e] : G[4 * r + 3] - (G[4 * r + 0] * sJ[3 * j] + G[4 * r + 1] * sJ[3 * j + 1] + G[4 * r + 2] * sJ[3 * j + 2]);
     }
     __syncthreads();
+    for (int i = tid; i < SK_STRIDE; i += 192) skel[(size_t)h * SK_STRIDE + i] = sk[i];
+    if (tid < NJ * 3) {
+        const int j = tid / 3, k = tid % 3;
+        float val = sG[12 * j + 4 * k + 3];
+        if (!TWO_HAND) {
+            joints[((size_t)h * NJ + j) * 3 + k] = val;
+        } else {
+            if (left) val = (k == 0 ? -val : val) + sShift[k];
+            const int b = left ? h - B : h;
+            joints[((size_t)b * 42 + (left ? 21 : 0) + j) * 3 + k] = val;
+        }
+    }
 }
 
-// skinning transform of vertex v: T (3x4 row-major) = sum_j W[v][j] A_j
-__device__ __forceinline__ void lbs_blend(const ihmr_mano& m, const LbsShared& sh, int v, float* T) {
+// ------------------------------------------------------------------------------------- skin
+// grid = (4 vertex tiles, ceil(N/8) hand groups), block = 256 (195 active lanes = vertices).
+template <bool TWO_HAND>
+__global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, const float* __restrict__ skel, int N, int B,
+                                                               float* __restrict__ verts, float* __restrict__ joints,
+                                                               float* __restrict__ v_posed_ws) {
+    __shared__ float4 pfT[136][2];        // [e][hands 0-3 | 4-7]
+    __shared__ float A_s[LBS_HG][192];
+    __shared__ float beta_s[10][LBS_HG];  // [l][hand]
+    __shared__ float shift_s[LBS_HG][4];
+    const int tid = threadIdx.x, hand0 = blockIdx.y * LBS_HG;
+    const int nh = min(LBS_HG, N - hand0);
+    for (int idx = tid; idx < LBS_HG * 136; idx += LBS_THREADS) {
+        const int hh = idx / 136, e = idx % 136;
+        const float v = (hh < nh && e < NPF) ? skel[(size_t)(hand0 + hh) * SK_STRIDE + SK_PF + e] : 0.f;
+        reinterpret_cast<float*>(&pfT[e][0])[hh] = v;
+    }
+    for (int idx = tid; idx < LBS_HG * 192; idx += LBS_THREADS) {
+        const int hh = idx / 192, e = idx % 192;
+        A_s[hh][e] = hh < nh ? skel[(size_t)(hand0 + hh) * SK_STRIDE + SK_A + e] : 0.f;
+    }
+    if (tid < LBS_HG * 10) {
+        const int hh = tid / 10, l = tid % 10;
+        beta_s[l][hh] = hh < nh ? skel[(size_t)(hand0 + hh) * SK_STRIDE + SK_BETA + l] : 0.f;
+    }
+    if (tid >= 128 && tid < 128 + LBS_HG * 4) {
+        const int hh = (tid - 128) / 4, k = (tid - 128) % 4;
+        shift_s[hh][k] = (hh < nh && k < 3) ? skel[(size_t)(hand0 + hh) * SK_STRIDE + SK_SHIFT + k] : 0.f;
+    }
+    __syncthreads();
+    const int v = blockIdx.x * LBS_TILE_V + tid;
+    if (tid >= LBS_TILE_V || v >= NV) return;
+
+    // shape blend: v_shaped = v_template + shapedirs . beta   (8 hands at once)
+    float vs[LBS_HG][3];
+    {
+        const float4 t = m.vt4[v];
+#pragma unroll
+        for (int hh = 0; hh < LBS_HG; ++hh) { vs[hh][0] = t.x; vs[hh][1] = t.y; vs[hh][2] = t.z; }
+#pragma unroll
+        for (int l = 0; l < 10; ++l) {
+            const float4 s = m.sd4[l * NVP + v];
+#pragma unroll
+            for (int hh = 0; hh < LBS_HG; ++hh) {
+                const float bl = beta_s[l][hh];
+                vs[hh][0] = __builtin_fmaf(s.x, bl, vs[hh][0]);
+                vs[hh][1] = __builtin_fmaf(s.y, bl, vs[hh][1]);
+                vs[hh][2] = __builtin_fmaf(s.z, bl, vs[hh][2]);
+            }
+        }
+    }
+    // pose blend: v_posed = v_shaped + pose_feature . posedirs
+    float po[LBS_HG][3];
+#pragma unroll
+    for (int hh = 0; hh < LBS_HG; ++hh) { po[hh][0] = 0.f; po[hh][1] = 0.f; po[hh][2] = 0.f; }
+#pragma unroll 3
+    for (int e = 0; e < NPF; ++e) {
+        const float4 p = m.pd4[e * NVP + v];
+        const float4 f0 = pfT[e][0], f1 = pfT[e][1];
+        const float f[LBS_HG] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+        for (int hh = 0; hh < LBS_HG; ++hh) {
+            po[hh][0] = __builtin_fmaf(f[hh], p.x, po[hh][0]);
+            po[hh][1] = __builtin_fmaf(f[hh], p.y, po[hh][1]);
+            po[hh][2] = __builtin_fmaf(f[hh], p.z, po[hh][2]);
+        }
+    }
+    float w[NJ];
+    {
+        const float4* w4 = reinterpret_cast<const float4*>(m.weights + v * NJ);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 x = w4[q]; w[4 * q] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w; }
+    }
+    int tip = -1;
+    if (TWO_HAND) {
+#pragma unroll
+        for (int t = 0; t < IHMR_NUM_TIPS; ++t)
+            if (v == m.tip_ids[t]) tip = t;
+    }
+#pragma unroll
+    for (int hh = 0; hh < LBS_HG; ++hh) {
+        if (hh >= nh) break;
+        const int h = hand0 + hh;
+        const float vp0 = vs[hh][0] + po[hh][0], vp1 = vs[hh][1] + po[hh][1], vp2 = vs[hh][2] + po[hh][2];
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float wj = w[j];
+            if (wj != 0.f) {
+                const float* A = &A_s[hh][12 * j];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) T[e] = __builtin_fmaf(wj, A[e], T[e]);
+            }
+        }
+        float out[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) out[r] = T[4 * r + 0] * vp0 + T[4 * r + 1] * vp1 + T[4 * r + 2] * vp2 + T[4 * r + 3];
+        float* ws = v_posed_ws + ((size_t)h * NV + v) * 3;
+        ws[0] = vp0; ws[1] = vp1; ws[2] = vp2;
+        const bool left = TWO_HAND && h >= B;
+        if (left) {  // optimize_model.py:210-211, 222-228
+            out[0] = -out[0] + shift_s[hh][0];
+            out[1] = out[1] + shift_s[hh][1];
+            out[2] = out[2] + shift_s[hh][2];
+        }
+        float* dst = verts + ((size_t)h * NV + v) * 3;
+        dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2];
+        if (TWO_HAND && tip >= 0) {  // fingertip joints are vertices (:201-202)
+            const int b = left ? h - B : h;
+            float* jd = joints + ((size_t)b * 42 + (left ? 21 : 0) + NJ + tip) * 3;
+            jd[0] = out[0]; jd[1] = out[1]; jd[2] = out[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------- backward 1
+// One workgroup per hand.  Inputs are gradients w.r.t. the forward OUTPUTS (final verts / joints).
+// need_mask: bit0 orient, bit1 pose, bit2 betas, bit3 trans.
+struct LbsBwdShared {
+    float sk[SK_STRIDE];
+    float g[NV3];         // d L / d verts (raw hand frame)
+    float vp[NV3];        // v_posed (saved by the forward)
+    float dvp[NV3];       // d L / d v_posed
+    float dA[NJ][12];
+    float dG[NJ][12];
+    float dR[NJ][9];
+    float drel[NJ][3];
+    float dJ[NJ][3];
+    float gsum[3];        // TWO_HAND: sum of the left-hand output gradients (= d L / d shift)
+    float gj[21][3];      // joint gradients (raw hand frame)
+    float red[LBS_THREADS];
+};
+
+__device__ __forceinline__ void lbs_blend_lds(const ihmr_mano& m, const float* sA, int v, float* T) {
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
     const float4* w4 = reinterpret_cast<const float4*>(m.weights + v * NJ);
@@ -158,7 +354,7 @@ __device__ __forceinline__ void lbs_blend(const ihmr_mano& m, const LbsShared& s
         for (int i = 0; i < 4; ++i) {
             const float wj = ws[i];
             if (wj != 0.f) {
-                const float* A = sh.A[4 * q + i];
+                const float* A = sA + 12 * (4 * q + i);
 #pragma unroll
                 for (int e = 0; e < 12; ++e) T[e] = __builtin_fmaf(wj, A[e], T[e]);
             }
@@ -166,123 +362,12 @@ __device__ __forceinline__ void lbs_blend(const ihmr_mano& m, const LbsShared& s
     }
 }
 
-// ------------------------------------------------------------------------------------- forward
-// grid = N hands, block = 256.  TWO_HAND: hands [0,B) right, [B,2B) left of sample (h - B);
-// verts out is (2,B,778,3) == (N,778,3); joints out is (B,42,3).
 template <bool TWO_HAND>
-__global__ __launch_bounds__(LBS_THREADS) void lbs_fwd_kernel(ihmr_mano m, const float* __restrict__ orient,
-                                                              const float* __restrict__ pose,
-                                                              const float* __restrict__ betas,
-                                                              const float* __restrict__ trans, int B,
-                                                              float* __restrict__ verts, float* __restrict__ joints,
-                                                              float* __restrict__ v_posed_ws) {
-    __shared__ LbsShared sh;
-    const int h = blockIdx.x, tid = threadIdx.x;
-    const bool left = TWO_HAND && h >= B;
-    lbs_skeleton(m, sh, orient + h * 3, pose + h * 45, betas + h * 10, left);
-
-    if (TWO_HAND) {
-        if (left && tid < 3) {
-            // right wrist of the same sample: J_r[0] = J_template[0] + J_shapedirs[0] . beta_right
-            const float* br = betas + (h - B) * 10;
-            float jr = m.J_template[tid];
-#pragma unroll
-            for (int l = 0; l < 10; ++l) jr = __builtin_fmaf(m.J_shapedirs[tid * 10 + l], br[l], jr);
-            const float jl = tid == 0 ? -sh.J[0][0] : sh.J[0][tid];  // mirrored left wrist
-            sh.shift[tid] = trans[(h - B) * 3 + tid] + (jr - jl);
-        }
-        __syncthreads();
-    }
-
-    const float* vt = m.v_template;
-    const float* sd = m.shapedirs_t;
-    const float* pd = m.posedirs;
-    for (int v = tid; v < NV; v += LBS_THREADS) {
-        float vs[3], vp[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float acc = vt[3 * v + k];
-#pragma unroll
-            for (int l = 0; l < 10; ++l) acc = __builtin_fmaf(sd[l * NV3 + 3 * v + k], sh.beta[l], acc);
-            vs[k] = acc;
-        }
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-#pragma unroll 5
-        for (int e = 0; e < NPF; ++e) {
-            const float f = sh.pf[e];
-            const float* row = pd + e * NV3 + 3 * v;
-            o0 = __builtin_fmaf(f, row[0], o0);
-            o1 = __builtin_fmaf(f, row[1], o1);
-            o2 = __builtin_fmaf(f, row[2], o2);
-        }
-        vp[0] = vs[0] + o0; vp[1] = vs[1] + o1; vp[2] = vs[2] + o2;
-        float T[12];
-        lbs_blend(m, sh, v, T);
-        float out[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) out[r] = T[4 * r + 0] * vp[0] + T[4 * r + 1] * vp[1] + T[4 * r + 2] * vp[2] + T[4 * r + 3];
-        float* ws = v_posed_ws + ((size_t)h * NV + v) * 3;
-        ws[0] = vp[0]; ws[1] = vp[1]; ws[2] = vp[2];
-        if (left) {
-            out[0] = -out[0] + sh.shift[0];
-            out[1] = out[1] + sh.shift[1];
-            out[2] = out[2] + sh.shift[2];
-        }
-        float* dst = verts + ((size_t)h * NV + v) * 3;
-        dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2];
-        if (TWO_HAND) {
-#pragma unroll
-            for (int t = 0; t < IHMR_NUM_TIPS; ++t)
-                if (v == m.tip_ids[t]) { sh.tip[t][0] = out[0]; sh.tip[t][1] = out[1]; sh.tip[t][2] = out[2]; }
-        }
-    }
-    if (!TWO_HAND) {
-        if (tid < NJ * 3) joints[(size_t)h * NJ * 3 + tid] = sh.G[tid / 3][4 * (tid % 3) + 3];
-    } else {
-        __syncthreads();
-        if (tid < 21 * 3) {
-            const int j = tid / 3, k = tid % 3;
-            float val;
-            if (j < NJ) {
-                val = sh.G[j][4 * k + 3];
-                if (left) val = (k == 0 ? -val : val) + sh.shift[k];
-            } else {
-                val = sh.tip[j - NJ][k];
-            }
-            const int b = left ? h - B : h;
-            joints[((size_t)b * 42 + (left ? 21 : 0) + j) * 3 + k] = val;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------- backward
-// Inputs are gradients w.r.t. the kernel's OUTPUTS (final verts / joints).  Outputs:
-//   d_orient (N,3), d_pose (N,45), d_betas (N,10) in the caller's (un-mirrored) parametrisation,
-//   TWO_HAND: d_trans (B,3) written by the left-hand workgroup.
-// need_mask: bit0 orient, bit1 pose, bit2 betas, bit3 trans.
-struct LbsBwdShared {
-    float dvp[NV3];       // d L / d v_posed
-    float g[NV3];         // d L / d verts (raw hand frame)
-    float dA[NJ][12];
-    float dG[NJ][12];
-    float dR[NJ][9];
-    float dJ[NJ][3];
-    float dpf[NPF];
-    float gsum[3];        // TWO_HAND: sum of the left-hand output gradients (= d L / d shift)
-    float gj[21][3];      // joint gradients (raw hand frame)
-};
-
-template <bool TWO_HAND>
-__global__ __launch_bounds__(LBS_THREADS) void lbs_bwd_kernel(ihmr_mano m, const float* __restrict__ orient,
-                                                              const float* __restrict__ pose,
-                                                              const float* __restrict__ betas, int B,
-                                                              const float* __restrict__ v_posed_ws,
-                                                              const float* __restrict__ d_verts,
-                                                              const float* __restrict__ d_joints,
-                                                              float* __restrict__ d_orient, float* __restrict__ d_pose,
-                                                              float* __restrict__ d_betas, float* __restrict__ d_trans,
-                                                              int need_mask) {
-    __shared__ LbsShared sh;
+__global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsWork wk, int B,
+                                                               const float* __restrict__ d_verts,
+                                                               const float* __restrict__ d_joints,
+                                                               float* __restrict__ d_orient, float* __restrict__ d_betas,
+                                                               float* __restrict__ d_trans, int need_mask) {
     __shared__ LbsBwdShared bw;
     const int h = blockIdx.x, tid = threadIdx.x;
     const bool left = TWO_HAND && h >= B;
@@ -298,22 +383,22 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd_kernel(ihmr_mano m, const
             const float* gj = d_joints + ((size_t)b * 42 + 21 + tid) * 3;
             s0 += gj[0]; s1 += gj[1]; s2 += gj[2];
         }
-        s0 = block_reduce_sum(s0, sh.red);
-        s1 = block_reduce_sum(s1, sh.red);
-        s2 = block_reduce_sum(s2, sh.red);
+        s0 = block_reduce_sum(s0, bw.red);
+        s1 = block_reduce_sum(s1, bw.red);
+        s2 = block_reduce_sum(s2, bw.red);
         if (tid == 0) { bw.gsum[0] = s0; bw.gsum[1] = s1; bw.gsum[2] = s2; }
         if (left && need_trans && tid < 3) d_trans[b * 3 + tid] = tid == 0 ? s0 : (tid == 1 ? s1 : s2);
         __syncthreads();
         if ((need_mask & 7) == 0) return;  // stage 0: only the translation moves
     }
 
-    lbs_skeleton(m, sh, orient + h * 3, pose + h * 45, betas + h * 10, left);
-
-    // ---- load output gradients into the raw hand frame
+    // ---- skeleton record of this iteration's forward, output gradients into the raw hand frame
+    for (int i = tid; i < SK_STRIDE; i += LBS_THREADS) bw.sk[i] = wk.skel[(size_t)h * SK_STRIDE + i];
     for (int i = tid; i < NV3; i += LBS_THREADS) {
         float gv = d_verts[(size_t)h * NV3 + i];
         if (left && (i % 3) == 0) gv = -gv;
         bw.g[i] = gv;
+        bw.vp[i] = wk.v_posed[(size_t)h * NV3 + i];
     }
     if (tid < 21 * 3) {
         const int j = tid / 3, k = tid % 3;
@@ -332,89 +417,87 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd_kernel(ihmr_mano m, const
         bw.g[3 * m.tip_ids[t] + k] += bw.gj[NJ + t][k];
     }
     __syncthreads();
+    const float* sR = bw.sk + SK_R; const float* sJ = bw.sk + SK_J; const float* sG = bw.sk + SK_G; const float* sA = bw.sk + SK_A;
 
     // ---- per vertex: d v_posed = T.R^T g
     for (int v = tid; v < NV; v += LBS_THREADS) {
         float T[12];
-        lbs_blend(m, sh, v, T);
+        lbs_blend_lds(m, sA, v, T);
         const float g0 = bw.g[3 * v], g1 = bw.g[3 * v + 1], g2 = bw.g[3 * v + 2];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) bw.dvp[3 * v + c] = T[c] * g0 + T[4 + c] * g1 + T[8 + c] * g2;
+        for (int c = 0; c < 3; ++c) {
+            const float d = T[c] * g0 + T[4 + c] * g1 + T[8 + c] * g2;
+            bw.dvp[3 * v + c] = d;
+            if (need_pose) wk.dvp[(size_t)h * NV3 + 3 * v + c] = d;
+        }
     }
-    __syncthreads();
-
     // ---- dA[j][e] = sum_v W[v][j] * [g (x) v_posed | g][e]  (CSR by joint, fixed order)
     if (tid < NJ * 12) {
         const int j = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
-        const float* vp = v_posed_ws + (size_t)h * NV3;
         float acc = 0.f;
-        for (int q = m.wj_start[j]; q < m.wj_start[j + 1]; ++q) {
+        const int q1 = m.wj_start[j + 1];
+        for (int q = m.wj_start[j]; q < q1; ++q) {
             const int v = m.wj_vert[q];
             const float gr = bw.g[3 * v + r];
-            const float x = c < 3 ? gr * vp[3 * v + c] : gr;
+            const float x = c < 3 ? gr * bw.vp[3 * v + c] : gr;
             acc = __builtin_fmaf(m.wj_w[q], x, acc);
         }
         bw.dA[j][e] = acc;
     }
-    // ---- d pose_feature[e] = posedirs[e] . dvp   (one wave per row, lanes across the 2334 columns)
-    if (need_pose) {
-        const int wave = tid / WAVE, lane = tid % WAVE;
-        for (int e = wave; e < NPF; e += LBS_THREADS / WAVE) {
-            const float* row = m.posedirs + (size_t)e * NV3;
-            float acc = 0.f;
-            for (int i = lane; i < NV3; i += WAVE) acc = __builtin_fmaf(row[i], bw.dvp[i], acc);
-            acc = wave_reduce_sum(acc);
-            if (lane == 0) bw.dpf[e] = acc;
-        }
-    } else if (tid < NPF) {
-        bw.dpf[tid] = 0.f;
-    }
     __syncthreads();
 
-    // ---- chain backward (joint-serial, level by level from the leaves)
+    // ---- chain backward by tree level
     // dG_j = [dA_j.R - dA_j.t (x) J_j | dA_j.t + d posed_joint_j];  dJ_j(direct) = -G_j.R^T dA_j.t
     if (tid < NJ * 12) {
         const int j = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
         const float dat = bw.dA[j][4 * r + 3];
-        bw.dG[j][e] = c < 3 ? bw.dA[j][e] - dat * sh.J[j][c] : dat + bw.gj[j][r];
+        bw.dG[j][e] = c < 3 ? bw.dA[j][e] - dat * sJ[3 * j + c] : dat + bw.gj[j][r];
     }
     if (tid >= 192 && tid < 192 + NJ * 3) {
         const int j = (tid - 192) / 3, c = (tid - 192) % 3;
-        const float* G = sh.G[j];
+        const float* G = sG + 12 * j;
         bw.dJ[j][c] = -(G[c] * bw.dA[j][3] + G[4 + c] * bw.dA[j][7] + G[8 + c] * bw.dA[j][11]);
     }
     __syncthreads();
     for (int d = m.max_depth; d >= 1; --d) {
-        // children at depth d push into their parents; siblings share a parent, so one lane per parent
-        if (tid < NJ) {
-            const int p = tid;
-            for (int j = 1; j < NJ; ++j) {
+        // children at depth d: dR_j = Gp.R^T dG_j.R ; drel_j = Gp.R^T dG_j.t
+        if (tid < NJ * 12) {
+            const int j = tid / 12, e = tid % 12;
+            if (m.depth[j] == d) {
+                const float* Gp = sG + 12 * m.parents[j];
+                const float* dGj = bw.dG[j];
+                if (e < 9) {
+                    const int c = e / 3, c2 = e % 3;
+                    bw.dR[j][e] = Gp[c] * dGj[c2] + Gp[4 + c] * dGj[4 + c2] + Gp[8 + c] * dGj[8 + c2];
+                } else {
+                    const int c = e - 9;
+                    bw.drel[j][c] = Gp[c] * dGj[3] + Gp[4 + c] * dGj[7] + Gp[8 + c] * dGj[11];
+                }
+            }
+        }
+        __syncthreads();
+        // parents gather from their children at depth d (index order): dGp.R += dG_j.R R_j^T + dG_j.t (x) rel_j ; dGp.t += dG_j.t
+        if (tid < NJ * 12) {
+            const int p = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
+            float acc = 0.f, accJ = 0.f;
+            for (int j = p + 1; j < NJ; ++j) {
                 if (m.parents[j] != p || m.depth[j] != d) continue;
                 const float* dGj = bw.dG[j];
-                const float* Rj = sh.R[j];
-                const float rel[3] = {sh.J[j][0] - sh.J[p][0], sh.J[j][1] - sh.J[p][1], sh.J[j][2] - sh.J[p][2]};
-                const float* Gp = sh.G[p];
-                // dR_j = Gp.R^T dG_j.R ; drel_j = Gp.R^T dG_j.t
-                float drel[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-#pragma unroll
-                    for (int c2 = 0; c2 < 3; ++c2)
-                        bw.dR[j][3 * c + c2] = Gp[c] * dGj[c2] + Gp[4 + c] * dGj[4 + c2] + Gp[8 + c] * dGj[8 + c2];
-                    drel[c] = Gp[c] * dGj[3] + Gp[4 + c] * dGj[7] + Gp[8 + c] * dGj[11];
+                if (c < 3) {
+                    const float* Rj = sR + 9 * j;
+                    const float rel = sJ[3 * j + c] - sJ[3 * p + c];
+                    acc += dGj[4 * r] * Rj[3 * c] + dGj[4 * r + 1] * Rj[3 * c + 1] + dGj[4 * r + 2] * Rj[3 * c + 2] + dGj[4 * r + 3] * rel;
+                } else {
+                    acc += dGj[4 * r + 3];
+                    accJ += bw.drel[j][r];
                 }
-                // dGp.R += dG_j.R R_j^T + dG_j.t (x) rel ; dGp.t += dG_j.t
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        bw.dG[p][4 * r + c] += dGj[4 * r] * Rj[3 * c] + dGj[4 * r + 1] * Rj[3 * c + 1] +
-                                               dGj[4 * r + 2] * Rj[3 * c + 2] + dGj[4 * r + 3] * rel[c];
-                    bw.dG[p][4 * r + 3] += dGj[4 * r + 3];
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { bw.dJ[j][c] += drel[c]; bw.dJ[p][c] -= drel[c]; }
             }
+            bw.dG[p][e] += acc;
+            if (c == 3) bw.dJ[p][r] -= accJ;
+        }
+        if (tid >= 192 && tid < 192 + NJ * 3) {
+            const int j = (tid - 192) / 3, c = (tid - 192) % 3;
+            if (m.depth[j] == d) bw.dJ[j][c] += bw.drel[j][c];
         }
         __syncthreads();
     }
@@ -422,17 +505,15 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd_kernel(ihmr_mano m, const
     if (tid >= 64 && tid < 67) bw.dJ[0][tid - 64] += bw.dG[0][4 * (tid - 64) + 3];
     __syncthreads();
 
-    // ---- pose gradients through Rodrigues (pose-feature term enters R_1..15 directly)
-    if (tid < NJ && ((tid == 0 && need_orient) || (tid > 0 && need_pose))) {
-        float dR[9];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) dR[e] = bw.dR[tid][e] + (tid > 0 ? bw.dpf[(tid - 1) * 9 + e] : 0.f);
+    // ---- global orientation gradient (the root rotation is not part of the pose feature)
+    if (need_orient && tid == 0) {
         float dr[3];
-        rodrigues_bwd(&sh.pose[3 * tid], dR, dr);
+        rodrigues_bwd(bw.sk + SK_POSE, bw.dR[0], dr);
         if (left) { dr[1] = -dr[1]; dr[2] = -dr[2]; }
-        float* dst = tid == 0 ? d_orient + h * 3 : d_pose + h * 45 + 3 * (tid - 1);
-        dst[0] = dr[0]; dst[1] = dr[1]; dst[2] = dr[2];
+        d_orient[h * 3 + 0] = dr[0]; d_orient[h * 3 + 1] = dr[1]; d_orient[h * 3 + 2] = dr[2];
     }
+    // ---- finger-pose stage: hand the chain part of dR to bwd3
+    if (need_pose && tid < NJ * 9) wk.chain[(size_t)h * 192 + tid] = bw.dR[tid / 9][tid % 9];
 
     // ---- shape gradients: d beta_l = shapedirs_l . d v_shaped + J_shapedirs_l . dJ   (d v_shaped = d v_posed)
     if (need_betas) {
@@ -455,4 +536,57 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd_kernel(ihmr_mano m, const
             if (lane == 0) d_betas[h * 10 + l] = acc;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------- backward 2
+// d pose_feature partials: part[c][hand][e] = sum_{i in chunk c} posedirs[e][i] * dvp[hand][i]
+// grid = (13 column chunks, ceil(N/8) hand groups), block = 256; the 135 x 192 basis tile sits in LDS.
+__global__ __launch_bounds__(LBS_THREADS) void lbs_bwd2_kernel(ihmr_mano m, LbsWork wk, int N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* pdt = smem;                       // [135][193]
+    float* dv = smem + NPF * (LBS_CHUNK + 1);  // [8][192]
+    const int tid = threadIdx.x, c = blockIdx.x, hand0 = blockIdx.y * LBS_HG, i0 = c * LBS_CHUNK;
+    const int nh = min(LBS_HG, N - hand0);
+    for (int idx = tid; idx < NPF * LBS_CHUNK; idx += LBS_THREADS) {
+        const int e = idx / LBS_CHUNK, i = idx % LBS_CHUNK;
+        pdt[e * (LBS_CHUNK + 1) + i] = (i0 + i < NV3) ? m.posedirs[(size_t)e * NV3 + i0 + i] : 0.f;
+    }
+    for (int idx = tid; idx < LBS_HG * LBS_CHUNK; idx += LBS_THREADS) {
+        const int hh = idx / LBS_CHUNK, i = idx % LBS_CHUNK;
+        dv[idx] = (hh < nh && i0 + i < NV3) ? wk.dvp[(size_t)(hand0 + hh) * NV3 + i0 + i] : 0.f;
+    }
+    __syncthreads();
+    for (int p = tid; p < nh * NPF; p += LBS_THREADS) {
+        const int hh = p / NPF, e = p % NPF;
+        const float* row = pdt + e * (LBS_CHUNK + 1);
+        const float* d = dv + hh * LBS_CHUNK;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < LBS_CHUNK; ++i) acc = __builtin_fmaf(row[i], d[i], acc);
+        wk.dpf_part[((size_t)c * N + hand0 + hh) * 136 + e] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------- backward 3
+// finger-pose gradients: dR_j = chain part + pose-feature part (chunk sums in fixed order), through Rodrigues.
+// grid = N, block = 64 (lanes 1..15 = joints).
+template <bool TWO_HAND>
+__global__ __launch_bounds__(64) void lbs_bwd3_kernel(LbsWork wk, int N, int B, float* __restrict__ d_pose) {
+    const int h = blockIdx.x, j = threadIdx.x;
+    if (j < 1 || j >= NJ) return;
+    const bool left = TWO_HAND && h >= B;
+    float dR[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+        float acc = 0.f;
+        for (int c = 0; c < LBS_NCHUNK; ++c) acc += wk.dpf_part[((size_t)c * N + h) * 136 + (j - 1) * 9 + e];
+        dR[e] = wk.chain[(size_t)h * 192 + 9 * j + e] + acc;
+    }
+    float r[3], dr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = wk.skel[(size_t)h * SK_STRIDE + SK_POSE + 3 * j + k];
+    rodrigues_bwd(r, dR, dr);
+    if (left) { dr[1] = -dr[1]; dr[2] = -dr[2]; }
+    float* dst = d_pose + (size_t)h * 45 + 3 * (j - 1);
+    dst[0] = dr[0]; dst[1] = dr[1]; dst[2] = dr[2];
 }

@@ -11,7 +11,7 @@
 #define OPT_PMAX 90  // largest parameter group: 2 x 45 finger pose
 
 struct OptWork {  // carved from ihmr_opt_io.workspace
-    float* v_posed;     // (2B,778,3)
+    LbsWork lbs;        // skeleton records, v_posed, bwd scratch for 2B hands
     float* joints_raw;  // (B,42,3)
     float* g_verts;     // (2,B,778,3)
     float* g_joints;    // (B,42,3)
@@ -26,7 +26,8 @@ struct OptWork {  // carved from ihmr_opt_io.workspace
 
 static inline size_t opt_ws_bytes(int B) {
     size_t n = 0;
-    n += (size_t)2 * B * NV3 * 4 * 2;     // v_posed, g_verts
+    n += (size_t)2 * B * NV3 * 4;         // g_verts
+    n += lbs_ws_bytes(2 * B);
     n += (size_t)B * 42 * 3 * 4 * 2;      // joints_raw, g_joints
     n += (size_t)B * (3 + 6 + 90 + 20 + 3 + 1) * 4;
     n = (n + 255) & ~(size_t)255;
@@ -38,7 +39,7 @@ static inline OptWork opt_carve(void* ws, int B) {
     OptWork w;
     char* p = (char*)ws;
     auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
-    w.v_posed = (float*)take((size_t)2 * B * NV3 * 4);
+    w.lbs = lbs_carve(take(lbs_ws_bytes(2 * B)), 2 * B);
     w.g_verts = (float*)take((size_t)2 * B * NV3 * 4);
     w.joints_raw = (float*)take((size_t)B * 42 * 3 * 4);
     w.g_joints = (float*)take((size_t)B * 42 * 3 * 4);

@@ -25,9 +25,10 @@ GROUP_TRANS, GROUP_ORIENT, GROUP_POSE, GROUP_SHAPE = 0, 1, 2, 3
 
 # every symbol include/ihmr_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = [
-    "ihmr_mano_create", "ihmr_mano_destroy", "ihmr_mano_update_shapedirs", "ihmr_mano_lbs_fwd", "ihmr_mano_lbs_bwd",
+    "ihmr_mano_create", "ihmr_mano_destroy", "ihmr_mano_update_shapedirs", "ihmr_mano_workspace_bytes", "ihmr_mano_lbs_fwd",
+    "ihmr_mano_lbs_bwd",
     "ihmr_sdf_workspace_bytes", "ihmr_sdf_collision", "ihmr_sdf_dense_grid", "ihmr_opt_workspace_bytes",
-    "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
+    "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_opt_sdf_stats", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
 ]
 
 
@@ -83,8 +84,10 @@ def lib():
         L.ihmr_mano_create.argtypes = [C.POINTER(ManoArrays), C.POINTER(vp)]
         L.ihmr_mano_destroy.argtypes = [vp]
         L.ihmr_mano_update_shapedirs.argtypes = [vp, vp]
+        L.ihmr_mano_workspace_bytes.argtypes = [i]
+        L.ihmr_mano_workspace_bytes.restype = C.c_size_t
         L.ihmr_mano_lbs_fwd.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp]
-        L.ihmr_mano_lbs_bwd.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, vp]
+        L.ihmr_mano_lbs_bwd.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, i, vp]
         L.ihmr_sdf_workspace_bytes.argtypes = [i]
         L.ihmr_sdf_workspace_bytes.restype = C.c_size_t
         L.ihmr_sdf_collision.argtypes = [vp, vp, vp, i, f, vp, vp, vp, vp, vp, vp]
@@ -93,6 +96,7 @@ def lib():
         L.ihmr_opt_workspace_bytes.restype = C.c_size_t
         L.ihmr_opt_run_stage.argtypes = [vp, vp, C.POINTER(OptIO), i, i, C.POINTER(OptWeights), f, i, i, f, f, i, vp]
         L.ihmr_opt_forward_losses.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), vp]
+        L.ihmr_opt_sdf_stats.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), vp, vp]
         L.ihmr_set_kernel_timer.argtypes = [C.POINTER(KernelTimer)]
         L.ihmr_flush_kernel_timer.argtypes = []
         L.ihmr_version.restype = C.c_char_p

@@ -32,26 +32,25 @@ class _LbsFunction(torch.autograd.Function):
         dev = orient.device
         verts = torch.empty(N, 778, 3, device=dev)
         joints = torch.empty(N, 16, 3, device=dev)
-        v_posed = torch.empty(N, 778, 3, device=dev)
+        ws = torch.empty(hip.lib().ihmr_mano_workspace_bytes(N), dtype=torch.uint8, device=dev)
         hip.check(hip.lib().ihmr_mano_lbs_fwd(module._handle().handle, hip.ptr(orient), hip.ptr(pose), hip.ptr(betas), N,
-                                              hip.ptr(verts), hip.ptr(joints), hip.ptr(v_posed), hip.stream_ptr()),
+                                              hip.ptr(verts), hip.ptr(joints), hip.ptr(ws), hip.stream_ptr()),
                   "ihmr_mano_lbs_fwd")
-        ctx.save_for_backward(orient, pose, betas, v_posed)
+        ctx.save_for_backward(orient, pose, betas, ws)
         ctx.module = module
         return verts, joints
 
     @staticmethod
     def backward(ctx, d_verts, d_joints):
-        orient, pose, betas, v_posed = ctx.saved_tensors
+        orient, pose, betas, ws = ctx.saved_tensors
         N = orient.shape[0]
         dev = orient.device
         d_verts = torch.zeros(N, 778, 3, device=dev) if d_verts is None else d_verts.contiguous().float()
         d_joints = torch.zeros(N, 16, 3, device=dev) if d_joints is None else d_joints.contiguous().float()
         d_orient, d_pose, d_betas = torch.zeros_like(orient), torch.zeros_like(pose), torch.zeros_like(betas)
         mask = (1 if ctx.needs_input_grad[0] else 0) | (2 if ctx.needs_input_grad[1] else 0) | (4 if ctx.needs_input_grad[2] else 0)
-        hip.check(hip.lib().ihmr_mano_lbs_bwd(ctx.module._handle().handle, hip.ptr(orient), hip.ptr(pose), hip.ptr(betas), N,
-                                              hip.ptr(v_posed), hip.ptr(d_verts), hip.ptr(d_joints), hip.ptr(d_orient),
-                                              hip.ptr(d_pose), hip.ptr(d_betas), mask, hip.stream_ptr()),
+        hip.check(hip.lib().ihmr_mano_lbs_bwd(ctx.module._handle().handle, N, hip.ptr(ws), hip.ptr(d_verts), hip.ptr(d_joints),
+                                              hip.ptr(d_orient), hip.ptr(d_pose), hip.ptr(d_betas), mask, hip.stream_ptr()),
                   "ihmr_mano_lbs_bwd")
         return (d_orient if mask & 1 else None, d_pose if mask & 2 else None, d_betas if mask & 4 else None, None)
 

@@ -157,6 +157,15 @@ class OptimizeModel:
         hip.check(hip.lib().ihmr_opt_forward_losses(mr, ml, C.byref(self.io), self.batch_size, C.byref(w), hip.stream_ptr()),
                   "ihmr_opt_forward_losses")
 
+    def collect_sdf_stats(self, loss_weights=None):
+        """Work counters of one ``sdf_eval_kernel`` launch at the current parameters (diagnostics)."""
+        w = _weights(loss_weights or self.default_loss_weights)
+        mr, ml = self._mano_handles()
+        out = (C.c_ulonglong * 4)()
+        hip.check(hip.lib().ihmr_opt_sdf_stats(mr, ml, C.byref(self.io), self.batch_size, C.byref(w), out, hip.stream_ptr()),
+                  "ihmr_opt_sdf_stats")
+        return dict(ray_tests=int(out[0]), dist_evals=int(out[1]), inside_voxels=int(out[2]), needed_voxels=int(out[3]))
+
     def run_stage(self, stage):
         a = stage_to_args(stage)
         w = _weights(stage["loss_weights"])

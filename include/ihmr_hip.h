@@ -57,13 +57,14 @@ int ihmr_mano_update_shapedirs(ihmr_mano* m, const float* shapedirs_host);
 /* ------------------------------------------------------------------ seam A: the MANO layer */
 /* forward of `mano_model(global_orient=(N,3), hand_pose=(N,45), betas=(N,10))`
  * (optimize_model.py:194-198; smplx MANO.forward + lbs): verts (N,778,3), joints (N,16,3).
- * v_posed_ws (N,778,3) is saved for the backward. */
+ * `workspace` (ihmr_mano_workspace_bytes(N)) keeps the skeleton records and v_posed for the backward. */
+size_t ihmr_mano_workspace_bytes(int N);
 int ihmr_mano_lbs_fwd(const ihmr_mano* m, const float* orient, const float* pose, const float* betas, int N,
-                      float* verts, float* joints, float* v_posed_ws, void* stream);
-/* backward of the above: d_verts (N,778,3), d_joints (N,16,3) -> d_orient (N,3), d_pose (N,45),
- * d_betas (N,10).  need_mask bit0 = orient, bit1 = pose, bit2 = betas. */
-int ihmr_mano_lbs_bwd(const ihmr_mano* m, const float* orient, const float* pose, const float* betas, int N,
-                      const float* v_posed_ws, const float* d_verts, const float* d_joints,
+                      float* verts, float* joints, void* workspace, void* stream);
+/* backward of the above (same workspace, untouched since the forward): d_verts (N,778,3),
+ * d_joints (N,16,3) -> d_orient (N,3), d_pose (N,45), d_betas (N,10).
+ * need_mask bit0 = orient, bit1 = pose, bit2 = betas. */
+int ihmr_mano_lbs_bwd(const ihmr_mano* m, int N, const void* workspace, const float* d_verts, const float* d_joints,
                       float* d_orient, float* d_pose, float* d_betas, int need_mask, void* stream);
 
 /* ------------------------------------------------------------------ seam B: the collision module */
@@ -136,6 +137,12 @@ int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
 /* forward() + __compute_loss(weights) only (:413-414), no step */
 int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                             const ihmr_opt_weights* w, void* stream);
+
+/* diagnostics (synchronises): forward + losses once with the SDF work counters on; out4 (host) =
+ * {(voxel,triangle) ray tests, exact point-triangle distances, inside voxels, needed voxels} of one
+ * sdf_eval_kernel launch -- the algorithmic work bench.py prices the roofline with. */
+int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                       const ihmr_opt_weights* w, unsigned long long* out4, void* stream);
 
 /* per-kernel timing hook for bench.py: when non-NULL, the library records hipEvents around the
  * dominant kernel on `stream` and accumulates (count, ms) here; host pointer, read after sync */
