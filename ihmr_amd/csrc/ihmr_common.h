@@ -25,6 +25,15 @@
 // dot product in the fixed order of the SDF arithmetic spec: fma(z, fma(y, x*x'))
 #define DOT3(ax, ay, az, bx, by, bz) __builtin_fmaf((az), (bz), __builtin_fmaf((ay), (by), (ax) * (bx)))
 
+// optional in-kernel phase stamps (debug builds only: -DIHMR_TIMING); thread 0 of workgroup (0,0) writes
+// the shader clock at named points, read back through ihmr_debug_read
+#ifdef IHMR_TIMING
+__device__ long long g_dbg[256];
+#define TSTAMP(slot) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_dbg[slot] = clock64(); } while (0)
+#else
+#define TSTAMP(slot) do { } while (0)
+#endif
+
 struct ihmr_mano {
     // device pointers (fp32 unless stated)
     float* v_template;    // [2334]
@@ -43,21 +52,39 @@ struct ihmr_mano {
     int32_t* wj_start;    // [17]  CSR by joint of the non-zero skinning weights
     int32_t* wj_vert;     // [nnz]
     float* wj_w;          // [nnz]
+    int32_t* seg_q;       // [nseg+1] CSR split into single-joint segments of <= LBS_SEG entries (balanced dA reduction)
+    int32_t* jseg_start;  // [17] first segment of each joint
+    int nseg;
     int32_t* faces;       // [3][NFP] SoA, padded with face 0
     float* J_regressor;   // [16][778] (host-side precompute source, kept for update_shapedirs)
     int max_depth;
     int nnz;
 };
 
+// wave64 min / max: 4 DPP row rotations (min over each 16-lane row, no LDS traffic), then the 4 row results
+// through scalar registers.  Exact (min/max are order-independent); every lane gets the result.
+#define DPP_ROW_ROR(n) (0x120 + (n))
 __device__ __forceinline__ float wave_reduce_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(8), 0xf, 0xf, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(4), 0xf, 0xf, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(2), 0xf, 0xf, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(1), 0xf, 0xf, false)));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
 }
 __device__ __forceinline__ float wave_reduce_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(8), 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(4), 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(2), 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(1), 0xf, 0xf, false)));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 // fixed-order butterfly sum: every lane ends with the same value, bit-reproducible run to run
 __device__ __forceinline__ float wave_reduce_sum(float v) {

@@ -82,6 +82,14 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
             if (wts[v * NJ + j] != 0.f) { wv.push_back(v); ww.push_back(wts[v * NJ + j]); }
         start[j + 1] = (int32_t)wv.size();
     }
+    std::vector<int32_t> seg_q, jseg(NJ + 1, 0);
+    for (int j = 0; j < NJ; ++j) {
+        jseg[j] = (int32_t)seg_q.size();
+        for (int q = start[j]; q < start[j + 1]; q += LBS_SEG) seg_q.push_back(q);
+    }
+    jseg[NJ] = (int32_t)seg_q.size();
+    seg_q.push_back((int32_t)wv.size());
+    // segment s of joint j ends at min(next segment start, end of the joint's list)
     std::vector<int32_t> fsoa((size_t)3 * NFP, 0);
     for (int f = 0; f < NFP; ++f)
         for (int k = 0; k < 3; ++k) {
@@ -99,9 +107,11 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
     rc |= upload(&m->J_template, J_t); rc |= upload(&m->J_shapedirs, J_sd); rc |= upload(&m->weights, wts);
     rc |= upload(&m->pose_mean, pm); rc |= upload(&m->parents, par); rc |= upload(&m->depth, depth);
     rc |= upload(&m->tip_ids, tips); rc |= upload(&m->wj_start, start); rc |= upload(&m->wj_vert, wv);
-    rc |= upload(&m->wj_w, ww); rc |= upload(&m->faces, fsoa); rc |= upload(&m->J_regressor, jr);
+    rc |= upload(&m->wj_w, ww); rc |= upload(&m->seg_q, seg_q); rc |= upload(&m->jseg_start, jseg); rc |= upload(&m->faces, fsoa); rc |= upload(&m->J_regressor, jr);
     m->max_depth = maxd;
     m->nnz = (int)wv.size();
+    m->nseg = (int)seg_q.size() - 1;
+    if (m->nseg > LBS_SEG_CAP) { ihmr_mano_destroy(m); return -1; }
     if (rc) return rc;
     *out = m;
     return 0;
@@ -110,7 +120,7 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
 extern "C" int ihmr_mano_destroy(ihmr_mano* m) {
     if (!m) return 0;
     void* ptrs[] = {m->v_template, m->shapedirs_t, m->posedirs, m->J_template, m->J_shapedirs, m->weights, m->pose_mean,
-                    m->parents, m->depth, m->tip_ids, m->wj_start, m->wj_vert, m->wj_w, m->faces, m->J_regressor, m->pd4, m->sd4, m->vt4};
+                    m->parents, m->depth, m->tip_ids, m->wj_start, m->wj_vert, m->wj_w, m->faces, m->J_regressor, m->pd4, m->sd4, m->vt4, m->seg_q, m->jseg_start};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -136,7 +146,7 @@ extern "C" size_t ihmr_mano_workspace_bytes(int N) { return lbs_ws_bytes(N); }
 
 static void lbs_forward_launch(const ihmr_mano* m, bool two_hand, const float* orient, const float* pose, const float* betas,
                                const float* trans, int N, int B, float* verts, float* joints, const LbsWork& wk, hipStream_t st) {
-    const dim3 skin_grid(4, (N + LBS_HG - 1) / LBS_HG);
+    const dim3 skin_grid(8, 4 * ((N + 63) / 64));
     if (two_hand) {
         hipLaunchKernelGGL(lbs_skel_kernel<true>, dim3(N), dim3(192), 0, st, *m, orient, pose, betas, trans, B, wk.skel, joints);
         hipLaunchKernelGGL(lbs_skin_kernel<true>, skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
@@ -164,7 +174,7 @@ static void lbs_backward_launch(const ihmr_mano* m, bool two_hand, int N, int B,
             (void)hipFuncSetAttribute((const void*)lbs_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL(lbs_bwd2_kernel, dim3(LBS_NCHUNK, (N + LBS_HG - 1) / LBS_HG), dim3(LBS_THREADS), lds, st, *m, wk, N);
+        hipLaunchKernelGGL(lbs_bwd2_kernel, dim3(8, LBS_NCHUNK * ((N + 63) / 64)), dim3(LBS_THREADS), lds, st, *m, wk, N);
         if (two_hand) hipLaunchKernelGGL(lbs_bwd3_kernel<true>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
         else hipLaunchKernelGGL(lbs_bwd3_kernel<false>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
     }
@@ -192,10 +202,15 @@ static int g_collect_stats = 0;
 
 static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const int32_t* faces_l_soa, int B, SdfWorkspace ws,
                       float robustifier, float* loss, float* per_vert, float* origin, float* dval, float* gverts,
-                      const float* gscale, hipStream_t st) {
-    HIP_TRY(hipMemsetAsync(ws.inside_count, 0, sizeof(int), st));
-    hipLaunchKernelGGL(sdf_prep_kernel<false>, dim3(2 * B), dim3(SDF_THREADS), 0, st, vl, faces_r_soa, faces_l_soa, ws);
-    hipLaunchKernelGGL(sdf_parity_kernel, dim3(SDF_EVAL_CHUNKS, 2 * B), dim3(SDF_THREADS), 0, st, ws, g_collect_stats);
+                      const float* gscale, const float* hand_type, bool dense, hipStream_t st) {
+    // the per-XCD inside-voxel counters are zeroed by the sample kernel of the previous call (and once at
+    // workspace set-up, see sdf_reset); the prep kernel appends to them
+    if (dense)
+        hipLaunchKernelGGL(sdf_prep_kernel<true>, dim3(2 * B), dim3(SDF_PREP_THREADS), 0, st, vl, B, faces_r_soa, faces_l_soa, ws,
+                           g_collect_stats);
+    else
+        hipLaunchKernelGGL(sdf_prep_kernel<false>, dim3(2 * B), dim3(SDF_PREP_THREADS), 0, st, vl, B, faces_r_soa, faces_l_soa, ws,
+                           g_collect_stats);
     TimedPair tp;
     const bool timed = g_timer != nullptr;
     if (timed) {
@@ -203,19 +218,21 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
         HIP_TRY(hipEventCreate(&tp.b));
         HIP_TRY(hipEventRecord(tp.a, st));
     }
-    hipLaunchKernelGGL(sdf_dist_kernel, dim3(SDF_DIST_BLOCKS), dim3(SDF_THREADS), 0, st, ws, g_collect_stats);
+    hipLaunchKernelGGL(sdf_dist_kernel, dim3(SDF_NXCD * SDF_DIST_BLOCKS_PER_XCD), dim3(SDF_THREADS), 0, st, ws, g_collect_stats);
     if (timed) {
         HIP_TRY(hipEventRecord(tp.b, st));
         tp.flops = 0.0;
         g_pending.push_back(tp);
     }
-    hipLaunchKernelGGL(sdf_sample_kernel, dim3(B), dim3(SDF_THREADS), 0, st, vl, ws, robustifier, loss, per_vert, origin,
-                       dval, gverts, B, gscale);
+    if (loss)
+        hipLaunchKernelGGL(sdf_sample_kernel, dim3(B), dim3(SDF_SAMPLE_THREADS), 0, st, vl, ws, robustifier, loss, per_vert, origin,
+                           dval, gverts, B, gscale, hand_type);
     return (int)hipGetLastError();
 }
 
 // seam-B callers hand over (F,3) int32 AoS faces on the device; the SoA copy lives in the workspace tail
-__global__ void faces_to_soa_kernel(const int32_t* __restrict__ aos, int32_t* __restrict__ soa) {
+__global__ void faces_to_soa_kernel(const int32_t* __restrict__ aos, int32_t* __restrict__ soa, int* zero8) {
+    if (zero8 && blockIdx.x == 0 && threadIdx.x < SDF_NXCD) zero8[threadIdx.x] = 0;  // per-XCD inside-voxel counters
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= NFP) return;
     const int s = f < NF ? f : 0;
@@ -229,10 +246,10 @@ extern "C" int ihmr_sdf_collision(const int32_t* faces_right, const int32_t* fac
     hipStream_t st = (hipStream_t)stream;
     SdfWorkspace ws = sdf_carve(workspace, 2 * B);
     int32_t* soa = (int32_t*)((char*)workspace + sdf_ws_bytes(2 * B));
-    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa);
-    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP);
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa, ws.inside_count);
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP, (int*)nullptr);
     VertLayout vl{hand_verts, (long)2 * NV3, (long)NV3};
-    return sdf_launch(vl, soa, soa + 3 * NFP, B, ws, robustifier, loss, per_vert, origin_scale, dval, nullptr, nullptr, st);
+    return sdf_launch(vl, soa, soa + 3 * NFP, B, ws, robustifier, loss, per_vert, origin_scale, dval, nullptr, nullptr, nullptr, false, st);
 }
 
 extern "C" int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
@@ -241,14 +258,16 @@ extern "C" int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* fa
     hipStream_t st = (hipStream_t)stream;
     SdfWorkspace ws = sdf_carve(workspace, 2 * B);
     int32_t* soa = (int32_t*)((char*)workspace + sdf_ws_bytes(2 * B));
-    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa);
-    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP);
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa, ws.inside_count);
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP, (int*)nullptr);
     VertLayout vl{hand_verts, (long)2 * NV3, (long)NV3};
-    HIP_TRY(hipMemsetAsync(ws.inside_count, 0, sizeof(int), st));
-    hipLaunchKernelGGL(sdf_prep_kernel<true>, dim3(2 * B), dim3(SDF_THREADS), 0, st, vl, soa, soa + 3 * NFP, ws);
-    hipLaunchKernelGGL(sdf_parity_kernel, dim3(SDF_EVAL_CHUNKS, 2 * B), dim3(SDF_THREADS), 0, st, ws, 0);
-    hipLaunchKernelGGL(sdf_dist_kernel, dim3(SDF_DIST_BLOCKS), dim3(SDF_THREADS), 0, st, ws, 0);
-    HIP_TRY(hipMemcpyAsync(phi, ws.phi, (size_t)2 * B * SDF_NVOX * 4, hipMemcpyDeviceToDevice, st));
+    int rc = sdf_launch(vl, soa, soa + 3 * NFP, B, ws, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, st);
+    if (rc) return rc;
+    // workspace order is hand = hnd*B + b; the caller's grid is (B,2,...)
+    for (int b = 0; b < B; ++b)
+        for (int hnd = 0; hnd < 2; ++hnd)
+            HIP_TRY(hipMemcpyAsync(phi + ((size_t)b * 2 + hnd) * SDF_NVOX, ws.phi + ((size_t)hnd * B + b) * SDF_NVOX,
+                                   (size_t)SDF_NVOX * 4, hipMemcpyDeviceToDevice, st));
     return (int)hipGetLastError();
 }
 
@@ -258,19 +277,12 @@ extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
                        const ihmr_opt_weights& w, hipStream_t st) {
     lbs_forward_launch(m, true, io->orient, io->pose, io->shape, io->trans, 2 * B, B, io->verts, wk.joints_raw, wk.lbs, st);
-    hipLaunchKernelGGL(opt_loss_kernel, dim3(B), dim3(LOSS_THREADS), 0, st, *io, wk, B, w);
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
+    hipLaunchKernelGGL(opt_loss_kernel, dim3(B), dim3(LOSS_THREADS), 0, st, *io, wk, B, w, ws.inside_count);
     VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
-    // loss_batch[2] = collision loss per sample; masking by hand type is applied through gscale / below
+    // loss_batch[2] = collision loss per sample, masked by hand type inside the sample kernel
     return sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, B, ws, 0.f, io->loss_batch + 2 * B, io->coll_per_vert, io->coll_origin_scale,
-                      nullptr, wk.g_verts, wk.gscale, st);
-}
-
-__global__ void opt_mask_collision_kernel(ihmr_opt_io io, int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
-    io.loss_batch[2 * B + b] *= mask;  // loss_utils.py:186-188
+                      nullptr, wk.g_verts, wk.gscale, io->hand_type_array, false, st);
 }
 
 extern "C" int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
@@ -280,7 +292,6 @@ extern "C" int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_le
     OptWork wk = opt_carve(io->workspace, B);
     int rc = opt_forward(m, m_left, io, wk, B, *w, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(opt_mask_collision_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B);
     return (int)hipGetLastError();
 }
 
@@ -298,8 +309,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     for (int it = 0; it < n_iters; ++it) {
         int rc = opt_forward(m, m_left, io, wk, B, *w, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(opt_mask_collision_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B);
-        lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
+            lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
                             wk.lbs, st);
         const int snap = (it % save_freq == 0) ? S++ : -1;
         const double t = (double)(it + 1);
@@ -353,5 +363,13 @@ extern "C" int ihmr_flush_kernel_timer(void) {
     g_pending.clear();
     return 0;
 }
+
+#ifdef IHMR_TIMING
+extern "C" int ihmr_debug_read(long long* out256) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_dbg), 256 * sizeof(long long)));
+    return 0;
+}
+#endif
 
 extern "C" const char* ihmr_version(void) { return "ihmr_hip 0.1 (gfx950)"; }

@@ -26,6 +26,9 @@
 #define LBS_TILE_V 195    // vertices per skin workgroup (4 x 195 = 780 >= 778)
 #define LBS_NCHUNK 13     // 13 x 192 = 2496 >= 2334 basis columns
 #define LBS_CHUNK 192
+#define LBS_SEG 13         // CSR entries per dA segment
+#define LBS_SEG_CAP 1024   // >= 778*16/13 + 16: every weight matrix fits
+#define LBS_CSR_CAP 4096   // non-zero skinning weights staged in LDS by bwd1 (MANO-like: <= 4-5 per vertex); else read from L2
 
 // skeleton record (floats), one per hand
 #define SK_R 0        // [16][9]
@@ -207,8 +210,12 @@ __global__ __launch_bounds__(192) void lbs_skel_kernel(ihmr_mano m, const float*
     }
 }
 
+// hand i of group (x, s): x + 8 * (8 s + i) -- all hands of a group share (hand % 8), i.e. the XCD that ran
+// their skeleton workgroup and will run their collision / backward workgroups (speed only).
+__device__ __forceinline__ int lbs_group_hand(int x, int s, int i) { return x + 8 * (8 * s + i); }
+
 // ------------------------------------------------------------------------------------- skin
-// grid = (4 vertex tiles, ceil(N/8) hand groups), block = 256 (195 active lanes = vertices).
+// grid = (8, 4 vertex tiles x ceil(N/64) groups), block = 256 (195 active lanes = vertices).
 template <bool TWO_HAND>
 __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, const float* __restrict__ skel, int N, int B,
                                                                float* __restrict__ verts, float* __restrict__ joints,
@@ -217,63 +224,73 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
     __shared__ float A_s[LBS_HG][192];
     __shared__ float beta_s[10][LBS_HG];  // [l][hand]
     __shared__ float shift_s[LBS_HG][4];
-    const int tid = threadIdx.x, hand0 = blockIdx.y * LBS_HG;
-    const int nh = min(LBS_HG, N - hand0);
+    const int tid = threadIdx.x, gx = blockIdx.x, tile = blockIdx.y % 4, gs = blockIdx.y / 4;
+    TSTAMP(0);
     for (int idx = tid; idx < LBS_HG * 136; idx += LBS_THREADS) {
-        const int hh = idx / 136, e = idx % 136;
-        const float v = (hh < nh && e < NPF) ? skel[(size_t)(hand0 + hh) * SK_STRIDE + SK_PF + e] : 0.f;
+        const int hh = idx / 136, e = idx % 136, hid = lbs_group_hand(gx, gs, hh);
+        const float v = (hid < N && e < NPF) ? skel[(size_t)hid * SK_STRIDE + SK_PF + e] : 0.f;
         reinterpret_cast<float*>(&pfT[e][0])[hh] = v;
     }
     for (int idx = tid; idx < LBS_HG * 192; idx += LBS_THREADS) {
-        const int hh = idx / 192, e = idx % 192;
-        A_s[hh][e] = hh < nh ? skel[(size_t)(hand0 + hh) * SK_STRIDE + SK_A + e] : 0.f;
+        const int hh = idx / 192, e = idx % 192, hid = lbs_group_hand(gx, gs, hh);
+        A_s[hh][e] = hid < N ? skel[(size_t)hid * SK_STRIDE + SK_A + e] : 0.f;
     }
     if (tid < LBS_HG * 10) {
-        const int hh = tid / 10, l = tid % 10;
-        beta_s[l][hh] = hh < nh ? skel[(size_t)(hand0 + hh) * SK_STRIDE + SK_BETA + l] : 0.f;
+        const int hh = tid / 10, l = tid % 10, hid = lbs_group_hand(gx, gs, hh);
+        beta_s[l][hh] = hid < N ? skel[(size_t)hid * SK_STRIDE + SK_BETA + l] : 0.f;
     }
     if (tid >= 128 && tid < 128 + LBS_HG * 4) {
-        const int hh = (tid - 128) / 4, k = (tid - 128) % 4;
-        shift_s[hh][k] = (hh < nh && k < 3) ? skel[(size_t)(hand0 + hh) * SK_STRIDE + SK_SHIFT + k] : 0.f;
+        const int hh = (tid - 128) / 4, k = (tid - 128) % 4, hid = lbs_group_hand(gx, gs, hh);
+        shift_s[hh][k] = (hid < N && k < 3) ? skel[(size_t)hid * SK_STRIDE + SK_SHIFT + k] : 0.f;
     }
     __syncthreads();
-    const int v = blockIdx.x * LBS_TILE_V + tid;
+    TSTAMP(1);
+    const int v = tile * LBS_TILE_V + tid;
     if (tid >= LBS_TILE_V || v >= NV) return;
 
     // shape blend: v_shaped = v_template + shapedirs . beta   (8 hands at once)
-    float vs[LBS_HG][3];
+    float vp[LBS_HG][3];
     {
         const float4 t = m.vt4[v];
+        float4 sd[10];
 #pragma unroll
-        for (int hh = 0; hh < LBS_HG; ++hh) { vs[hh][0] = t.x; vs[hh][1] = t.y; vs[hh][2] = t.z; }
+        for (int l = 0; l < 10; ++l) sd[l] = m.sd4[l * NVP + v];
+#pragma unroll
+        for (int hh = 0; hh < LBS_HG; ++hh) { vp[hh][0] = t.x; vp[hh][1] = t.y; vp[hh][2] = t.z; }
 #pragma unroll
         for (int l = 0; l < 10; ++l) {
-            const float4 s = m.sd4[l * NVP + v];
 #pragma unroll
             for (int hh = 0; hh < LBS_HG; ++hh) {
                 const float bl = beta_s[l][hh];
-                vs[hh][0] = __builtin_fmaf(s.x, bl, vs[hh][0]);
-                vs[hh][1] = __builtin_fmaf(s.y, bl, vs[hh][1]);
-                vs[hh][2] = __builtin_fmaf(s.z, bl, vs[hh][2]);
+                vp[hh][0] = __builtin_fmaf(sd[l].x, bl, vp[hh][0]);
+                vp[hh][1] = __builtin_fmaf(sd[l].y, bl, vp[hh][1]);
+                vp[hh][2] = __builtin_fmaf(sd[l].z, bl, vp[hh][2]);
             }
         }
     }
-    // pose blend: v_posed = v_shaped + pose_feature . posedirs
-    float po[LBS_HG][3];
+    TSTAMP(2);
+    // pose blend: v_posed = v_shaped + pose_feature . posedirs.  The basis rows are fetched 9 at a time
+    // (explicit register batch + scheduling barrier: left alone, hipcc issues one load per use and waits
+    // vmcnt(0) on each -- measured 37 us of exposed latency for this loop).
+#pragma unroll 1
+    for (int e0 = 0; e0 < NPF; e0 += 9) {
+        float4 p[9];
 #pragma unroll
-    for (int hh = 0; hh < LBS_HG; ++hh) { po[hh][0] = 0.f; po[hh][1] = 0.f; po[hh][2] = 0.f; }
-#pragma unroll 3
-    for (int e = 0; e < NPF; ++e) {
-        const float4 p = m.pd4[e * NVP + v];
-        const float4 f0 = pfT[e][0], f1 = pfT[e][1];
-        const float f[LBS_HG] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        for (int u = 0; u < 9; ++u) p[u] = m.pd4[(e0 + u) * NVP + v];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int hh = 0; hh < LBS_HG; ++hh) {
-            po[hh][0] = __builtin_fmaf(f[hh], p.x, po[hh][0]);
-            po[hh][1] = __builtin_fmaf(f[hh], p.y, po[hh][1]);
-            po[hh][2] = __builtin_fmaf(f[hh], p.z, po[hh][2]);
+        for (int u = 0; u < 9; ++u) {
+            const float4 f0 = pfT[e0 + u][0], f1 = pfT[e0 + u][1];
+            const float f[LBS_HG] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+            for (int hh = 0; hh < LBS_HG; ++hh) {
+                vp[hh][0] = __builtin_fmaf(f[hh], p[u].x, vp[hh][0]);
+                vp[hh][1] = __builtin_fmaf(f[hh], p[u].y, vp[hh][1]);
+                vp[hh][2] = __builtin_fmaf(f[hh], p[u].z, vp[hh][2]);
+            }
         }
     }
+    TSTAMP(3);
     float w[NJ];
     {
         const float4* w4 = reinterpret_cast<const float4*>(m.weights + v * NJ);
@@ -288,9 +305,9 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
     }
 #pragma unroll
     for (int hh = 0; hh < LBS_HG; ++hh) {
-        if (hh >= nh) break;
-        const int h = hand0 + hh;
-        const float vp0 = vs[hh][0] + po[hh][0], vp1 = vs[hh][1] + po[hh][1], vp2 = vs[hh][2] + po[hh][2];
+        const int h = lbs_group_hand(gx, gs, hh);
+        if (h >= N) continue;
+        const float vp0 = vp[hh][0], vp1 = vp[hh][1], vp2 = vp[hh][2];
         float T[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = 0.f;
@@ -322,6 +339,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
             jd[0] = out[0]; jd[1] = out[1]; jd[2] = out[2];
         }
     }
+    TSTAMP(4);
 }
 
 // ------------------------------------------------------------------------------------- backward 1
@@ -340,6 +358,7 @@ struct LbsBwdShared {
     float gsum[3];        // TWO_HAND: sum of the left-hand output gradients (= d L / d shift)
     float gj[21][3];      // joint gradients (raw hand frame)
     float red[LBS_THREADS];
+    float part[LBS_SEG_CAP][12];  // per-segment partial sums of dA
 };
 
 __device__ __forceinline__ void lbs_blend_lds(const ihmr_mano& m, const float* sA, int v, float* T) {
@@ -374,6 +393,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
     const int b = TWO_HAND ? (left ? h - B : h) : 0;
     const bool need_orient = need_mask & 1, need_pose = need_mask & 2, need_betas = need_mask & 4, need_trans = need_mask & 8;
 
+    TSTAMP(10);
     // ---- TWO_HAND: d L / d shift = sum over the LEFT hand's vertex and joint gradients of this sample
     if (TWO_HAND) {
         const float* gl = d_verts + ((size_t)(B + b) * NV) * 3;
@@ -392,8 +412,10 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
         if ((need_mask & 7) == 0) return;  // stage 0: only the translation moves
     }
 
+    TSTAMP(11);
     // ---- skeleton record of this iteration's forward, output gradients into the raw hand frame
     for (int i = tid; i < SK_STRIDE; i += LBS_THREADS) bw.sk[i] = wk.skel[(size_t)h * SK_STRIDE + i];
+
     for (int i = tid; i < NV3; i += LBS_THREADS) {
         float gv = d_verts[(size_t)h * NV3 + i];
         if (left && (i % 3) == 0) gv = -gv;
@@ -419,6 +441,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
     __syncthreads();
     const float* sR = bw.sk + SK_R; const float* sJ = bw.sk + SK_J; const float* sG = bw.sk + SK_G; const float* sA = bw.sk + SK_A;
 
+    TSTAMP(12);
     // ---- per vertex: d v_posed = T.R^T g
     for (int v = tid; v < NV; v += LBS_THREADS) {
         float T[12];
@@ -431,21 +454,56 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
             if (need_pose) wk.dvp[(size_t)h * NV3 + 3 * v + c] = d;
         }
     }
-    // ---- dA[j][e] = sum_v W[v][j] * [g (x) v_posed | g][e]  (CSR by joint, fixed order)
-    if (tid < NJ * 12) {
-        const int j = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
-        float acc = 0.f;
-        const int q1 = m.wj_start[j + 1];
-        for (int q = m.wj_start[j]; q < q1; ++q) {
-            const int v = m.wj_vert[q];
-            const float gr = bw.g[3 * v + r];
-            const float x = c < 3 ? gr * bw.vp[3 * v + c] : gr;
-            acc = __builtin_fmaf(m.wj_w[q], x, acc);
+    TSTAMP(13);
+    // ---- dA[j][e] = sum_v W[v][j] * [g (x) v_posed | g][e].  The CSR-by-joint list is cut into single-joint
+    //      segments of <= 13 entries, one lane each (balanced: the wrist alone owns ~600 entries), then the
+    //      segment partials of a joint are summed in index order -- fixed order, bit-reproducible.
+    for (int sg = tid; sg < m.nseg; sg += LBS_THREADS) {
+        const int q0 = m.seg_q[sg];
+        int q1 = m.seg_q[sg + 1];
+        // a joint's last segment stops at the joint's end (the next segment belongs to the next joint)
+        q1 = min(q1, q0 + LBS_SEG);
+        int vv[LBS_SEG];
+        float ww[LBS_SEG];
+#pragma unroll
+        for (int u = 0; u < LBS_SEG; ++u) {
+            const int qq = min(q0 + u, q1 - 1);
+            vv[u] = m.wj_vert[qq];
+            ww[u] = q0 + u < q1 ? m.wj_w[qq] : 0.f;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        float acc[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int u = 0; u < LBS_SEG; ++u) {
+            const int v = vv[u];
+            const float g0 = bw.g[3 * v], g1 = bw.g[3 * v + 1], g2 = bw.g[3 * v + 2];
+            const float p0 = bw.vp[3 * v], p1 = bw.vp[3 * v + 1], p2 = bw.vp[3 * v + 2];
+            const float w = ww[u];
+            const float wg[3] = {w * g0, w * g1, w * g2};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                acc[4 * r + 0] = __builtin_fmaf(wg[r], p0, acc[4 * r + 0]);
+                acc[4 * r + 1] = __builtin_fmaf(wg[r], p1, acc[4 * r + 1]);
+                acc[4 * r + 2] = __builtin_fmaf(wg[r], p2, acc[4 * r + 2]);
+                acc[4 * r + 3] += wg[r];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 12; ++e) bw.part[sg][e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < NJ * 12) {
+        const int j = tid / 12, e = tid % 12;
+        float acc = 0.f;
+        const int s1 = m.jseg_start[j + 1];
+        for (int sg = m.jseg_start[j]; sg < s1; ++sg) acc += bw.part[sg][e];
         bw.dA[j][e] = acc;
     }
     __syncthreads();
 
+    TSTAMP(14);
     // ---- chain backward by tree level
     // dG_j = [dA_j.R - dA_j.t (x) J_j | dA_j.t + d posed_joint_j];  dJ_j(direct) = -G_j.R^T dA_j.t
     if (tid < NJ * 12) {
@@ -505,6 +563,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
     if (tid >= 64 && tid < 67) bw.dJ[0][tid - 64] += bw.dG[0][4 * (tid - 64) + 3];
     __syncthreads();
 
+    TSTAMP(15);
     // ---- global orientation gradient (the root rotation is not part of the pose feature)
     if (need_orient && tid == 0) {
         float dr[3];
@@ -528,42 +587,54 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
         }
         const int wave = tid / WAVE, lane = tid % WAVE;
         for (int l = wave; l < 10; l += LBS_THREADS / WAVE) {
-            const float* row = m.shapedirs_t + (size_t)l * NV3;
+            float4 srow[NVP / WAVE];
+#pragma unroll
+            for (int t = 0; t < NVP / WAVE; ++t) srow[t] = m.sd4[l * NVP + lane + WAVE * t];  // padding rows are zero
+            __builtin_amdgcn_sched_barrier(0);
             float acc = 0.f;
-            for (int i = lane; i < NV3; i += WAVE) acc = __builtin_fmaf(row[i], bw.dvp[i], acc);
+#pragma unroll
+            for (int t = 0; t < NVP / WAVE; ++t) {
+                const int v = lane + WAVE * t;
+                if (v < NV) {
+                    acc = __builtin_fmaf(srow[t].x, bw.dvp[3 * v], acc);
+                    acc = __builtin_fmaf(srow[t].y, bw.dvp[3 * v + 1], acc);
+                    acc = __builtin_fmaf(srow[t].z, bw.dvp[3 * v + 2], acc);
+                }
+            }
             if (lane < 48) acc = __builtin_fmaf(m.J_shapedirs[lane * 10 + l], bw.dJ[lane / 3][lane % 3], acc);
             acc = wave_reduce_sum(acc);
             if (lane == 0) d_betas[h * 10 + l] = acc;
         }
     }
+    TSTAMP(16);
 }
 
 // ------------------------------------------------------------------------------------- backward 2
 // d pose_feature partials: part[c][hand][e] = sum_{i in chunk c} posedirs[e][i] * dvp[hand][i]
-// grid = (13 column chunks, ceil(N/8) hand groups), block = 256; the 135 x 192 basis tile sits in LDS.
+// grid = (8, 13 column chunks x ceil(N/64) groups), block = 256; the 135 x 192 basis tile sits in LDS.
 __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd2_kernel(ihmr_mano m, LbsWork wk, int N) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* pdt = smem;                       // [135][193]
     float* dv = smem + NPF * (LBS_CHUNK + 1);  // [8][192]
-    const int tid = threadIdx.x, c = blockIdx.x, hand0 = blockIdx.y * LBS_HG, i0 = c * LBS_CHUNK;
-    const int nh = min(LBS_HG, N - hand0);
+    const int tid = threadIdx.x, gx = blockIdx.x, c = blockIdx.y % LBS_NCHUNK, gs = blockIdx.y / LBS_NCHUNK, i0 = c * LBS_CHUNK;
     for (int idx = tid; idx < NPF * LBS_CHUNK; idx += LBS_THREADS) {
         const int e = idx / LBS_CHUNK, i = idx % LBS_CHUNK;
         pdt[e * (LBS_CHUNK + 1) + i] = (i0 + i < NV3) ? m.posedirs[(size_t)e * NV3 + i0 + i] : 0.f;
     }
     for (int idx = tid; idx < LBS_HG * LBS_CHUNK; idx += LBS_THREADS) {
-        const int hh = idx / LBS_CHUNK, i = idx % LBS_CHUNK;
-        dv[idx] = (hh < nh && i0 + i < NV3) ? wk.dvp[(size_t)(hand0 + hh) * NV3 + i0 + i] : 0.f;
+        const int hh = idx / LBS_CHUNK, i = idx % LBS_CHUNK, hid = lbs_group_hand(gx, gs, hh);
+        dv[idx] = (hid < N && i0 + i < NV3) ? wk.dvp[(size_t)hid * NV3 + i0 + i] : 0.f;
     }
     __syncthreads();
-    for (int p = tid; p < nh * NPF; p += LBS_THREADS) {
-        const int hh = p / NPF, e = p % NPF;
+    for (int p = tid; p < LBS_HG * NPF; p += LBS_THREADS) {
+        const int hh = p / NPF, e = p % NPF, hid = lbs_group_hand(gx, gs, hh);
+        if (hid >= N) continue;
         const float* row = pdt + e * (LBS_CHUNK + 1);
         const float* d = dv + hh * LBS_CHUNK;
         float acc = 0.f;
 #pragma unroll 8
         for (int i = 0; i < LBS_CHUNK; ++i) acc = __builtin_fmaf(row[i], d[i], acc);
-        wk.dpf_part[((size_t)c * N + hand0 + hh) * 136 + e] = acc;
+        wk.dpf_part[((size_t)c * N + hid) * 136 + e] = acc;
     }
 }
 

@@ -66,9 +66,11 @@ __device__ __forceinline__ void cross3(const float* a, const float* b, float* o)
 __device__ __forceinline__ int align_root(float w) { return w > 0.5f ? 0 : (w < 1e-7f ? 21 : -1); }
 
 // grid = B, block = 64: thread j < 42 owns joint j.
-__global__ __launch_bounds__(LOSS_THREADS) void opt_loss_kernel(ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w) {
+__global__ __launch_bounds__(LOSS_THREADS) void opt_loss_kernel(ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,
+                                                                int* zero8) {
     __shared__ float raw[42][3], p1[42][3], p2[42][3], g2[42][3], acc[8][LOSS_THREADS], gsum[2][3];
     const int b = blockIdx.x, j = threadIdx.x;
+    if (b == 0 && j < 8) zero8[j] = 0;  // per-XCD inside-voxel counters of the collision kernels that follow
     const bool act = j < 42;
     const float* cam = io.cam + b * 3;
     const float cs = cam[0], ctx = cam[1], cty = cam[2];
