@@ -93,8 +93,25 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
     return v;
 }
 __device__ __forceinline__ unsigned wave_reduce_xor(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v ^= (unsigned)__shfl_xor((int)v, o);
+    v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_ROR(8), 0xf, 0xf, false);
+    v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_ROR(4), 0xf, 0xf, false);
+    v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_ROR(2), 0xf, 0xf, false);
+    v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_ROR(1), 0xf, 0xf, false);
+    return (unsigned)(__builtin_amdgcn_readlane((int)v, 0) ^ __builtin_amdgcn_readlane((int)v, 16) ^
+                      __builtin_amdgcn_readlane((int)v, 32) ^ __builtin_amdgcn_readlane((int)v, 48));
+}
+// wave64 inclusive prefix sum of small ints: DPP row shifts inside the 16-lane rows, row totals via SGPRs
+#define DPP_ROW_SHR(n) (0x110 + (n))
+__device__ __forceinline__ int wave_incl_scan(int v, int& total) {
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, false);
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31),
+              t2 = __builtin_amdgcn_readlane(v, 47), t3 = __builtin_amdgcn_readlane(v, 63);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    v += row == 0 ? 0 : (row == 1 ? t0 : (row == 2 ? t0 + t1 : t0 + t1 + t2));
+    total = t0 + t1 + t2 + t3;
     return v;
 }
 

@@ -108,6 +108,9 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
     rc |= upload(&m->pose_mean, pm); rc |= upload(&m->parents, par); rc |= upload(&m->depth, depth);
     rc |= upload(&m->tip_ids, tips); rc |= upload(&m->wj_start, start); rc |= upload(&m->wj_vert, wv);
     rc |= upload(&m->wj_w, ww); rc |= upload(&m->seg_q, seg_q); rc |= upload(&m->jseg_start, jseg); rc |= upload(&m->faces, fsoa); rc |= upload(&m->J_regressor, jr);
+    // lbs_bwd2 keeps a 110 KB basis tile in the CU's 160 KB LDS: above the default dynamic-LDS cap
+    (void)hipFuncSetAttribute((const void*)lbs_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((NPF * (LBS_CHUNK + 1) + LBS_HG * LBS_CHUNK) * sizeof(float)));
     m->max_depth = maxd;
     m->nnz = (int)wv.size();
     m->nseg = (int)seg_q.size() - 1;
@@ -169,11 +172,6 @@ static void lbs_backward_launch(const ihmr_mano* m, bool two_hand, int N, int B,
                            d_betas, d_trans, need_mask);
     if (need_mask & 2) {
         const size_t lds = (size_t)(NPF * (LBS_CHUNK + 1) + LBS_HG * LBS_CHUNK) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {  // 110 KB of the CU's 160 KB LDS: above the default dynamic-LDS cap
-            (void)hipFuncSetAttribute((const void*)lbs_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
         hipLaunchKernelGGL(lbs_bwd2_kernel, dim3(8, LBS_NCHUNK * ((N + 63) / 64)), dim3(LBS_THREADS), lds, st, *m, wk, N);
         if (two_hand) hipLaunchKernelGGL(lbs_bwd3_kernel<true>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
         else hipLaunchKernelGGL(lbs_bwd3_kernel<false>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
@@ -321,6 +319,67 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     hipLaunchKernelGGL(opt_select_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B, group, S, filter_factor_j3d,
                        filter_factor_coll, select_on_collision);
     return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ stage graphs
+// A stage is ~8 launches x n_iters with no host decision inside: capture it once into a hipGraph (per model
+// instance and stage -- the io pointers and the per-iteration Adam constants are baked into the nodes) and
+// replay it, so the host cost per stage drops from ~n_iters x 8 launches to one graph launch.
+struct ihmr_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+template <typename F>
+static int capture_graph(F&& enqueue, ihmr_graph** out) {
+    hipStream_t cs;
+    HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    ihmr_kernel_timer* keep = g_timer;
+    g_timer = nullptr;  // no event records inside a capture
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    int rc = e == hipSuccess ? enqueue(cs) : (int)e;
+    hipGraph_t g = nullptr;
+    hipError_t e2 = hipStreamEndCapture(cs, &g);
+    g_timer = keep;
+    (void)hipStreamDestroy(cs);
+    if (rc) return rc;
+    if (e2 != hipSuccess) return (int)e2;
+    ihmr_graph* h = new ihmr_graph();
+    h->graph = g;
+    hipError_t e3 = hipGraphInstantiate(&h->exec, g, nullptr, nullptr, 0);
+    if (e3 != hipSuccess) { (void)hipGraphDestroy(g); delete h; return (int)e3; }
+    *out = h;
+    return 0;
+}
+
+extern "C" int ihmr_opt_stage_graph_create(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, int group,
+                                           const ihmr_opt_weights* w, float lr, int n_iters, int save_freq,
+                                           float filter_factor_j3d, float filter_factor_coll, int select_on_collision,
+                                           ihmr_graph** out) {
+    if (!out) return -1;
+    return capture_graph([&](hipStream_t cs) {
+        return ihmr_opt_run_stage(m, m_left, io, B, group, w, lr, n_iters, save_freq, filter_factor_j3d, filter_factor_coll,
+                                  select_on_collision, (void*)cs);
+    }, out);
+}
+
+extern "C" int ihmr_opt_forward_graph_create(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                                             const ihmr_opt_weights* w, ihmr_graph** out) {
+    if (!out) return -1;
+    return capture_graph([&](hipStream_t cs) { return ihmr_opt_forward_losses(m, m_left, io, B, w, (void*)cs); }, out);
+}
+
+extern "C" int ihmr_graph_launch(ihmr_graph* g, void* stream) {
+    if (!g) return -1;
+    return (int)hipGraphLaunch(g->exec, (hipStream_t)stream);
+}
+
+extern "C" int ihmr_graph_destroy(ihmr_graph* g) {
+    if (!g) return 0;
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return 0;
 }
 
 // diagnostics (synchronises): one forward + losses with the SDF work counters switched on.

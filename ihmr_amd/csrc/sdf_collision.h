@@ -295,51 +295,89 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     __threadfence_block();
     __syncthreads();
     TSTAMP(25);
-    // ---- wave = column (k,j), lanes across the column's triangle list: the (u,v) test once per (column,
-    //      triangle); per needed voxel the t > 0 hits are counted with one ballot (parity = popcount & 1)
+    // ---- 16-lane row = column (k,j): four columns in flight per wave.  Lanes first run across the column's
+    //      triangle list for the (u,v) test (once per column and triangle); then roles flip: lane r of the row
+    //      owns voxels i = r and i = r + 16 of the column and walks the few surviving candidates (their record
+    //      re-read from LDS as a row-wide broadcast), toggling its own parity -- so the t > 0 work runs on
+    //      voxel-dense lanes and no cross-lane reduction is needed.
     unsigned long long st_tests = 0;
     float* phi = ws.phi + (size_t)H * SDF_NVOX;
-    for (int col = wave; col < SDF_NCOL; col += SDF_PREP_THREADS / WAVE) {
+    const int row = tid >> 4, rlane = tid & 15, rshift = lane & 48;   // 64 rows of 16 lanes
+    const float pxA = (float)(2 * rlane + 1) / (float)SDF_G - 1.0f;
+    const float pxB = (float)(2 * (rlane + 16) + 1) / (float)SDF_G - 1.0f;
+#ifdef IHMR_TIMING
+    long long c0_ = clock64(); int n_it_ = 0, n_rd_ = 0, n_vx_ = 0;
+#endif
+    for (int cidx = row; cidx < SDF_NCOL; cidx += SDF_PREP_THREADS / 16) {
+        const int col = (cidx * 37) & (SDF_NCOL - 1);   // bijective scatter: the read columns cluster, spread them over the waves
         const unsigned need = needed[col];
-        if (!need) { if (lane == 0) cur[col] = 0; continue; }
+        if (!__any(need != 0u)) {              // none of the wave's four columns is read: skip
+            if (rlane == 0) cur[col] = 0;
+            continue;
+        }
         const int k = col >> 5, j = col & 31;
         const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
         const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
-        const int t0 = full_scan ? 0 : cnt[col], len = full_scan ? NF : cur[col];
-        unsigned par = 0;
-        for (int base = 0; base < len; base += WAVE) {
-            const int t = base + lane;
+        const int t0 = full_scan ? 0 : cnt[col], len = !need ? 0 : (full_scan ? NF : cur[col]);
+        const bool hasA = (need >> rlane) & 1u, hasB = (need >> (rlane + 16)) & 1u;
+        bool parA = false, parB = false;
+#ifdef IHMR_TIMING
+        n_it_++;
+#endif
+        for (int base = 0; __any(base < len); base += 16) {
+#ifdef IHMR_TIMING
+            n_rd_++;
+#endif
+            const int t = base + rlane;
             const bool valid = t < len;
             const int f = !valid ? 0 : (full_scan ? t : (in_lds ? (int)ltri[t0 + t] : (int)glst[t0 + t]));
-            const float4 r0 = lpar[f][0], r1 = lpar[f][1];
-            const float ay = r0.x, az = r0.y, e1y = r0.z, e1z = r0.w, e2y = r1.x, e2z = r1.y, inv = r1.z, ax = r1.w;
-            const float sy = py - ay, sz = pz - az;
-            const float uu = __builtin_fmaf(sz, e2y, -(sy * e2z)) * inv;
-            const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y));
-            const float vv = qx * inv;
-            const bool cand = valid && (uu >= 0.0f) && (uu <= 1.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f);
+            bool cand;
+            {
+                const float4 r0 = lpar[f][0], r1 = lpar[f][1];
+                const float sy = py - r0.x, sz = pz - r0.y;
+                const float uu = __builtin_fmaf(sz, r1.x, -(sy * r1.y)) * r1.z;
+                const float qx = __builtin_fmaf(sy, r0.w, -(sz * r0.z));
+                const float vv = qx * r1.z;
+                cand = valid && (uu >= 0.0f) && (uu <= 1.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f);
+            }
             st_tests += valid ? 1 : 0;
-            if (__ballot(cand) == 0ull) continue;
-            const float4 r2 = lpar[f][2];
-            const float e1x = r2.x, e2x = r2.y;
-            unsigned rem = need;
-            while (rem) {
-                const int i = __ffs((int)rem) - 1;
-                rem &= rem - 1;
-                const float px = (float)(2 * i + 1) / (float)SDF_G - 1.0f;
-                const float sx = px - ax;
-                const float qy = __builtin_fmaf(sz, e1x, -(sx * e1z));
-                const float qz = __builtin_fmaf(sx, e1y, -(sy * e1x));
-                const float tt = DOT3(e2x, e2y, e2z, qx, qy, qz) * inv;
-                const unsigned long long hit = __ballot(cand && tt > 0.0f);
-                if (__popcll(hit) & 1) par ^= 1u << i;
-                st_tests += cand ? 1 : 0;
+            unsigned cm = (unsigned)(__ballot(cand) >> rshift) & 0xffffu;   // candidates of my row (uniform in the row)
+            while (__any(cm != 0u)) {
+                const int c = cm ? __ffs((int)cm) - 1 : 0;
+                const int fc = __shfl(f, rshift + c);                     // triangle of the row's next candidate
+                if (cm) {
+                    cm &= cm - 1;
+                    const float4 r0 = lpar[fc][0], r1 = lpar[fc][1], r2 = lpar[fc][2];
+                    const float ay = r0.x, az = r0.y, e1y = r0.z, e1z = r0.w, e2y = r1.x, e2z = r1.y, inv = r1.z, ax = r1.w;
+                    const float e1x = r2.x, e2x = r2.y;
+                    const float sy = py - ay, sz = pz - az;
+                    const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y));
+                    {
+                        const float sx = pxA - ax;
+                        const float qy = __builtin_fmaf(sz, e1x, -(sx * e1z));
+                        const float qz = __builtin_fmaf(sx, e1y, -(sy * e1x));
+                        const float tt = DOT3(e2x, e2y, e2z, qx, qy, qz) * inv;
+                        parA ^= hasA && (tt > 0.0f);
+                    }
+                    {
+                        const float sx = pxB - ax;
+                        const float qy = __builtin_fmaf(sz, e1x, -(sx * e1z));
+                        const float qz = __builtin_fmaf(sx, e1y, -(sy * e1x));
+                        const float tt = DOT3(e2x, e2y, e2z, qx, qy, qz) * inv;
+                        parB ^= hasB && (tt > 0.0f);
+                    }
+                    st_tests += (hasA ? 1 : 0) + (hasB ? 1 : 0);
+                }
             }
         }
-        const unsigned inside = par & need;
-        if (lane < SDF_G && (((need & ~inside) >> lane) & 1u)) phi[col * SDF_G + lane] = 0.0f;  // outside voxels
-        if (lane == 0) cur[col] = (int)inside;
+        const unsigned inside = ((unsigned)(__ballot(parA) >> rshift) & 0xffffu) | (((unsigned)(__ballot(parB) >> rshift) & 0xffffu) << 16);
+        if (hasA && !parA) phi[col * SDF_G + rlane] = 0.0f;          // outside voxels
+        if (hasB && !parB) phi[col * SDF_G + rlane + 16] = 0.0f;
+        if (rlane == 0) cur[col] = (int)inside;
     }
+#ifdef IHMR_TIMING
+    if (blockIdx.x == 0 && lane == 0) { g_dbg[100 + wave] = clock64() - c0_; g_dbg[120 + wave] = n_it_; g_dbg[140 + wave] = n_rd_; g_dbg[160 + wave] = n_vx_; }
+#endif
     __syncthreads();
     TSTAMP(27);
     // ---- publish the inside voxels into this XCD's list (one global atomic per workgroup); thread = column
@@ -446,8 +484,17 @@ __global__ __launch_bounds__(SDF_THREADS) void sdf_dist_kernel(SdfWorkspace ws, 
     int curH = -1;
     const float4* abc = nullptr;
     unsigned long long st_dist = 0;
+#ifdef IHMR_TIMING
+    long long ph[6] = {0, 0, 0, 0, 0, 0};
+#define PH(i) do { const long long now_ = clock64(); ph[i] += now_ - last_; last_ = now_; } while (0)
+    long long last_ = clock64();
+#else
+#define PH(i) do { } while (0)
+#endif
+    unsigned ent_l = 0;
     for (int q = q0; q < q1; ++q) {
-        const unsigned ent = glist[q];
+        if (((q - q0) & (WAVE - 1)) == 0) ent_l = (q + lane < q1) ? glist[q + lane] : 0u;  // 64 entries per fetch
+        const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ent_l, (q - q0) & (WAVE - 1));
         const int H = (int)(ent >> 16), id = (int)(ent & 0xffffu);
         if (H != curH) {
             curH = H;
@@ -456,6 +503,7 @@ __global__ __launch_bounds__(SDF_THREADS) void sdf_dist_kernel(SdfWorkspace ws, 
 #pragma unroll
             for (int t = 0; t < NFP / WAVE; ++t) sp[t] = sph[lane + WAVE * t];
         }
+        PH(0);
         const int col = id >> 5, i = id & 31, k = col >> 5, j = col & 31;
         const float px = (float)(2 * i + 1) / (float)SDF_G - 1.0f;
         const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
@@ -470,19 +518,27 @@ __global__ __launch_bounds__(SDF_THREADS) void sdf_dist_kernel(SdfWorkspace ws, 
         }
         ub2 = wave_reduce_min(ub2);  // the centroid is a point of the triangle: dist <= |p - centroid|
         const float ub_lim = sqrtf(ub2) * 1.0001f + 1e-6f;
-        int cnt = 0;
+        PH(1);
+        unsigned keepmask = 0;
 #pragma unroll
         for (int t = 0; t < NFP / WAVE; ++t) {
             const float lim = ub_lim + sp[t].w;
             // cull iff |p - centroid| - radius > upper bound (exact: such a triangle cannot be the minimum)
             const bool keep = (sp[t].w >= 0.0f) && !(d2[t] > lim * lim * 1.00001f);
-            const unsigned long long bal = __ballot(keep);
-            if (keep) mylist[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(lane + WAVE * t);
-            cnt += __popcll(bal);
+            keepmask |= keep ? (1u << t) : 0u;
+        }
+        int cnt;
+        const int mine = __popc(keepmask);
+        int off = wave_incl_scan(mine, cnt) - mine;
+        while (keepmask) {
+            const int t = __ffs((int)keepmask) - 1;
+            keepmask &= keepmask - 1;
+            mylist[off++] = (unsigned short)(lane + WAVE * t);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        PH(2);
         float best = INFINITY;
         for (int sidx = lane; sidx < cnt; sidx += WAVE) {
             const int f = mylist[sidx];
@@ -491,11 +547,19 @@ __global__ __launch_bounds__(SDF_THREADS) void sdf_dist_kernel(SdfWorkspace ws, 
             best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
             st_dist += 1;
         }
+        PH(3);
         best = wave_reduce_min(best);
         if (lane == 0) ws.phi[(size_t)H * SDF_NVOX + id] = sqrtf(best);
         __builtin_amdgcn_wave_barrier();
+        PH(4);
+#ifdef IHMR_TIMING
+        ph[5] += cnt;
+#endif
     }
     TSTAMP(41);
+#ifdef IHMR_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) g_dbg[70 + i_] = ph[i_];
+#endif
 #ifdef IHMR_TIMING
     if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[42] = q1 - q0;
 #endif

@@ -28,7 +28,8 @@ EXPORTED_SYMBOLS = [
     "ihmr_mano_create", "ihmr_mano_destroy", "ihmr_mano_update_shapedirs", "ihmr_mano_workspace_bytes", "ihmr_mano_lbs_fwd",
     "ihmr_mano_lbs_bwd",
     "ihmr_sdf_workspace_bytes", "ihmr_sdf_collision", "ihmr_sdf_dense_grid", "ihmr_opt_workspace_bytes",
-    "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_opt_sdf_stats", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
+    "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_opt_sdf_stats", "ihmr_opt_stage_graph_create",
+    "ihmr_opt_forward_graph_create", "ihmr_graph_launch", "ihmr_graph_destroy", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
 ]
 
 
@@ -96,6 +97,10 @@ def lib():
         L.ihmr_opt_workspace_bytes.restype = C.c_size_t
         L.ihmr_opt_run_stage.argtypes = [vp, vp, C.POINTER(OptIO), i, i, C.POINTER(OptWeights), f, i, i, f, f, i, vp]
         L.ihmr_opt_forward_losses.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), vp]
+        L.ihmr_opt_stage_graph_create.argtypes = [vp, vp, C.POINTER(OptIO), i, i, C.POINTER(OptWeights), f, i, i, f, f, i, C.POINTER(vp)]
+        L.ihmr_opt_forward_graph_create.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(vp)]
+        L.ihmr_graph_launch.argtypes = [vp, vp]
+        L.ihmr_graph_destroy.argtypes = [vp]
         L.ihmr_opt_sdf_stats.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), vp, vp]
         L.ihmr_set_kernel_timer.argtypes = [C.POINTER(KernelTimer)]
         L.ihmr_flush_kernel_timer.argtypes = []

@@ -84,6 +84,8 @@ class OptimizeModel:
         self.save_mid_freq = getattr(opt, "save_mid_freq", 1)
         self._alloc(self.batch_size)
         self.selected_history = []
+        self.use_graphs = bool(getattr(opt, "use_graphs", True))
+        self._graphs = {}
 
     # optimize_model.py:97-117
     def load_mano_model(self):
@@ -152,8 +154,18 @@ class OptimizeModel:
 
     # optimize_model.py:254-330 with explicit weights (forward + __compute_loss)
     def forward_losses(self, loss_weights=None):
-        w = _weights(loss_weights or self.default_loss_weights)
+        lw = loss_weights or self.default_loss_weights
+        w = _weights(lw)
         mr, ml = self._mano_handles()
+        if self.use_graphs:
+            key = ("fwd",) + tuple(sorted(lw.items()))
+            if key not in self._graphs:
+                g = C.c_void_p()
+                hip.check(hip.lib().ihmr_opt_forward_graph_create(mr, ml, C.byref(self.io), self.batch_size, C.byref(w), C.byref(g)),
+                          "ihmr_opt_forward_graph_create")
+                self._graphs[key] = g
+            hip.check(hip.lib().ihmr_graph_launch(self._graphs[key], hip.stream_ptr()), "ihmr_graph_launch")
+            return
         hip.check(hip.lib().ihmr_opt_forward_losses(mr, ml, C.byref(self.io), self.batch_size, C.byref(w), hip.stream_ptr()),
                   "ihmr_opt_forward_losses")
 
@@ -170,6 +182,18 @@ class OptimizeModel:
         a = stage_to_args(stage)
         w = _weights(stage["loss_weights"])
         mr, ml = self._mano_handles()
+        if self.use_graphs:
+            key = ("stage", a["group"], float(stage["lr"]), int(stage["epoch"]), int(self.save_mid_freq), a["fac_j3d"], a["fac_coll"],
+                   a["select_on_collision"]) + tuple(sorted(stage["loss_weights"].items()))
+            if key not in self._graphs:
+                g = C.c_void_p()
+                hip.check(hip.lib().ihmr_opt_stage_graph_create(mr, ml, C.byref(self.io), self.batch_size, a["group"], C.byref(w),
+                                                                float(stage["lr"]), int(stage["epoch"]) + 1, int(self.save_mid_freq),
+                                                                a["fac_j3d"], a["fac_coll"], a["select_on_collision"], C.byref(g)),
+                          "ihmr_opt_stage_graph_create")
+                self._graphs[key] = g
+            hip.check(hip.lib().ihmr_graph_launch(self._graphs[key], hip.stream_ptr()), "ihmr_graph_launch")
+            return
         hip.check(hip.lib().ihmr_opt_run_stage(mr, ml, C.byref(self.io), self.batch_size, a["group"], C.byref(w),
                                                float(stage["lr"]), int(stage["epoch"]) + 1, int(self.save_mid_freq),
                                                a["fac_j3d"], a["fac_coll"], a["select_on_collision"], hip.stream_ptr()),
@@ -185,6 +209,16 @@ class OptimizeModel:
                 print(f"iter:{iter_id + 1:04d}/{num_iter:04d}, stage-{stage_id:02d} completes")
                 sys.stdout.flush()
         self.forward_losses(self.default_loss_weights)
+
+    def __del__(self):
+        try:
+            if sys is None or sys.is_finalizing():
+                return
+            for g in self._graphs.values():
+                hip.lib().ihmr_graph_destroy(g)
+            self._graphs = {}
+        except Exception:
+            pass
 
     # reference-named views of the state
     @property

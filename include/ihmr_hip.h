@@ -138,6 +138,18 @@ int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
 int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                             const ihmr_opt_weights* w, void* stream);
 
+/* hipGraph form of the two calls above: capture once per model instance and stage (the io pointers and the
+ * per-iteration Adam constants are baked into the nodes), replay with ihmr_graph_launch.  *_create allocate
+ * (graph instantiation) and must not be called inside a capture; launch is asynchronous on `stream`. */
+typedef struct ihmr_graph ihmr_graph;
+int ihmr_opt_stage_graph_create(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, int group,
+                                const ihmr_opt_weights* w, float lr, int n_iters, int save_freq, float filter_factor_j3d,
+                                float filter_factor_coll, int select_on_collision, ihmr_graph** out);
+int ihmr_opt_forward_graph_create(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                                  const ihmr_opt_weights* w, ihmr_graph** out);
+int ihmr_graph_launch(ihmr_graph* g, void* stream);
+int ihmr_graph_destroy(ihmr_graph* g);
+
 /* diagnostics (synchronises): forward + losses once with the SDF work counters on; out4 (host) =
  * {(voxel,triangle) ray tests, exact point-triangle distances, inside voxels, needed voxels} of one
  * sdf_eval_kernel launch -- the algorithmic work bench.py prices the roofline with. */
