@@ -40,7 +40,7 @@ def make_opt(B, epoch, freq, rank):
                                  optimizer="adam", opt_epoch=epoch)
 
 
-def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=4, iters_per_stage=2):
+def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=16, iters_per_stage=4):
     """The oracle (kind "port": same op graph as the reference -- torch LBS + losses + torch.optim.Adam,
     dense 32^3 voxel SDF in C/OpenMP) on the first `n_samples` samples of the same batch for
     `iters_per_stage` iterations per stage, extrapolated linearly to the full iteration count
@@ -73,8 +73,8 @@ def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=4, iters_per_stage=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--epoch", type=int, default=49, help="opt_default epoch per stage (49 -> 200 iterations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,21 +179,23 @@ def main():
         model.init_optimize()
         st_ini = model.collect_sdf_stats()
         stats = {k: 0.5 * (st_ini[k] + st_end[k]) for k in st_ini}
-        # flops per unit of work (DESIGN.md "Measurement"): ray test 11, exact point-triangle distance 75,
-        # per inside voxel 2 sphere passes x 1538 triangles x 9
-        stats["flops_per_launch"] = 11.0 * stats["ray_tests"] + 75.0 * stats["dist_evals"] + 2 * 1538 * 9.0 * stats["inside_voxels"]
+        # algorithmic flops of ONE sdf_dist_kernel launch (DESIGN.md "Measurement"): per inside voxel the
+        # sphere pass over all 1538 triangles (8 flops: |p - centroid|^2) and the cull test (3 flops), plus
+        # 75 flops per exact point-triangle distance that survives the cull
+        stats["flops_per_launch"] = 1538 * 11.0 * stats["inside_voxels"] + 75.0 * stats["dist_evals"]
         avg_ms = timer.ms_sdf_eval / max(timer.n_sdf_eval, 1)
         if avg_ms > 0:
             flops = stats["flops_per_launch"]
             ach = flops / (avg_ms * 1e-3) / 1e12
             roofline = dict(bound="mfma", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS,
-                            traffic=None, kernel="sdf_eval_kernel", avg_launch_ms=avg_ms, launches=int(timer.n_sdf_eval),
-                            note="fp32 VALU kernel (no GEMM shape): priced against the fp32 peak, which is the same "
-                                 "157.3 TFLOP/s for vector and f32-input MFMA on gfx950",
+                            traffic=None, kernel="sdf_dist_kernel", avg_launch_ms=avg_ms, launches=int(timer.n_sdf_eval),
+                            note="largest share of GPU time in the rocprofv3 kernel summary (profiles/). fp32 VALU kernel (no GEMM "
+                                 "shape): priced against the fp32 peak, the same 157.3 TFLOP/s for vector and f32-input MFMA on "
+                                 "gfx950; timed with HIP events on the launch stream in a single-stream pass",
                             algorithmic_flops_per_launch=flops, work_per_launch=stats)
         else:
             roofline = dict(bound="mfma", achieved=None, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=None, traffic=None,
-                            kernel="sdf_eval_kernel", avg_launch_ms=avg_ms, launches=int(timer.n_sdf_eval))
+                            kernel="sdf_dist_kernel", avg_launch_ms=avg_ms, launches=int(timer.n_sdf_eval))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
