@@ -1,0 +1,55 @@
+"""Multi-GPU plumbing: one process per GPU, samples sharded with no data-path collective, one all-reduce of
+the metric sums at the end.
+
+Replaces ``src/utils/init_utils.py:10-18`` (``init_dist``: env-var rendezvous, ``'nccl'`` = RCCL on ROCm,
+``torch.cuda.set_device(rank % num_gpus)``) and the pickle-file gather + ``barrier`` of
+``src/optimize.py:78-89``.  The padding rule follows ``data/opt_dataset.py:38-51``: the sample list is padded
+with copies of sample 0 up to a multiple of ``batch x world`` and the duplicates are masked out of the metrics.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_dist(backend: str | None = None):
+    """Returns (rank, world_size).  No-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local % torch.cuda.device_count())
+    if not dist.is_initialized():
+        dist.init_process_group(backend)
+    return rank, world
+
+
+def shard_indices(num_samples: int, batch_size: int, rank: int, world: int):
+    """Contiguous per-rank slices of the padded index list; returns (indices, is_padding) for this rank."""
+    per_round = batch_size * world
+    padded = ((num_samples + per_round - 1) // per_round) * per_round
+    idx = np.arange(padded)
+    is_pad = idx >= num_samples
+    idx = np.where(is_pad, 0, idx)          # opt_dataset.py:49-51 pads with copies of sample 0
+    per_rank = padded // world
+    sl = slice(rank * per_rank, (rank + 1) * per_rank)
+    return idx[sl], is_pad[sl]
+
+
+def reduce_metrics(sums: np.ndarray, device=None) -> np.ndarray:
+    """all_reduce(SUM) of the additive metric vector (float64); identity for single-process runs."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(sums, dtype=np.float64)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor(np.asarray(sums, dtype=np.float64), device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()

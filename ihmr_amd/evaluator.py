@@ -1,0 +1,103 @@
+"""Host-side evaluation, mirroring the metric half of the reference's ``src/utils/evaluator.py`` and
+``src/utils/metric_utils.py`` (CPU / numpy in the reference too; the visualisation half is out of scope).
+
+``Evaluator.update(data_idxs, pred_results)`` consumes the dict of ``get_pred_result()`` exactly like
+``evaluator.py:38-97``; the four reported metrics are ``mpjpe_3d``, ``inter_mpjpe_3d``, ``collision_ave``,
+``collision_max`` (``evaluator.py:149-181``, printed by ``optimize.py:98-102``).  For multi-GPU runs
+``metric_sums()`` returns the additive form that :func:`ihmr_amd.dist.reduce_metrics` all-reduces.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def get_single_joints_error(pred, gt, joint_weights, scale_factor):
+    """metric_utils.py:23-38 -- per-hand MPJPE; the root subtraction is cumulative on the same copies."""
+    a, b = pred.copy(), gt.copy()
+    errors = []
+    for i in (0, 21):
+        if joint_weights[i, 0] > 0:
+            a -= a[i:i + 1, :]
+            b -= b[i:i + 1, :]
+            for j in range(21):
+                if joint_weights[i + j, 0] > 0:
+                    errors.append(np.linalg.norm(a[i + j] - b[i + j]) / scale_factor)
+    return errors
+
+
+def calc_transform_no_rot(S1, S2):
+    """metric_utils.py:107-117 -- per-axis mean / std alignment."""
+    m1, m2 = np.mean(S1, axis=0).reshape(1, 3), np.mean(S2, axis=0).reshape(1, 3)
+    s1, s2 = np.std(S1, axis=0).reshape(1, 3), np.std(S2, axis=0).reshape(1, 3)
+    return (S1 - m1) / s1 * s2 + m2
+
+
+def get_single_pa_inter_joints_error(pred, gt, joints_valid, scale_factor):
+    """metric_utils.py:120-143 with use_rot=False."""
+    v = joints_valid[:, 0] if joints_valid.ndim == 2 else joints_valid
+    if np.sum(v) < 2.0:
+        return []
+    p, g = pred[v > 0, :3], gt[v > 0, :3]
+    return (np.linalg.norm(calc_transform_no_rot(p.copy(), g.copy()) - g, axis=1) / scale_factor).tolist()
+
+
+class Evaluator:
+    def __init__(self, mano_models=None, data_list=None):
+        self.left_hand_faces = None if mano_models is None else mano_models["left"].faces
+        self.right_hand_faces = None if mano_models is None else mano_models["right"].faces
+        self.data_list = data_list or {}
+        self.pred_results = []
+
+    def clear(self):
+        self.pred_results = []
+
+    def gather_pred(self, pred_results):
+        self.pred_results += pred_results
+
+    def update(self, data_idxs, pred_results, hand_type="interacting", scale=1.0):
+        for i, data_idx in enumerate(np.asarray(data_idxs).tolist()):
+            meta = self.data_list.get(data_idx, {}) if isinstance(self.data_list, dict) else {}
+            single = dict(
+                data_idx=data_idx, img_path_relative=meta.get("img_path", f"synthetic/{data_idx:08d}.jpg"),
+                pred_cam_params=pred_results["pred_cam_params"][i], pred_shape_params=pred_results["pred_shape_params"][i],
+                pred_pose_params=pred_results["pred_pose_params"][i], pred_hand_trans=pred_results["pred_hand_trans"][i],
+                pred_joints_3d=pred_results["pred_joints_3d"][i], gt_joints_3d=pred_results["gt_joints_3d"][i],
+                collision_loss_origin_scale=pred_results["collision_loss_origin_scale"][i],
+                hand_type=meta.get("hand_type", hand_type), scale=meta.get("scale", scale))
+            gt = single["gt_joints_3d"]
+            single["j3d_error"] = get_single_joints_error(single["pred_joints_3d"], gt[:, :3], gt[:, 3:], single["scale"])
+            single["pa_no_rot_inter_j3d_error"] = get_single_pa_inter_joints_error(
+                single["pred_joints_3d"], gt[:, :3], gt[:, 3:], single["scale"])
+            self.pred_results.append(single)
+
+    def remove_redunc(self):
+        """evaluator.py:137-146: drop the padding duplicates (same image id)."""
+        seen, out = set(), []
+        for d in self.pred_results:
+            if d["img_path_relative"] not in seen:
+                out.append(d)
+                seen.add(d["img_path_relative"])
+        self.pred_results = out
+
+    def metric_sums(self):
+        """[sum mpjpe, n, sum inter, n, sum coll_ave, sum coll_max, n_interacting] (float64, additive over ranks)."""
+        e = [x for p in self.pred_results for x in p["j3d_error"]]
+        pa = [x for p in self.pred_results for x in p["pa_no_rot_inter_j3d_error"]]
+        inter = [p for p in self.pred_results if p["hand_type"] == "interacting"]
+        ca = [np.mean(p["collision_loss_origin_scale"]) * 1000 for p in inter]
+        cm = [np.max(p["collision_loss_origin_scale"]) * 1000 for p in inter]
+        return np.array([np.sum(e), len(e), np.sum(pa), len(pa), np.sum(ca), np.sum(cm), len(inter)], dtype=np.float64)
+
+    @staticmethod
+    def metrics_from_sums(s):
+        d = lambda a, b: float(a / b) if b > 0 else float("nan")
+        return dict(mpjpe_3d=d(s[0], s[1]), inter_mpjpe_3d=d(s[2], s[3]), collision_ave=d(s[4], s[6]), collision_max=d(s[5], s[6]))
+
+    @property
+    def mpjpe_3d(self): return self.metrics_from_sums(self.metric_sums())["mpjpe_3d"]
+    @property
+    def inter_mpjpe_3d(self): return self.metrics_from_sums(self.metric_sums())["inter_mpjpe_3d"]
+    @property
+    def collision_ave(self): return self.metrics_from_sums(self.metric_sums())["collision_ave"]
+    @property
+    def collision_max(self): return self.metrics_from_sums(self.metric_sums())["collision_max"]

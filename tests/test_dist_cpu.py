@@ -1,0 +1,98 @@
+"""world_size-2 gloo tests of the sharding + metric reduction (CPU, no GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_pred(idx, rng):
+    n = len(idx)
+    gt = rng.normal(0, 0.05, (n, 42, 3)).astype(np.float32)
+    pred = gt + rng.normal(0, 0.005, (n, 42, 3)).astype(np.float32)
+    return dict(pred_cam_params=np.zeros((n, 3), np.float32), pred_shape_params=np.zeros((n, 20), np.float32),
+                pred_pose_params=np.zeros((n, 96), np.float32), pred_hand_trans=np.zeros((n, 1, 3), np.float32),
+                pred_joints_3d=pred, gt_joints_3d=np.concatenate([gt, np.ones((n, 42, 1), np.float32)], 2),
+                collision_loss_origin_scale=np.abs(rng.normal(0, 1e-3, (n, 1556))).astype(np.float32))
+
+
+def _all_preds(num):
+    rng = np.random.RandomState(0)
+    return _fake_pred(np.arange(num), rng)
+
+
+def _worker(rank, world, port, num, bs, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ihmr_amd import dist as D
+    from ihmr_amd.evaluator import Evaluator
+    r, w = D.init_dist("gloo")
+    assert (r, w) == (rank, world)
+    idx, pad = D.shard_indices(num, bs, r, w)
+    full = _all_preds(num)
+    ev = Evaluator()
+    for s in range(0, len(idx), bs):
+        sel = idx[s:s + bs]
+        keep = ~pad[s:s + bs]
+        pr = {k: v[sel] for k, v in full.items()}
+        ev.update(sel, pr)
+        new = ev.pred_results[-len(sel):]
+        ev.pred_results = ev.pred_results[:-len(sel)] + [p for p, k in zip(new, keep) if k]   # mask padding duplicates
+    total = D.reduce_metrics(ev.metric_sums())
+    if rank == 0:
+        np.save(out, total)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_metric_reduction_matches_single_process(tmp_path):
+    sys.path.insert(0, ROOT)
+    from ihmr_amd.evaluator import Evaluator
+    num, bs, world = 13, 4, 2          # 13 samples pad to 16 = 2 ranks x 2 batches of 4
+    out = str(tmp_path / "sums.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, num, bs, out), nprocs=world, join=True)
+    got = np.load(out)
+    ev = Evaluator()
+    ev.update(np.arange(num), _all_preds(num))
+    ref = ev.metric_sums()
+    assert np.allclose(got, ref, rtol=1e-10, atol=1e-12), (got, ref)   # float64 sums, different association
+    m = Evaluator.metrics_from_sums(got)
+    assert m["mpjpe_3d"] > 0 and m["collision_max"] >= m["collision_ave"]
+
+
+def test_shard_indices_cover_and_pad():
+    sys.path.insert(0, ROOT)
+    from ihmr_amd.dist import shard_indices
+    seen, pads = [], 0
+    for r in range(4):
+        idx, pad = shard_indices(70, 8, r, 4)
+        assert len(idx) == 24                      # 70 -> 96 = 4 ranks x 3 batches of 8
+        seen += idx[~pad].tolist()
+        pads += int(pad.sum())
+        assert np.all(idx[pad] == 0)
+    assert sorted(seen) == list(range(70)) and pads == 26
+
+
+def test_evaluator_matches_reference_metrics():
+    """the product's host evaluator against the golden vectors captured from the reference's metric_utils"""
+    sys.path.insert(0, ROOT)
+    from ihmr_amd import evaluator as E
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "metrics.npz")))
+    for i in range(4):
+        a = E.get_single_joints_error(g[f"pred_{i}"], g[f"gt_{i}"], g[f"valid_{i}"], float(g[f"scale_{i}"]))
+        assert np.allclose(a, g[f"j3d_err_{i}"], atol=1e-9)
+        p = E.get_single_pa_inter_joints_error(g[f"pred_{i}"], g[f"gt_{i}"], g[f"valid_{i}"], float(g[f"scale_{i}"]))
+        assert np.allclose(p, g[f"pa_err_{i}"], atol=1e-7)
