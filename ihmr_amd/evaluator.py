@@ -84,9 +84,10 @@ class Evaluator:
         e = [x for p in self.pred_results for x in p["j3d_error"]]
         pa = [x for p in self.pred_results for x in p["pa_no_rot_inter_j3d_error"]]
         inter = [p for p in self.pred_results if p["hand_type"] == "interacting"]
-        ca = [np.mean(p["collision_loss_origin_scale"]) * 1000 for p in inter]
-        cm = [np.max(p["collision_loss_origin_scale"]) * 1000 for p in inter]
-        return np.array([np.sum(e), len(e), np.sum(pa), len(pa), np.sum(ca), np.sum(cm), len(inter)], dtype=np.float64)
+        ca = [np.mean(p["collision_loss_origin_scale"].astype(np.float64)) * 1000 for p in inter]
+        cm = [np.max(p["collision_loss_origin_scale"].astype(np.float64)) * 1000 for p in inter]
+        f64 = lambda x: float(np.sum(np.asarray(x, dtype=np.float64)))
+        return np.array([f64(e), len(e), f64(pa), len(pa), f64(ca), f64(cm), len(inter)], dtype=np.float64)
 
     @staticmethod
     def metrics_from_sums(s):
