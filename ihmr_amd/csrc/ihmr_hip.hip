@@ -10,6 +10,7 @@
 #include "mano_lbs.h"
 #include "sdf_collision.h"
 #include "refine.h"
+#include "encoder.h"
 
 static ihmr_kernel_timer* g_timer = nullptr;
 struct TimedPair { hipEvent_t a, b; double flops; };
@@ -402,6 +403,35 @@ extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, c
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(out4, ws.stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------ encoder
+extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias, const float* residual, float* y, int N, int H,
+                               int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int ldx, int ldw,
+                               int ldy, int ldr, int act, void* stream) {
+    if (!x || !w || !y || N <= 0 || Cout <= 0) return -1;
+    ConvArgs a{x, w, bias, residual, y, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, ldx, ldw, ldy, ldr, act};
+    const int M = N * Ho * Wo;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout > 64 && ldw % 128 == 0) {
+        hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3((M + CONV_BM - 1) / CONV_BM, (Cout + 127) / 128), dim3(CONV_THREADS), 0, st, a);
+    } else {
+        if (ldw % 64 != 0) return -1;
+        hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3((M + CONV_BM - 1) / CONV_BM, (Cout + 63) / 64), dim3(CONV_THREADS), 0, st, a);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+    if (C % 4) return -1;
+    const long total = (long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, Ho, Wo);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_avgpool_relu(const float* x, float* y, int N, int HW, int C, int ldy, void* stream) {
+    hipLaunchKernelGGL(avgpool_relu_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, N, HW, C, ldy);
+    return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------ misc

@@ -1,0 +1,93 @@
+"""GPU parity of the encoder kernels (fp32 implicit GEMM on MFMA) against the CPU oracle / plain PyTorch fp32."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _report(name, got, ref, atol, rtol):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(got - ref)
+    print(f"[parity] {name}: max|err|={err.max():.3e} max|ref|={np.abs(ref).max():.3e}")
+    assert np.all(err <= atol + rtol * np.abs(ref)), f"{name}: max err {err.max():.3e}"
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, H=14, W=14, Cin=64, Cout=64, k=3, s=1, p=1),      # 3x3, M = 392 (tail tile), narrow tile
+    dict(N=3, H=15, W=13, Cin=32, Cout=160, k=3, s=2, p=1),     # odd sizes, stride 2, Cout not a tile multiple
+    dict(N=2, H=28, W=28, Cin=128, Cout=256, k=1, s=2, p=0),    # strided 1x1 (downsample)
+    dict(N=2, H=32, W=32, Cin=3, Cout=64, k=7, s=2, p=3),       # stem-like, Cin = 3 (generic gather path)
+])
+def test_conv_igemm_matches_torch(cfg):
+    from ihmr_amd.networks import _Packed, conv_igemm
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(cfg["N"], cfg["Cin"], cfg["H"], cfg["W"], generator=g)
+    w = torch.randn(cfg["Cout"], cfg["Cin"], cfg["k"], cfg["k"], generator=g) / np.sqrt(cfg["Cin"] * cfg["k"] ** 2)
+    b = torch.randn(cfg["Cout"], generator=g)
+    ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=cfg["s"], padding=cfg["p"]))
+    pk = _Packed(w.cuda(), b.cuda(), stride=cfg["s"], pad=cfg["p"])
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y, Ho, Wo = conv_igemm(xn, pk, cfg["N"], cfg["H"], cfg["W"], ldx=cfg["Cin"], act=1)
+    got = y.view(cfg["N"], Ho, Wo, cfg["Cout"]).permute(0, 3, 1, 2).cpu()
+    # fp32 products summed in a different order: K <= 1152 terms of O(1/sqrt(K)) -> 1e-5 absolute is ample
+    _report(f"conv {cfg}", got, ref, atol=2e-5, rtol=1e-5)
+
+
+def test_encoder_matches_oracle():
+    from helpers import seeded_state_dict
+    from ihmr_amd.networks import InterHandEncoder
+    from oracle.encoder_ref import InterHandEncoderRef
+    rng = np.random.RandomState(3)
+    mean_params = torch.tensor(rng.normal(0, 0.2, (1, 122)), dtype=torch.float32)
+    mean_params[0, 0] = 5.0
+    B = 2
+    ref = InterHandEncoderRef(mean_params.repeat(B, 1))
+    sd = seeded_state_dict(ref, 100)
+    ref.load_state_dict(sd)
+    ref.eval()
+    enc = InterHandEncoder(types.SimpleNamespace(total_params_dim=122), mean_params.repeat(B, 1))
+    assert list(enc.state_dict().keys()) == list(ref.state_dict().keys())
+    enc.load_state_dict(sd)
+    img = torch.tensor(np.random.RandomState(7).uniform(-1, 1, (B, 3, 224, 224)), dtype=torch.float32)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        p_ref, h_ref = ref(img)
+        f_ref = ref.main_encoder(img)
+    enc = enc.cuda()
+    p, h = enc(img.cuda())
+    torch.cuda.synchronize()
+    # 53 fp32 layers with different summation order and folded BN: 1e-4 relative to the feature scale
+    _report("main_feat", enc.main_feat.cpu(), f_ref, atol=1e-4 * float(f_ref.abs().max()), rtol=1e-4)
+    _report("pred_params", p.cpu(), p_ref, atol=1e-4, rtol=1e-4)
+    _report("hand_class", h.cpu(), h_ref, atol=1e-5, rtol=0)
+
+
+def test_encoder_matches_reference_golden():
+    """Same seeded weights / image as tests/golden/encoder.npz (outputs of the reference's own InterHandEncoder)."""
+    import os
+    from helpers import seeded_state_dict
+    from ihmr_amd.networks import InterHandEncoder
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "encoder.npz")))
+    mean_params = torch.tensor(g["mean_params"])
+    enc = InterHandEncoder(types.SimpleNamespace(total_params_dim=122), mean_params.repeat(2, 1))
+    enc.load_state_dict(seeded_state_dict(enc, 100))
+    img = torch.tensor(np.random.RandomState(7).uniform(-1, 1, (2, 3, 224, 224)), dtype=torch.float32)
+    p, h = enc.cuda()(img.cuda())
+    _report("golden params", p.cpu(), g["params"], atol=1e-4, rtol=1e-4)
+    _report("golden hand_class", h.cpu(), g["hand_class"], atol=1e-5, rtol=0)
+    _report("golden main_feat", enc.main_feat.cpu(), g["main_feat"], atol=1e-4 * float(np.abs(g["main_feat"]).max()), rtol=1e-4)
+
+
+def test_mlp_head_matches_reference_golden():
+    import os
+    from helpers import seeded_state_dict
+    from ihmr_amd.networks import InterHandSubNetwork
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "mlp_head.npz")))
+    for k in (3, 90):
+        net = InterHandSubNetwork(None, 1146, k)
+        net.load_state_dict(seeded_state_dict(net, 500 + k))
+        y = net.cuda()(torch.tensor(g[f"x_{k}"]).cuda())
+        _report(f"mlp head {k}", y.cpu(), g[f"y_{k}"], atol=1e-6, rtol=1e-4)
