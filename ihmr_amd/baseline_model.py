@@ -1,0 +1,151 @@
+"""``InterHandModel`` -- IHMR-Baseline inference on the HIP path, with the call surface the reference's
+``src/test_baseline.py:45-61`` uses: ``InterHandModel(opt)``, ``.encoder``, ``.load_network(net, 'baseline', epoch)``,
+``.eval()``, ``.set_input(data)``, ``.test()``, ``.get_pred_result()`` (``src/models/baseline_model.py``).
+
+forward (``baseline_model.py:257-282``): encoder (ResNet-50 + IEF head on the matrix cores) -> slice the
+122-vector ``[cam 3 | pose 96 | shape 20 | trans 3]`` (``:262-270``) -> MANO for predicted AND ground-truth
+parameters with SEPARATE right / left models, no mirroring (``:208-254``) -> orthographic projection;
+``test()`` (``:350-355``) adds the collision term for the metric.  Training (``backward_E``), DDP and
+visualisation are out of scope.
+"""
+from __future__ import annotations
+
+import os.path as osp
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import hip
+from . import mano as mano_shim
+from . import ry_utils
+from .networks import InterHandEncoder
+from .sdf import SDFLoss
+
+TIP_IDS = (744, 320, 443, 554, 671)  # baseline_model.py:136
+
+
+def batch_orthogonal_project(X, camera):
+    """transform_utils.py:47-54 (device-side tensor glue)."""
+    camera = camera.view(-1, 1, 3)
+    return (X[:, :, :2] + camera[:, :, 1:]) * camera[:, :, 0:1]
+
+
+class InterHandModel:
+    name = "InterHandModel"
+
+    def __init__(self, opt):
+        hip.require_gpu()
+        self.opt = opt
+        self.isTrain = getattr(opt, "isTrain", False)
+        assert not self.isTrain, "training is outside the hot path of this build"
+        self.inputSize = opt.inputSize
+        self.batch_size = opt.batchSize
+        self.cam_params_dim, self.pose_params_dim = opt.cam_params_dim, opt.pose_params_dim
+        self.shape_params_dim, self.trans_params_dim = opt.shape_params_dim, opt.trans_params_dim
+        self.total_params_dim = opt.total_params_dim
+        assert self.total_params_dim == self.cam_params_dim + self.trans_params_dim + self.pose_params_dim + self.shape_params_dim
+        self.save_dir = getattr(opt, "checkpoints_dir", "./checkpoints")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.load_mean_params()
+        self.load_mano_model()
+        self.sdf_loss = SDFLoss(self.mano_models["right"].faces, self.mano_models["left"].faces, robustifier=None).to(self.device)
+        self.encoder = InterHandEncoder(opt, self.mean_params).to(self.device)
+
+    # baseline_model.py:105-130
+    def load_mean_params(self):
+        f = osp.join(getattr(self.opt, "model_root", "") or "", getattr(self.opt, "mean_param_file", "mean_mano_params.pkl"))
+        mean_params = np.zeros((1, self.total_params_dim))
+        mean_params[0, 0] = 5.0
+        if osp.isfile(f):
+            mv = ry_utils.load_pkl(f)
+            mean_pose = np.array(mv["mean_pose"], dtype=np.float64).copy()
+            mean_pose[:3] = 0.0
+            mean_shape = np.array(mv["mean_betas"], dtype=np.float64).reshape(10)
+        else:  # the HMR mean-parameter file is not shipped: neutral pose / shape
+            mean_pose, mean_shape = np.zeros(48), np.zeros(10)
+        mean_params[0, 3:] = np.hstack((np.tile(mean_pose, 2), np.tile(mean_shape, 2), np.zeros(3)))
+        self.mean_params = torch.from_numpy(np.repeat(mean_params, self.batch_size, axis=0)).float()
+
+    # baseline_model.py:133-153
+    def load_mano_model(self):
+        root = getattr(self.opt, "model_root", "") or ""
+        models = {}
+        for hand_type in ["left", "right"]:
+            f = osp.join(root, f"MANO_{hand_type.upper()}.pkl")
+            models[hand_type] = mano_shim.create(f, "mano", use_pca=False, is_rhand=(hand_type == "right"), batch_size=self.batch_size)
+        diff = torch.mean(torch.abs(models["left"].shapedirs[:, 0, :] - models["right"].shapedirs[:, 0, :]))
+        if diff < 1e-7:
+            models["left"].shapedirs[:, 0, :] *= -1
+        self.mano_models = {k: m.to(self.device) for k, m in models.items()}
+
+    def eval(self):
+        self.encoder.eval()
+        return self
+
+    # base_model.py:45-61
+    def load_network(self, network, model_name, epoch, stage_id=None):
+        name = f"{epoch}_net_{model_name}.pth" if stage_id is None else f"{epoch}_net_{model_name}_stage_{stage_id:02d}.pth"
+        path = osp.join(self.save_dir, name)
+        if not osp.exists(path):
+            print(f"{path} does not exist !!!")
+            return False
+        network.load_state_dict(torch.load(path, map_location="cpu"))
+        return True
+
+    # baseline_model.py:178-205
+    def set_input(self, input):
+        dev = self.device
+        g = lambda k: input[k].to(dev, dtype=torch.float32, non_blocking=True)
+        self.input_img = g("img")
+        self.do_flip = input["do_flip"].to(dev).bool() if "do_flip" in input else torch.zeros(self.batch_size, device=dev, dtype=torch.bool)
+        self.hand_type_array, self.hand_type_valid = g("hand_type_array"), g("hand_type_valid")
+        self.joints_2d, self.joints_3d, self.hand_trans = g("joints_2d"), g("joints_3d"), g("hand_trans")
+        self.gt_pose_params, self.gt_shape_params = g("mano_pose"), g("mano_betas")
+        self.mano_params_weight = g("mano_params_weight")
+
+    # baseline_model.py:208-254 -- separate right / left models, no mirroring
+    def get_mano_output(self, pose_params, shape_params, hand_trans):
+        verts, joints = {}, {}
+        for hand_type, ps, bs in (("right", 0, 0), ("left", 48, 10)):
+            out = self.mano_models[hand_type](global_orient=pose_params[:, ps:ps + 3].contiguous(),
+                                              hand_pose=pose_params[:, ps + 3:ps + 48].contiguous(),
+                                              betas=shape_params[:, bs:bs + 10].contiguous())
+            verts[hand_type] = out.vertices
+            joints[hand_type] = torch.cat([out.joints, out.vertices[:, list(TIP_IDS), :]], dim=1)
+        shift = hand_trans.reshape(-1, 1, 3) + (joints["right"][:, 0:1, :] - joints["left"][:, 0:1, :])
+        return verts["right"], verts["left"] + shift, torch.cat([joints["right"], joints["left"] + shift], dim=1)
+
+    # baseline_model.py:257-282
+    @torch.no_grad()
+    def forward(self):
+        self.final_params, self.pred_hand_type = self.encoder(self.input_img)
+        c, p, s = self.cam_params_dim, self.pose_params_dim, self.shape_params_dim
+        self.pred_cam_params = self.final_params[:, :c]
+        self.pred_pose_params = self.final_params[:, c:c + p]
+        self.pred_shape_params = self.final_params[:, c + p:c + p + s]
+        self.pred_hand_trans = self.final_params[:, c + p + s:]
+        self.pred_right_hand_verts, self.pred_left_hand_verts, self.pred_joints_3d = self.get_mano_output(
+            self.pred_pose_params, self.pred_shape_params, self.pred_hand_trans)
+        self.pred_joints_2d = batch_orthogonal_project(self.pred_joints_3d, self.pred_cam_params)
+        self.gt_right_hand_verts, self.gt_left_hand_verts, self.gt_joints_3d_mano = self.get_mano_output(
+            self.gt_pose_params, self.gt_shape_params, self.hand_trans[:, :, :3])
+
+    # baseline_model.py:350-355
+    @torch.no_grad()
+    def test(self):
+        self.forward()
+        hv = torch.stack([self.pred_right_hand_verts, self.pred_left_hand_verts], dim=1).contiguous()
+        _, _, self.collision_loss_origin_scale = self.sdf_loss(hv, return_per_vert_loss=True, return_origin_scale_loss=True)
+
+    # baseline_model.py:358-375
+    def get_pred_result(self):
+        n = lambda t: t.detach().cpu().numpy()
+        return OrderedDict(
+            pred_cam_params=n(self.pred_cam_params), pred_hand_type=n(self.pred_hand_type),
+            pred_pose_params=n(self.pred_pose_params), pred_shape_params=n(self.pred_shape_params),
+            pred_hand_trans=n(self.pred_hand_trans), gt_right_hand_verts=n(self.gt_right_hand_verts),
+            gt_left_hand_verts=n(self.gt_left_hand_verts), pred_right_hand_verts=n(self.pred_right_hand_verts),
+            pred_left_hand_verts=n(self.pred_left_hand_verts), mano_params_weight=n(self.mano_params_weight),
+            pred_joints_3d=n(self.pred_joints_3d), gt_joints_3d=n(self.joints_3d),
+            collision_loss_origin_scale=n(self.collision_loss_origin_scale), do_flip=n(self.do_flip))

@@ -21,7 +21,7 @@ def two_hand_forward(mano_right, right_orient, left_orient, right_pose, left_pos
     flip = torch.tensor([-1.0, 1.0, 1.0], device=verts.device)
     rv, rj = verts[:bs], joints[:bs]
     lv, lj = verts[bs:] * flip, joints[bs:] * flip
-    shift = hand_trans.view(bs, 1, 3) + (rj[:, 0:1, :] - lj[:, 0:1, :])
+    shift = hand_trans.reshape(bs, 1, 3) + (rj[:, 0:1, :] - lj[:, 0:1, :])
     return rv, lv + shift, torch.cat([rj, lj + shift], dim=1)
 
 

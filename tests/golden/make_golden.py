@@ -240,10 +240,64 @@ def gen_metrics(ns):
     print("metrics.npz")
 
 
+def make_mlp_batch(B, seed):
+    """Synthetic IHMR-MLP batch (schema of data/mlp_dataset.py:185-208) from the OPT synthetic batch."""
+    from ihmr_amd.assets import synthetic_mano
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    from oracle.opt_ref import OptimizeRef
+    helper = OptimizeRef(synthetic_mano(True), synthetic_mano(False), B, [], save_mid_freq=1)
+
+    def fwd(pose, shape, trans):
+        helper.pred_right_orient, helper.pred_left_orient = pose[:, :3], pose[:, 48:51]
+        helper.pred_right_pose_params, helper.pred_left_pose_params = pose[:, 3:48], pose[:, 51:]
+        helper.pred_right_shape_params, helper.pred_left_shape_params = shape[:, :10], shape[:, 10:]
+        helper.pred_hand_trans = trans.view(-1, 1, 3)
+        return helper.get_mano_output()[2]
+
+    b = synthetic_opt_batch(B, fwd, seed=seed, with_feat=True)
+    b["init_hand_trans"] = b["init_hand_trans"][:, 0, :3].contiguous()
+    b["img"] = torch.zeros(B, 3, 8, 8)
+    b.pop("init_hand_trans_j")
+    return b
+
+
+def gen_mlp_test(ns):
+    """The reference's MLPModel.test() (mlp_model.py:683-699) with six seeded sub-networks on a synthetic batch."""
+    import importlib
+    import sys as _sys
+    from helpers import seeded_state_dict
+    _sys.modules["ry_utils"].load_pkl = lambda p: {"mean_pose": np.zeros(48), "mean_betas": np.zeros(10)}
+    mlp_model = importlib.import_module("models.mlp_model")
+    B = 3
+    opt = make_opt(B, strategy="mlp_default")
+    opt.total_epoch = 1
+    opt.pretrain_weights_dir = None
+    model = mlp_model.MLPModel(opt)
+    batch = make_mlp_batch(B, 777)
+    batch["joints_3d"][1, 0, 3] = 0.0          # one sample without a right wrist in the GT weights
+    model.set_input({k: v.clone() for k, v in batch.items()})
+    strategy = ns.strategies.strategies["mlp_default"]
+    model.set_update_info(strategy, 10)
+    for sid in range(len(strategy)):
+        model.add_new_network(sid)
+        net = model.sub_network_list[sid]
+        net.load_state_dict(seeded_state_dict(net, 900 + sid, last_scale=0.02))
+        net.eval()
+    model.set_input({k: v.clone() for k, v in batch.items()})
+    model.test()
+    res = model.get_pred_result()
+    out = {f"in_{k}": v for k, v in batch.items()}
+    out.update({f"out_{k}": v for k, v in res.items()})
+    out["out_joints_3d_loss_p_batch"] = model.joints_3d_loss_p_batch
+    out["out_joints_2d_loss_p_batch"] = model.joints_2d_loss_p_batch
+    np.savez_compressed(osp.join(HERE, "mlp_test.npz"), **t2n(out))
+    print("mlp_test.npz", {k: np.asarray(v).shape for k, v in res.items() if k.startswith("pred_")})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ns = import_reference()
-    which = sys.argv[1:] or ["losses", "select", "opt_traj", "encoder", "mlp_head", "metrics"]
+    which = sys.argv[1:] or ["losses", "select", "opt_traj", "encoder", "mlp_head", "metrics", "mlp_test"]
     for w in which:
         globals()[f"gen_{w}"](ns)

@@ -3,7 +3,7 @@ import numpy as np
 import torch
 
 
-def seeded_state_dict(module, seed):
+def seeded_state_dict(module, seed, last_scale=None):
     """Deterministic weights reproducible on any side: tensor i of ``state_dict()`` (in order) is drawn
     from RandomState(seed + i); conv/linear weights ~ N(0, 1/fan_in), BN gamma ~ U(0.5,1.5),
     beta / bias ~ N(0, 0.05), running_mean ~ N(0, 0.1), running_var ~ U(0.5, 1.5)."""
@@ -25,4 +25,8 @@ def seeded_state_dict(module, seed):
                                   dtype=torch.float32)
         else:
             new[k] = torch.tensor(rng.normal(0, 0.05, shp), dtype=torch.float32)
+    if last_scale is not None:  # shrink the output layer (small residual updates, like the trained MLP heads)
+        last = [k for k in new if k.endswith('weight')][-1]
+        new[last] = new[last] * last_scale
+        new[last.replace('weight', 'bias')] = new[last.replace('weight', 'bias')] * last_scale
     return new

@@ -1,0 +1,118 @@
+"""GPU parity of the model-level paths: IHMR-Baseline (`InterHandModel.test`) and IHMR-MLP (`MLPModel.test`)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _opt(B, **kw):
+    d = dict(isTrain=False, dist=False, process_rank=-1, batchSize=B, inputSize=224, input_nc=3, num_joints=42,
+             total_params_dim=122, cam_params_dim=3, pose_params_dim=96, shape_params_dim=20, trans_params_dim=3,
+             model_root="", mean_param_file="mean_mano_params.pkl", checkpoints_dir="./checkpoints", strategy="mlp_default")
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def _report(name, got, ref, atol, rtol=0.0):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(got - ref)
+    print(f"[parity] {name}: max|err|={err.max():.3e} max|ref|={np.abs(ref).max():.3e}")
+    assert np.all(err <= atol + rtol * np.abs(ref)), f"{name}: max err {err.max():.3e}"
+
+
+def test_mlp_model_matches_reference_golden_and_oracle(mano_arrays):
+    from helpers import seeded_state_dict
+    from ihmr_amd.mlp_model import MLPModel
+    from ihmr_amd.strategies import make_mlp_strategy
+    from oracle.mlp_ref import MLPRef
+    g = dict(np.load(os.path.join(GOLD, "mlp_test.npz")))
+    batch = {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("in_")}
+    B = batch["init_cam"].shape[0]
+    strategy = make_mlp_strategy()
+    model = MLPModel(_opt(B))
+    model.set_update_info(strategy, 10)
+    right, left = mano_arrays
+    orc = MLPRef(right, left, B, strategy, num_data=10)
+    for sid in range(len(strategy)):
+        model.add_new_network(sid)
+        sd = seeded_state_dict(orc.nets[sid], 900 + sid, last_scale=0.02)
+        orc.nets[sid].load_state_dict(sd)
+        model.sub_network_list[sid].load_state_dict(sd)
+    model.eval()
+    model.set_input(batch)
+    model.test()
+    torch.cuda.synchronize()
+    res = model.get_pred_result()
+    orc.set_input(batch)
+    orc.test()
+    kept_ref = np.stack(orc.kept_history)
+    kept_got = torch.stack(model.kept_history).cpu().numpy()
+    print("[parity] kept ref", kept_ref.astype(int).tolist(), "got", kept_got.astype(int).tolist())
+    assert np.array_equal(kept_ref, kept_got), "per-stage keep/reject decisions differ"
+    for k in ("pred_cam_params", "pred_pose_params", "pred_shape_params", "pred_hand_trans"):
+        _report(f"mlp {k} vs reference", res[k], g[f"out_{k}"], atol=2e-5)
+    for k in ("pred_right_hand_verts", "pred_left_hand_verts", "pred_joints_3d", "gt_right_hand_verts", "gt_left_hand_verts", "gt_joints_3d"):
+        _report(f"mlp {k} vs reference [m]", res[k], g[f"out_{k}"], atol=1e-5)
+    _report("mlp collision origin scale vs reference [m]", res["collision_loss_origin_scale"], g["out_collision_loss_origin_scale"], atol=1e-5)
+    _report("mlp collision_loss vs reference", res["collision_loss"], g["out_collision_loss"], atol=1e-4, rtol=1e-4)
+
+
+def test_baseline_model_matches_oracle(mano_arrays):
+    """InterHandModel.test(): encoder -> separate right/left MANO -> shift -> projection -> collision metric."""
+    from helpers import seeded_state_dict
+    from ihmr_amd.baseline_model import InterHandModel
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    from oracle import losses_ref as L
+    from oracle.encoder_ref import InterHandEncoderRef
+    from oracle.mano_ref import ManoRef
+    from oracle.sdf_ref import SDFLossRef
+    right, left = mano_arrays
+    B = 2
+    model = InterHandModel(_opt(B))
+    ref_enc = InterHandEncoderRef(model.mean_params.clone())
+    sd = seeded_state_dict(ref_enc, 100)
+    # shrink the IEF regressor so that the predicted pose stays hand-like
+    sd["regressor_ih.0.weight"] *= 0.05
+    sd["regressor_ih.0.bias"] *= 0.05
+    ref_enc.load_state_dict(sd)
+    ref_enc.eval()
+    model.encoder.load_state_dict(sd)
+    model.eval()
+    mr = ManoRef(right)
+    l_arr = dict(left); l_arr["shapedirs"] = left["shapedirs"].copy(); l_arr["shapedirs"][:, 0, :] *= -1
+    ml = ManoRef(l_arr)
+
+    def two(pose, shape, trans):
+        outs = {}
+        for name, m, ps, bs in (("right", mr, 0, 0), ("left", ml, 48, 10)):
+            o = m(global_orient=pose[:, ps:ps + 3], hand_pose=pose[:, ps + 3:ps + 48], betas=shape[:, bs:bs + 10])
+            outs[name] = (o.vertices, torch.cat([o.joints, o.vertices[:, [744, 320, 443, 554, 671]]], 1))
+        shift = trans.reshape(-1, 1, 3) + (outs["right"][1][:, 0:1] - outs["left"][1][:, 0:1])
+        return outs["right"][0], outs["left"][0] + shift, torch.cat([outs["right"][1], outs["left"][1] + shift], 1)
+
+    batch = synthetic_opt_batch(B, lambda p, s, t: two(p, s, t)[2], seed=99, with_image=True)
+    model.set_input(batch)
+    model.test()
+    torch.cuda.synchronize()
+    res = model.get_pred_result()
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        fp, hc = ref_enc(batch["img"])
+        rv, lv, j3 = two(fp[:, 3:99], fp[:, 99:119], fp[:, 119:122])
+        j2 = L.batch_orthogonal_project(j3, fp[:, :3])
+        _, _, os_ = SDFLossRef(right["faces"], left["faces"])(torch.stack([rv, lv], 1), return_per_vert_loss=True, return_origin_scale_loss=True)
+        grv, glv, _ = two(batch["mano_pose"], batch["mano_betas"], batch["hand_trans"][:, 0, :3])
+    _report("baseline params", np.concatenate([res["pred_cam_params"], res["pred_pose_params"], res["pred_shape_params"], res["pred_hand_trans"]], 1), fp, atol=1e-4, rtol=1e-4)
+    _report("baseline hand type", res["pred_hand_type"], hc, atol=1e-5)
+    _report("baseline right verts [m]", res["pred_right_hand_verts"], rv, atol=1e-4)
+    _report("baseline left verts [m]", res["pred_left_hand_verts"], lv, atol=1e-4)
+    _report("baseline joints [m]", res["pred_joints_3d"], j3, atol=1e-4)
+    _report("baseline joints 2d", model.pred_joints_2d.cpu(), j2, atol=2e-3)
+    _report("baseline gt right verts [m]", res["gt_right_hand_verts"], grv, atol=1e-6)
+    _report("baseline gt left verts [m]", res["gt_left_hand_verts"], glv, atol=1e-6)
+    _report("baseline penetration depth [m]", res["collision_loss_origin_scale"], os_, atol=1e-4)

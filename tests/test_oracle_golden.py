@@ -357,3 +357,26 @@ def test_synthetic_asset_is_mano_shaped(mano_arrays):
     comb = np.concatenate([right["faces"], left["faces"] + 778], 0)
     assert comb.dtype == np.int64 and comb.max() == 2 * 778 - 1 and comb.shape == (3076, 3)
     assert np.abs(left["shapedirs"][:, 0, :] - right["shapedirs"][:, 0, :]).mean() < 1e-7  # triggers the sign fix
+
+
+def test_mlp_test_path_matches_reference(mano_arrays):
+    """oracle MLPRef.test() == the reference's MLPModel.test() (captured in mlp_test.npz)."""
+    from helpers import seeded_state_dict
+    from ihmr_amd.strategies import make_mlp_strategy
+    from oracle.mlp_ref import MLPRef
+    g = gold("mlp_test.npz")
+    batch = {k[3:]: T(v) for k, v in g.items() if k.startswith("in_")}
+    B = batch["init_cam"].shape[0]
+    right, left = mano_arrays
+    torch.set_num_threads(8)
+    m = MLPRef(right, left, B, make_mlp_strategy(), num_data=10)
+    for sid, net in enumerate(m.nets):
+        net.load_state_dict(seeded_state_dict(net, 900 + sid, last_scale=0.02))
+    m.set_input(batch)
+    m.test()
+    res = m.get_pred_result()
+    for k, v in res.items():
+        close(v, g[f"out_{k}"], 2e-6, what=k)
+    close(m.joints_3d_loss_p_batch, g["out_joints_3d_loss_p_batch"], 1e-6, what="j3d_p batch")
+    close(m.joints_2d_loss_p_batch, g["out_joints_2d_loss_p_batch"], 1e-6, what="j2d_p batch")
+    print("kept per stage:", [k.tolist() for k in m.kept_history])
