@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's ``src/optimize.py`` (main loop :61-71, result gathering :78-102) on synthetic
+data: one process per GPU (``python -m torch.distributed.run --nproc-per-node N -m ihmr_amd.run_optimize``),
+samples sharded contiguously over the ranks, every rank refines its batches with :class:`OptimizeModel`, and the
+four reported metrics are combined with ONE all-reduce of the metric sums (instead of the reference's
+pickle-file gather + barrier).
+
+    python -m ihmr_amd.run_optimize --num_samples 256 --batchSize 64 --opt_epoch 49
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import time
+import types
+
+import numpy as np
+import torch
+
+from . import dist as D
+from . import two_hand
+from .evaluator import Evaluator
+from .optimize_model import OptimizeModel
+from .synthetic import synthetic_opt_batch
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num_samples", type=int, default=128)
+    ap.add_argument("--batchSize", type=int, default=64)
+    ap.add_argument("--opt_epoch", type=int, default=49, help="iterations per stage - 1 (reference default 300)")
+    ap.add_argument("--save_mid_freq", type=int, default=10)
+    ap.add_argument("--strategy", type=str, default="opt_default")
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args(argv)
+
+    rank, world = D.init_dist()
+    if world == 1:
+        torch.cuda.set_device(0)
+    opt = types.SimpleNamespace(isTrain=False, dist=world > 1, process_rank=rank if world > 1 else -1, batchSize=args.batchSize,
+                                inputSize=224, num_joints=42, total_params_dim=122, cam_params_dim=3, pose_params_dim=96,
+                                shape_params_dim=20, trans_params_dim=3, model_root="", strategy=args.strategy,
+                                save_mid_freq=args.save_mid_freq, optimizer="adam", opt_epoch=args.opt_epoch)
+    model = OptimizeModel(opt)
+    evaluator = Evaluator(model.mano_models)
+    fwd = lambda p, s, t: two_hand.forward_from_packed(model.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
+
+    idx, is_pad = D.shard_indices(args.num_samples, args.batchSize, rank, world)
+    t0 = time.time()
+    for s in range(0, len(idx), args.batchSize):
+        sel, pad = idx[s:s + args.batchSize], is_pad[s:s + args.batchSize]
+        # the synthetic "dataset": sample i is generated from seed + i's batch; padding entries repeat sample 0's batch row
+        data = synthetic_opt_batch(args.batchSize, fwd, seed=args.seed + int(sel[0]), first_index=int(sel[0]))
+        model.set_input(data)
+        model.init_optimize()
+        model.optimize(s // args.batchSize, len(idx) // args.batchSize, verbose=False)
+        pred = model.get_pred_result()
+        n0 = len(evaluator.pred_results)
+        evaluator.update(sel, pred)
+        new = evaluator.pred_results[n0:]
+        evaluator.pred_results = evaluator.pred_results[:n0] + [p for p, k in zip(new, ~pad) if k]   # drop padding duplicates
+    sums = D.reduce_metrics(evaluator.metric_sums())
+    elapsed = time.time() - t0
+    if rank == 0:
+        m = Evaluator.metrics_from_sums(sums)
+        for k in ("mpjpe_3d", "inter_mpjpe_3d", "collision_ave", "collision_max"):
+            print(f"{k} : {m[k]:.3f} (optimize)")
+        print(json.dumps(dict(num_samples=args.num_samples, world=world, seconds=elapsed, **m)))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
