@@ -24,7 +24,8 @@
 #define SDF_BIN_CAP 32768          // (triangle, column) pairs per hand before falling back to a full scan
 #define SDF_EVAL_CHUNKS 8          // workgroups per hand in the parity kernel
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
-#define SDF_DIST_BLOCKS_PER_XCD 64
+#define SDF_DIST_BLOCKS_PER_XCD 256
+#define SDF_ITEM 16                // inside voxels per work item of the distance kernel (one hand per item)
 
 // Per-hand, per-iteration triangle tables (float4 records, so a random triangle costs one or three
 // 16 B loads instead of a cache line per SoA row):
@@ -48,7 +49,7 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     int xcd_cap;
 };
 
-__host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)(((H / 2 + SDF_NXCD - 1) / SDF_NXCD) * 2) * SDF_NVOX; }
+__host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)(((H / 2 + SDF_NXCD - 1) / SDF_NXCD) * 2) * (SDF_NVOX + SDF_ITEM); }
 
 __host__ __device__ inline size_t sdf_ws_bytes(int H) {
     size_t n = 0;
@@ -387,9 +388,13 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     cur[tid] = __popc(inside);
     const int blk_total = block_excl_scan_1024(cur, scratch);
     const int xcd = H % SDF_NXCD;
-    if (tid == 0) { blk_inside = blk_total; blk_base = blk_total > 0 ? atomicAdd(&ws.inside_count[xcd], blk_total) : 0; }
+    // the hand's inside voxels occupy a 32-aligned run of the XCD's list (tail padded with an invalid marker),
+    // so every 32-entry work item of the distance kernel belongs to exactly one hand
+    const int blk_padded = (blk_total + SDF_ITEM - 1) & ~(SDF_ITEM - 1);
+    if (tid == 0) { blk_inside = blk_total; blk_base = blk_total > 0 ? atomicAdd(&ws.inside_count[xcd], blk_padded) : 0; }
     __syncthreads();
     TSTAMP(28);
+    if (tid < blk_padded - blk_total) ws.inside_list[(size_t)xcd * ws.xcd_cap + blk_base + blk_total + tid] = 0xffffffffu;
     {
         unsigned* glist = ws.inside_list + (size_t)xcd * ws.xcd_cap + blk_base + cur[tid];
         unsigned rem = inside;
@@ -464,105 +469,86 @@ __device__ __forceinline__ float sdf_point_tri_dist2(const float* a, const float
 
 // ------------------------------------------------------------------------------------- distance
 // grid = 8 * SDF_DIST_BLOCKS_PER_XCD, block = 256 (4 waves); workgroup L serves the list of XCD (L % 8), i.e.
-// of the hands whose tables that XCD's L2 already holds.  Every wave takes a contiguous slice of the list;
-// per voxel: exact min distance over the mesh as a wave-level min-reduction (lanes across triangles).  The
-// 1538 bounding spheres of the current hand live in registers (25 per lane) and are reloaded only when the
-// slice crosses into another hand; survivors of the sphere cull are compacted through a per-wave LDS list so
-// the expensive closest-point evaluation runs on dense lanes.
+// of the hands whose tables that XCD's L2 already holds.  A work item = 32 consecutive list entries = inside
+// voxels of ONE hand: the workgroup stages that hand's 1538 bounding spheres in LDS (25 KB), then each wave
+// takes 8 voxels.  Per voxel: wave-level min-reduction over the mesh (lanes across triangles) -- sphere pass
+// for the upper bound, cull, scan-compacted survivors, exact closest-point distance on dense lanes, DPP min.
+// Keeping the table in LDS instead of registers leaves ~70 VGPRs, i.e. 5 workgroups per CU to hide latency.
 __global__ __launch_bounds__(SDF_THREADS) void sdf_dist_kernel(SdfWorkspace ws, int collect_stats) {
+    __shared__ float4 sph_s[NFP];
     __shared__ unsigned short surv[SDF_THREADS / WAVE][NFP];
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
     const int xcd = blockIdx.x % SDF_NXCD, slot = blockIdx.x / SDF_NXCD, nslot = gridDim.x / SDF_NXCD;
     const int total = ws.inside_count[xcd];
     const unsigned* glist = ws.inside_list + (size_t)xcd * ws.xcd_cap;
-    const int nwaves = nslot * (SDF_THREADS / WAVE), gw = slot * (SDF_THREADS / WAVE) + wave;
-    const int per = (total + nwaves - 1) / nwaves;
-    const int q0 = gw * per, q1 = min(total, q0 + per);
-    TSTAMP(40);
     unsigned short* mylist = surv[wave];
-    float4 sp[NFP / WAVE];
     int curH = -1;
-    const float4* abc = nullptr;
     unsigned long long st_dist = 0;
-#ifdef IHMR_TIMING
-    long long ph[6] = {0, 0, 0, 0, 0, 0};
-#define PH(i) do { const long long now_ = clock64(); ph[i] += now_ - last_; last_ = now_; } while (0)
-    long long last_ = clock64();
-#else
-#define PH(i) do { } while (0)
-#endif
-    unsigned ent_l = 0;
-    for (int q = q0; q < q1; ++q) {
-        if (((q - q0) & (WAVE - 1)) == 0) ent_l = (q + lane < q1) ? glist[q + lane] : 0u;  // 64 entries per fetch
-        const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ent_l, (q - q0) & (WAVE - 1));
-        const int H = (int)(ent >> 16), id = (int)(ent & 0xffffu);
-        if (H != curH) {
-            curH = H;
-            abc = ws.abc + (size_t)H * NFP * 3;
+    TSTAMP(40);
+    for (int item = slot; item * SDF_ITEM < total; item += nslot) {
+        const unsigned ent_l = lane < SDF_ITEM ? glist[item * SDF_ITEM + lane] : 0xffffffffu;
+        const int H = (int)((unsigned)__builtin_amdgcn_readlane((int)ent_l, 0) >> 16);   // entry 0 of an item is always valid
+        if (H != curH) {             // uniform over the workgroup (same item for all waves)
+            __syncthreads();
             const float4* sph = ws.sph + (size_t)H * NFP;
+            for (int f = tid; f < NFP; f += SDF_THREADS) sph_s[f] = sph[f];
+            __syncthreads();
+            curH = H;
+        }
+        const float4* abc = ws.abc + (size_t)H * NFP * 3;
+        for (int e = wave * (SDF_ITEM / 4); e < (wave + 1) * (SDF_ITEM / 4); ++e) {
+            const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ent_l, e);
+            if (ent == 0xffffffffu) break;     // padding (only at the tail of a hand's run)
+            const int id = (int)(ent & 0xffffu);
+            const int col = id >> 5, i = id & 31, k = col >> 5, j = col & 31;
+            const float px = (float)(2 * i + 1) / (float)SDF_G - 1.0f;
+            const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
+            const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
+            float d2[NFP / WAVE];
+            float ub2 = INFINITY;
 #pragma unroll
-            for (int t = 0; t < NFP / WAVE; ++t) sp[t] = sph[lane + WAVE * t];
-        }
-        PH(0);
-        const int col = id >> 5, i = id & 31, k = col >> 5, j = col & 31;
-        const float px = (float)(2 * i + 1) / (float)SDF_G - 1.0f;
-        const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
-        const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
-        float d2[NFP / WAVE];
-        float ub2 = INFINITY;
+            for (int t = 0; t < NFP / WAVE; ++t) {
+                const float4 sp = sph_s[lane + WAVE * t];
+                const float dx = px - sp.x, dy = py - sp.y, dz = pz - sp.z;
+                d2[t] = dx * dx + dy * dy + dz * dz;
+                if (sp.w >= 0.0f) ub2 = fminf(ub2, d2[t]);
+            }
+            ub2 = wave_reduce_min(ub2);  // the centroid is a point of the triangle: dist <= |p - centroid|
+            const float ub_lim = sqrtf(ub2) * 1.0001f + 1e-6f;
+            unsigned keepmask = 0;
 #pragma unroll
-        for (int t = 0; t < NFP / WAVE; ++t) {
-            const float dx = px - sp[t].x, dy = py - sp[t].y, dz = pz - sp[t].z;
-            d2[t] = dx * dx + dy * dy + dz * dz;
-            if (sp[t].w >= 0.0f) ub2 = fminf(ub2, d2[t]);
+            for (int t = 0; t < NFP / WAVE; ++t) {
+                const float r = sph_s[lane + WAVE * t].w;
+                const float lim = ub_lim + r;
+                // cull iff |p - centroid| - radius > upper bound (exact: such a triangle cannot be the minimum)
+                const bool keep = (r >= 0.0f) && !(d2[t] > lim * lim * 1.00001f);
+                keepmask |= keep ? (1u << t) : 0u;
+            }
+            int cnt;
+            const int mine = __popc(keepmask);
+            int off = wave_incl_scan(mine, cnt) - mine;
+            while (keepmask) {
+                const int t = __ffs((int)keepmask) - 1;
+                keepmask &= keepmask - 1;
+                mylist[off++] = (unsigned short)(lane + WAVE * t);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            float best = INFINITY;
+            for (int sidx = lane; sidx < cnt; sidx += WAVE) {
+                const int f = mylist[sidx];
+                const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
+                const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
+                best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
+                st_dist += 1;
+            }
+            best = wave_reduce_min(best);
+            if (lane == 0) ws.phi[(size_t)H * SDF_NVOX + id] = sqrtf(best);
+            __builtin_amdgcn_wave_barrier();
         }
-        ub2 = wave_reduce_min(ub2);  // the centroid is a point of the triangle: dist <= |p - centroid|
-        const float ub_lim = sqrtf(ub2) * 1.0001f + 1e-6f;
-        PH(1);
-        unsigned keepmask = 0;
-#pragma unroll
-        for (int t = 0; t < NFP / WAVE; ++t) {
-            const float lim = ub_lim + sp[t].w;
-            // cull iff |p - centroid| - radius > upper bound (exact: such a triangle cannot be the minimum)
-            const bool keep = (sp[t].w >= 0.0f) && !(d2[t] > lim * lim * 1.00001f);
-            keepmask |= keep ? (1u << t) : 0u;
-        }
-        int cnt;
-        const int mine = __popc(keepmask);
-        int off = wave_incl_scan(mine, cnt) - mine;
-        while (keepmask) {
-            const int t = __ffs((int)keepmask) - 1;
-            keepmask &= keepmask - 1;
-            mylist[off++] = (unsigned short)(lane + WAVE * t);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        PH(2);
-        float best = INFINITY;
-        for (int sidx = lane; sidx < cnt; sidx += WAVE) {
-            const int f = mylist[sidx];
-            const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
-            const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
-            best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
-            st_dist += 1;
-        }
-        PH(3);
-        best = wave_reduce_min(best);
-        if (lane == 0) ws.phi[(size_t)H * SDF_NVOX + id] = sqrtf(best);
-        __builtin_amdgcn_wave_barrier();
-        PH(4);
-#ifdef IHMR_TIMING
-        ph[5] += cnt;
-#endif
     }
     TSTAMP(41);
-#ifdef IHMR_TIMING
-    if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) g_dbg[70 + i_] = ph[i_];
-#endif
-#ifdef IHMR_TIMING
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[42] = q1 - q0;
-#endif
     if (collect_stats) {
         unsigned long long d = st_dist;
 #pragma unroll

@@ -28,5 +28,5 @@ for stage_id in (2, 3):
     seg("bwd1 [gsum | load | dvp | dA | chain | tail]", [10,11,12,13,14,15,16])
     seg("prep [bbox | norm+mark | table+count | scan | fill | column-loop | sync | publish | stats]", [20,21,22,23,24,25,27,28,29,26]); dd=np.array(out[:200],dtype=np.int64); print("   per-wave loop us", [round(float(x)/2400,1) for x in dd[100:116]], "\n   iters", dd[120:136].tolist(), "\n   rounds", dd[140:156].tolist(), "\n   lane0 voxel-iters", dd[160:176].tolist())
     seg("parity [loop | publish]", [30,31,32])
-    seg("dist [loop]", [40,41]); print("   dist voxels in wave0:", d[42], " per-phase us [fetch | d2+ub | cull+compact | exact eval | reduce+store]:", [round(float(x)/2400,2) for x in np.array(out[70:75])], "survivors", out[75])
+    seg("dist [loop]", [40,41]); pass
     seg("sample [loop | reduce]", [50,51,52])
