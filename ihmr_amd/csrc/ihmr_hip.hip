@@ -217,7 +217,7 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
         HIP_TRY(hipEventCreate(&tp.b));
         HIP_TRY(hipEventRecord(tp.a, st));
     }
-    hipLaunchKernelGGL(sdf_dist_kernel, dim3(SDF_NXCD * SDF_DIST_BLOCKS_PER_XCD), dim3(SDF_THREADS), 0, st, ws, g_collect_stats);
+    hipLaunchKernelGGL(sdf_dist_kernel, dim3(SDF_DIST_BLOCKS), dim3(SDF_THREADS), 0, st, ws, g_collect_stats);
     if (timed) {
         HIP_TRY(hipEventRecord(tp.b, st));
         tp.flops = 0.0;

@@ -24,8 +24,11 @@
 #define SDF_BIN_CAP 32768          // (triangle, column) pairs per hand before falling back to a full scan
 #define SDF_EVAL_CHUNKS 8          // workgroups per hand in the parity kernel
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
-#define SDF_DIST_BLOCKS_PER_XCD 256
-#define SDF_ITEM 16                // inside voxels per work item of the distance kernel (one hand per item)
+#ifndef SDF_DIST_BLOCKS
+#define SDF_DIST_BLOCKS 1024          // 4 workgroups (30 KB LDS, <= 128 VGPRs) per CU: a typical launch's work items are all resident at once
+#endif
+#define SDF_SURV_CAP 512             // LDS slots per wave for the triangles surviving the sphere cull (typically ~40)
+#define SDF_ITEM 16                // inside voxels per work item of the distance kernel (one hand per item); power of two
 
 // Per-hand, per-iteration triangle tables (float4 records, so a random triangle costs one or three
 // 16 B loads instead of a cache line per SoA row):
@@ -49,7 +52,7 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     int xcd_cap;
 };
 
-__host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)(((H / 2 + SDF_NXCD - 1) / SDF_NXCD) * 2) * (SDF_NVOX + SDF_ITEM); }
+__host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)H * (SDF_NVOX + SDF_ITEM); }   // one batch-wide list
 
 __host__ __device__ inline size_t sdf_ws_bytes(int H) {
     size_t n = 0;
@@ -59,7 +62,7 @@ __host__ __device__ inline size_t sdf_ws_bytes(int H) {
     n += (size_t)H * SDF_NCOL * sizeof(unsigned);
     n += (size_t)H * 1028 * sizeof(int);
     n += (size_t)H * 4 * sizeof(int);
-    n += (size_t)SDF_NXCD * sdf_xcd_cap(H) * sizeof(unsigned);
+    n += sdf_xcd_cap(H) * sizeof(unsigned);
     n += (size_t)H * SDF_BIN_CAP * sizeof(unsigned short);
     n += (size_t)H * SDF_NVOX * sizeof(unsigned short);
     n += 128 + 256;
@@ -80,7 +83,7 @@ static inline SdfWorkspace sdf_carve(void* ws, int H) {
     w.stats = (unsigned long long*)p; p += 64;
     w.inside_count = (int*)p; p += 64;
     w.xcd_cap = (int)sdf_xcd_cap(H);
-    w.inside_list = (unsigned*)p; p += (size_t)SDF_NXCD * sdf_xcd_cap(H) * sizeof(unsigned);
+    w.inside_list = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
     w.col_tris = (unsigned short*)p; p += (size_t)H * SDF_BIN_CAP * sizeof(unsigned short);
     w.vox_list = (unsigned short*)p;
     return w;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     __syncthreads();
     cur[tid] = __popc(inside);
     const int blk_total = block_excl_scan_1024(cur, scratch);
-    const int xcd = H % SDF_NXCD;
+    const int xcd = 0;   // one batch-wide list: balanced work items matter more here than L2 affinity
     // the hand's inside voxels occupy a 32-aligned run of the XCD's list (tail padded with an invalid marker),
     // so every 32-entry work item of the distance kernel belongs to exactly one hand
     const int blk_padded = (blk_total + SDF_ITEM - 1) & ~(SDF_ITEM - 1);
@@ -468,19 +471,19 @@ __device__ __forceinline__ float sdf_point_tri_dist2(const float* a, const float
 }
 
 // ------------------------------------------------------------------------------------- distance
-// grid = 8 * SDF_DIST_BLOCKS_PER_XCD, block = 256 (4 waves); workgroup L serves the list of XCD (L % 8), i.e.
-// of the hands whose tables that XCD's L2 already holds.  A work item = 32 consecutive list entries = inside
+// grid = SDF_DIST_BLOCKS, block = 256 (4 waves).  The inside voxels of the whole batch sit in one list (balanced
+// work matters more here than L2 affinity: the per-sample counts vary by 3x).  A work item = 32 consecutive list entries = inside
 // voxels of ONE hand: the workgroup stages that hand's 1538 bounding spheres in LDS (25 KB), then each wave
 // takes 8 voxels.  Per voxel: wave-level min-reduction over the mesh (lanes across triangles) -- sphere pass
 // for the upper bound, cull, scan-compacted survivors, exact closest-point distance on dense lanes, DPP min.
 // Keeping the table in LDS instead of registers leaves ~70 VGPRs, i.e. 5 workgroups per CU to hide latency.
-__global__ __launch_bounds__(SDF_THREADS) void sdf_dist_kernel(SdfWorkspace ws, int collect_stats) {
+__global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace ws, int collect_stats) {
     __shared__ float4 sph_s[NFP];
-    __shared__ unsigned short surv[SDF_THREADS / WAVE][NFP];
+    __shared__ unsigned short surv[SDF_THREADS / WAVE][SDF_SURV_CAP];
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
-    const int xcd = blockIdx.x % SDF_NXCD, slot = blockIdx.x / SDF_NXCD, nslot = gridDim.x / SDF_NXCD;
-    const int total = ws.inside_count[xcd];
-    const unsigned* glist = ws.inside_list + (size_t)xcd * ws.xcd_cap;
+    const int slot = blockIdx.x, nslot = gridDim.x;
+    const int total = ws.inside_count[0];
+    const unsigned* glist = ws.inside_list;
     unsigned short* mylist = surv[wave];
     int curH = -1;
     unsigned long long st_dist = 0;
@@ -527,21 +530,33 @@ __global__ __launch_bounds__(SDF_THREADS) void sdf_dist_kernel(SdfWorkspace ws, 
             int cnt;
             const int mine = __popc(keepmask);
             int off = wave_incl_scan(mine, cnt) - mine;
-            while (keepmask) {
-                const int t = __ffs((int)keepmask) - 1;
-                keepmask &= keepmask - 1;
-                mylist[off++] = (unsigned short)(lane + WAVE * t);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             float best = INFINITY;
-            for (int sidx = lane; sidx < cnt; sidx += WAVE) {
-                const int f = mylist[sidx];
-                const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
-                const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
-                best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
-                st_dist += 1;
+            if (cnt <= SDF_SURV_CAP) {
+                while (keepmask) {
+                    const int t = __ffs((int)keepmask) - 1;
+                    keepmask &= keepmask - 1;
+                    mylist[off++] = (unsigned short)(lane + WAVE * t);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (int sidx = lane; sidx < cnt; sidx += WAVE) {
+                    const int f = mylist[sidx];
+                    const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
+                    const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
+                    best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
+                    st_dist += 1;
+                }
+            } else {   // (degenerate geometry) more survivors than list slots: every lane walks its own triangles
+                while (keepmask) {
+                    const int t = __ffs((int)keepmask) - 1;
+                    keepmask &= keepmask - 1;
+                    const int f = lane + WAVE * t;
+                    const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
+                    const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
+                    best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
+                    st_dist += 1;
+                }
             }
             best = wave_reduce_min(best);
             if (lane == 0) ws.phi[(size_t)H * SDF_NVOX + id] = sqrtf(best);
