@@ -138,23 +138,38 @@ __device__ __forceinline__ void tri_col_range(float y0, float y1, float y2, floa
 
 // ------------------------------------------------------------------------------------- prep + parity
 // grid = 2B (block id = hand id H = hnd*B + b, so both hands of sample b sit on XCD b % 8 when B % 8 == 0),
-// block = 1024 (one CU's worth of LDS: ~120 KB).  Everything up to the inside/outside decision of a hand
-// happens here, out of LDS, with no dependent trips to memory:
-//   box -> normalised vertices -> needed-voxel mask (one 32-bit word per (k,j) column) ->
-//   triangle records (sphere + abc to HBM for the distance kernel, ray-test records to LDS) ->
-//   triangles binned per needed column (conservative yz box) -> thread = column: the (u,v) test once per
-//   (column, triangle), t > 0 per needed voxel -> phi = 0 for outside voxels, inside voxels appended to the
-//   list of this hand's XCD.
-#define SDF_LCAP 12288   // LDS capacity of the per-column triangle lists; beyond: global list; beyond SDF_BIN_CAP: full scan
+// block = 1024.  Everything up to the inside/outside decision of a hand happens here, out of LDS:
+//   box -> normalised vertices -> needed-voxel mask (one 32-bit word per (k,j) column)
+//   -> lane = triangle: sphere + abc records to HBM for the distance kernel; for every needed column whose
+//      centre lies in the triangle's yz bounding box the (u,v) ray test, and for a hit the t > 0 test of the
+//      column's needed voxels, XOR-ed into the column's parity word (LDS atomic; XOR is order-free)
+//   -> phi = 0 for outside voxels, inside voxels appended to the batch-wide list.
+// Triangle-parallel on purpose: no per-column triangle lists, no dependent LDS chains, balanced lanes.
+// t > 0 test of the needed voxels of one column against one triangle (already known to pass the (u,v) test);
+// returns the hit mask.  Same operation order as oracle/sdf_grid.c ray_hit_px.
+__device__ __forceinline__ unsigned sdf_ray_hits(unsigned need, float ax, float e1x, float e1y, float e1z, float e2x, float e2y,
+                                                 float e2z, float inv, float sy, float sz, float qx) {
+    unsigned hits = 0, rem = need;
+    while (rem) {
+        const int i = __ffs((int)rem) - 1;
+        rem &= rem - 1;
+        const float px = (float)(2 * i + 1) / (float)SDF_G - 1.0f;
+        const float sx = px - ax;
+        const float qy = __builtin_fmaf(sz, e1x, -(sx * e1z));
+        const float qz = __builtin_fmaf(sx, e1y, -(sy * e1x));
+        const float tt = DOT3(e2x, e2y, e2z, qx, qy, qz) * inv;
+        if (tt > 0.0f) hits |= 1u << i;
+    }
+    return hits;
+}
+
 template <bool DENSE>
 __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout vl, int B, const int32_t* __restrict__ faces_r,
                                                                     const int32_t* __restrict__ faces_l, SdfWorkspace ws,
                                                                     int collect_stats) {
     __shared__ float vn[NV3];
-    __shared__ float4 lpar[NF][3];
-    __shared__ unsigned short ltri[SDF_LCAP];
     __shared__ unsigned needed[SDF_NCOL];
-    __shared__ int cnt[SDF_NCOL];
+    __shared__ unsigned parity[SDF_NCOL];
     __shared__ int cur[SDF_NCOL];
     __shared__ float red[6][SDF_PREP_THREADS / WAVE];
     __shared__ float box[4];
@@ -178,14 +193,20 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             mx[k] = x;
         }
     }
+    // face indices of this lane's (up to two) triangles: issued early, consumed after the box is known
+    int fidx[2][3];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int f = min(tid + it * SDF_PREP_THREADS, NFP - 1);
+        fidx[it][0] = faces[f]; fidx[it][1] = faces[NFP + f]; fidx[it][2] = faces[2 * NFP + f];
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float a = wave_reduce_min(mn[k]), c = wave_reduce_max(mx[k]);
         if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = c; }
     }
     needed[tid] = DENSE ? 0xffffffffu : 0u;
-    cnt[tid] = 0;
-    if (tid == 0) blk_inside = 0;
+    parity[tid] = 0u;
     __syncthreads();
     if (tid == 0) {
         float lo[3], hi[3];
@@ -231,30 +252,25 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     }
     __syncthreads();
     TSTAMP(22);
-    // ---- per-iteration triangle records + column binning, pass 1 (count)
+    // ---- lane = triangle: records for the distance kernel + ray parity of the needed voxels it can hit
     float4* sph = ws.sph + (size_t)H * NFP;
     float4* abc = ws.abc + (size_t)H * NFP * 3;
-    bool ok[2] = {false, false};
-    int jr[2][4];
+    unsigned long long st_tests = 0;
+#pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int f = tid + it * SDF_PREP_THREADS;
         if (f >= NFP) break;
-        const int fa = faces[f], fb = faces[NFP + f], fc = faces[2 * NFP + f];
+        const int fa = fidx[it][0], fb = fidx[it][1], fc = fidx[it][2];
         const float a[3] = {vn[3 * fa], vn[3 * fa + 1], vn[3 * fa + 2]};
         const float bb[3] = {vn[3 * fb], vn[3 * fb + 1], vn[3 * fb + 2]};
         const float c[3] = {vn[3 * fc], vn[3 * fc + 1], vn[3 * fc + 2]};
         const float e1x = bb[0] - a[0], e1y = bb[1] - a[1], e1z = bb[2] - a[2];
         const float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
         const float det = __builtin_fmaf(e1z, e2y, -(e1y * e2z));
-        ok[it] = f < NF && fabsf(det) >= 1e-12f;
+        const bool ok = f < NF && fabsf(det) >= 1e-12f;
         abc[3 * f] = make_float4(a[0], a[1], a[2], 0.f);
         abc[3 * f + 1] = make_float4(bb[0], bb[1], bb[2], 0.f);
         abc[3 * f + 2] = make_float4(c[0], c[1], c[2], 0.f);
-        if (f < NF) {
-            lpar[f][0] = make_float4(a[1], a[2], e1y, e1z);
-            lpar[f][1] = make_float4(e2y, e2z, ok[it] ? 1.0f / det : __builtin_nanf(""), a[0]);  // NaN => never a hit
-            lpar[f][2] = make_float4(e1x, e2x, 0.f, 0.f);
-        }
         // bounding sphere about the centroid (conservative radius)
         const float gx = (a[0] + bb[0] + c[0]) * (1.0f / 3.0f), gy = (a[1] + bb[1] + c[1]) * (1.0f / 3.0f),
                     gz = (a[2] + bb[2] + c[2]) * (1.0f / 3.0f);
@@ -265,134 +281,56 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             dx = c[0] - gx; dy = c[1] - gy; dz = c[2] - gz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
         }
         sph[f] = make_float4(gx, gy, gz, f < NF ? sqrtf(r2) * 1.0001f + 1e-6f : -1.0f);  // radius < 0 marks padding
-        if (ok[it]) {
-            tri_col_range(a[1], bb[1], c[1], a[2], bb[2], c[2], jr[it][0], jr[it][1], jr[it][2], jr[it][3]);
-            for (int k = jr[it][2]; k <= jr[it][3]; ++k)
-                for (int j = jr[it][0]; j <= jr[it][1]; ++j)
-                    if (needed[k * SDF_G + j]) atomicAdd(&cnt[k * SDF_G + j], 1);
-        }
-    }
-    TSTAMP(23);
-    const int total_pairs = block_excl_scan_1024(cnt, scratch);
-    TSTAMP(24);
-    cur[tid] = 0;
-    __syncthreads();
-    // ---- binning pass 2 (fill); list order inside a column is irrelevant (parity is an XOR)
-    const bool full_scan = total_pairs > SDF_BIN_CAP;
-    const bool in_lds = total_pairs <= SDF_LCAP;
-    unsigned short* glst = ws.col_tris + (size_t)H * SDF_BIN_CAP;
-    if (!full_scan) {
-        for (int it = 0; it < 2; ++it) {
-            if (!ok[it]) continue;
-            const int f = tid + it * SDF_PREP_THREADS;
-            for (int k = jr[it][2]; k <= jr[it][3]; ++k)
-                for (int j = jr[it][0]; j <= jr[it][1]; ++j) {
-                    const int col = k * SDF_G + j;
-                    if (needed[col]) {
-                        const int pos = cnt[col] + atomicAdd(&cur[col], 1);
-                        if (in_lds) ltri[pos] = (unsigned short)f;
-                        else glst[pos] = (unsigned short)f;
-                    }
-                }
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-    TSTAMP(25);
-    // ---- 16-lane row = column (k,j): four columns in flight per wave.  Lanes first run across the column's
-    //      triangle list for the (u,v) test (once per column and triangle); then roles flip: lane r of the row
-    //      owns voxels i = r and i = r + 16 of the column and walks the few surviving candidates (their record
-    //      re-read from LDS as a row-wide broadcast), toggling its own parity -- so the t > 0 work runs on
-    //      voxel-dense lanes and no cross-lane reduction is needed.
-    unsigned long long st_tests = 0;
-    float* phi = ws.phi + (size_t)H * SDF_NVOX;
-    const int row = tid >> 4, rlane = tid & 15, rshift = lane & 48;   // 64 rows of 16 lanes
-    const float pxA = (float)(2 * rlane + 1) / (float)SDF_G - 1.0f;
-    const float pxB = (float)(2 * (rlane + 16) + 1) / (float)SDF_G - 1.0f;
 #ifdef IHMR_TIMING
-    long long c0_ = clock64(); int n_it_ = 0, n_rd_ = 0, n_vx_ = 0;
+        if (blockIdx.x == 0 && lane == 0) g_dbg[120 + wave + 16 * it] = clock64() - g_dbg[22];
 #endif
-    for (int cidx = row; cidx < SDF_NCOL; cidx += SDF_PREP_THREADS / 16) {
-        const int col = (cidx * 37) & (SDF_NCOL - 1);   // bijective scatter: the read columns cluster, spread them over the waves
-        const unsigned need = needed[col];
-        if (!__any(need != 0u)) {              // none of the wave's four columns is read: skip
-            if (rlane == 0) cur[col] = 0;
-            continue;
-        }
-        const int k = col >> 5, j = col & 31;
-        const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
-        const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
-        const int t0 = full_scan ? 0 : cnt[col], len = !need ? 0 : (full_scan ? NF : cur[col]);
-        const bool hasA = (need >> rlane) & 1u, hasB = (need >> (rlane + 16)) & 1u;
-        bool parA = false, parB = false;
+        if (!ok) continue;                                   // degenerate in yz: the +x ray never counts it
+        const float inv = 1.0f / det;
+        int j0, j1, k0, k1;
+        tri_col_range(a[1], bb[1], c[1], a[2], bb[2], c[2], j0, j1, k0, k1);
 #ifdef IHMR_TIMING
-        n_it_++;
+        { int ncol_ = (k1 - k0 + 1) * (j1 - j0 + 1); for (int o = 32; o > 0; o >>= 1) ncol_ = max(ncol_, __shfl_xor(ncol_, o)); if (blockIdx.x == 0 && lane == 0) g_dbg[160 + wave + 16 * it] = ncol_; }
 #endif
-        for (int base = 0; __any(base < len); base += 16) {
-#ifdef IHMR_TIMING
-            n_rd_++;
-#endif
-            const int t = base + rlane;
-            const bool valid = t < len;
-            const int f = !valid ? 0 : (full_scan ? t : (in_lds ? (int)ltri[t0 + t] : (int)glst[t0 + t]));
-            bool cand;
-            {
-                const float4 r0 = lpar[f][0], r1 = lpar[f][1];
-                const float sy = py - r0.x, sz = pz - r0.y;
-                const float uu = __builtin_fmaf(sz, r1.x, -(sy * r1.y)) * r1.z;
-                const float qx = __builtin_fmaf(sy, r0.w, -(sz * r0.z));
-                const float vv = qx * r1.z;
-                cand = valid && (uu >= 0.0f) && (uu <= 1.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f);
-            }
-            st_tests += valid ? 1 : 0;
-            unsigned cm = (unsigned)(__ballot(cand) >> rshift) & 0xffffu;   // candidates of my row (uniform in the row)
-            while (__any(cm != 0u)) {
-                const int c = cm ? __ffs((int)cm) - 1 : 0;
-                const int fc = __shfl(f, rshift + c);                     // triangle of the row's next candidate
-                if (cm) {
-                    cm &= cm - 1;
-                    const float4 r0 = lpar[fc][0], r1 = lpar[fc][1], r2 = lpar[fc][2];
-                    const float ay = r0.x, az = r0.y, e1y = r0.z, e1z = r0.w, e2y = r1.x, e2z = r1.y, inv = r1.z, ax = r1.w;
-                    const float e1x = r2.x, e2x = r2.y;
-                    const float sy = py - ay, sz = pz - az;
-                    const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y));
-                    {
-                        const float sx = pxA - ax;
-                        const float qy = __builtin_fmaf(sz, e1x, -(sx * e1z));
-                        const float qz = __builtin_fmaf(sx, e1y, -(sy * e1x));
-                        const float tt = DOT3(e2x, e2y, e2z, qx, qy, qz) * inv;
-                        parA ^= hasA && (tt > 0.0f);
-                    }
-                    {
-                        const float sx = pxB - ax;
-                        const float qy = __builtin_fmaf(sz, e1x, -(sx * e1z));
-                        const float qz = __builtin_fmaf(sx, e1y, -(sy * e1x));
-                        const float tt = DOT3(e2x, e2y, e2z, qx, qy, qz) * inv;
-                        parB ^= hasB && (tt > 0.0f);
-                    }
-                    st_tests += (hasA ? 1 : 0) + (hasB ? 1 : 0);
-                }
+        for (int k = k0; k <= k1; ++k) {
+            const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
+            for (int j = j0; j <= j1; ++j) {
+                const unsigned need = needed[k * SDF_G + j];
+                if (!need) continue;
+                const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
+                const float sy = py - a[1], sz = pz - a[2];
+                const float uu = __builtin_fmaf(sz, e2y, -(sy * e2z)) * inv;
+                const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y));
+                const float vv = qx * inv;
+                st_tests += 1;
+                if (!((uu >= 0.0f) && (uu <= 1.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f))) continue;
+                const unsigned hits = sdf_ray_hits(need, a[0], e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx);
+                st_tests += __popc(need);
+                if (hits) atomicXor(&parity[k * SDF_G + j], hits);
             }
         }
-        const unsigned inside = ((unsigned)(__ballot(parA) >> rshift) & 0xffffu) | (((unsigned)(__ballot(parB) >> rshift) & 0xffffu) << 16);
-        if (hasA && !parA) phi[col * SDF_G + rlane] = 0.0f;          // outside voxels
-        if (hasB && !parB) phi[col * SDF_G + rlane + 16] = 0.0f;
-        if (rlane == 0) cur[col] = (int)inside;
     }
 #ifdef IHMR_TIMING
-    if (blockIdx.x == 0 && lane == 0) { g_dbg[100 + wave] = clock64() - c0_; g_dbg[120 + wave] = n_it_; g_dbg[140 + wave] = n_rd_; g_dbg[160 + wave] = n_vx_; }
+    { const long long tnow = clock64(); if (blockIdx.x == 0 && lane == 0) g_dbg[100 + wave] = tnow - g_dbg[22]; }
 #endif
     __syncthreads();
     TSTAMP(27);
-    // ---- publish the inside voxels into this XCD's list (one global atomic per workgroup); thread = column
-    const unsigned inside = (unsigned)cur[tid];
-    const unsigned need_mine = needed[tid];
-    __syncthreads();
+    // ---- publish: thread = column; phi = 0 for the outside voxels, inside voxels into the batch-wide list
+    float* phi = ws.phi + (size_t)H * SDF_NVOX;
+    const unsigned need = needed[tid];
+    const unsigned inside = parity[tid] & need;
+    {
+        unsigned rem = need & ~inside;
+        while (rem) {
+            const int i = __ffs((int)rem) - 1;
+            rem &= rem - 1;
+            phi[tid * SDF_G + i] = 0.0f;
+        }
+    }
     cur[tid] = __popc(inside);
     const int blk_total = block_excl_scan_1024(cur, scratch);
     const int xcd = 0;   // one batch-wide list: balanced work items matter more here than L2 affinity
-    // the hand's inside voxels occupy a 32-aligned run of the XCD's list (tail padded with an invalid marker),
-    // so every 32-entry work item of the distance kernel belongs to exactly one hand
+    // the hand's inside voxels occupy a 16-aligned run of the list (tail padded with an invalid marker),
+    // so every work item of the distance kernel belongs to exactly one hand
     const int blk_padded = (blk_total + SDF_ITEM - 1) & ~(SDF_ITEM - 1);
     if (tid == 0) { blk_inside = blk_total; blk_base = blk_total > 0 ? atomicAdd(&ws.inside_count[xcd], blk_padded) : 0; }
     __syncthreads();
@@ -408,7 +346,6 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             glist[o++] = ((unsigned)H << 16) | (unsigned)(tid * SDF_G + i);
         }
     }
-    const unsigned need = need_mine;
     TSTAMP(29);
     if (collect_stats) {
         unsigned long long c = st_tests;

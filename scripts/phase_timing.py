@@ -26,7 +26,7 @@ for stage_id in (2, 3):
         print(f"stage{stage_id} {name}: " + "  ".join(f"{(d[b]-d[a])/2400:.1f}us" for a, b in zip(ids[:-1], ids[1:])) + f"   total {(d[ids[-1]]-d[ids[0]])/2400:.1f}us")
     seg("skin [load-skel | shape | pose | weights+skin+store]", [0,1,2,3,4])
     seg("bwd1 [gsum | load | dvp | dA | chain | tail]", [10,11,12,13,14,15,16])
-    seg("prep [bbox | norm+mark | table+count | scan | fill | column-loop | sync | publish | stats]", [20,21,22,23,24,25,27,28,29,26]); dd=np.array(out[:200],dtype=np.int64); print("   per-wave loop us", [round(float(x)/2400,1) for x in dd[100:116]], "\n   iters", dd[120:136].tolist(), "\n   rounds", dd[140:156].tolist(), "\n   lane0 voxel-iters", dd[160:176].tolist())
+    seg("prep [bbox | norm+mark | triangles+parity | publish-scan | publish | stats]", [20,21,22,27,28,29,26]); dd=np.array(out[:200],dtype=np.int64); print("   per-wave triangle-phase us", [round(float(x)/2400,1) for x in dd[100:116]]); print("   after-table us it0", [round(float(x)/2400,1) for x in dd[120:136]], "it1", [round(float(x)/2400,1) for x in dd[136:152]]); print("   max cols it0", dd[160:176].tolist(), "it1", dd[176:192].tolist())
     seg("parity [loop | publish]", [30,31,32])
     seg("dist [loop]", [40,41]); dd=np.array(out[:100],dtype=np.int64); print("   dist max over waves: total %.1fus load %.1fus vox %.1fus items %d vox %d; per-XCD totals %s" % (dd[80]/2400, dd[81]/2400, dd[82]/2400, dd[83], dd[84], dd[90:98].tolist()))
     seg("sample [loop | reduce]", [50,51,52])
