@@ -70,6 +70,21 @@ def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=16, iters_per_stage=4):
                 ms_per_refine_iter=1000.0 * t_iter)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the newest committed rocprofv3 PMC summary (``profiles/*_pmc_traffic.csv``,
+    produced by ``scripts/profile_round.sh`` = two separate ``--pmc`` passes of this very command, FETCH_SIZE doubled
+    per the gfx950 correction).  Counters cannot be read from inside the process, so this is the profile's figure."""
+    import csv, glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.csv")))
+    if not files:
+        return None, None
+    with open(files[-1], newline="") as fh:
+        for r in csv.DictReader(fh):
+            if r["kernel"].startswith(kernel):
+                return float(r["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(files[-1])
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,11 +199,13 @@ def main():
         # 75 flops per exact point-triangle distance that survives the cull
         stats["flops_per_launch"] = 1538 * 11.0 * stats["inside_voxels"] + 75.0 * stats["dist_evals"]
         avg_ms = timer.ms_sdf_eval / max(timer.n_sdf_eval, 1)
+        traffic, traffic_src = pmc_traffic("sdf_dist_kernel") if (B == 64 and args.epoch == 49) else (None, None)
         if avg_ms > 0:
             flops = stats["flops_per_launch"]
             ach = flops / (avg_ms * 1e-3) / 1e12
             roofline = dict(bound="mfma", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS,
-                            traffic=None, kernel="sdf_dist_kernel", avg_launch_ms=avg_ms, launches=int(timer.n_sdf_eval),
+                            traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
+                            kernel="sdf_dist_kernel", avg_launch_ms=avg_ms, launches=int(timer.n_sdf_eval),
                             note="largest share of GPU time in the rocprofv3 kernel summary (profiles/). fp32 VALU kernel (no GEMM "
                                  "shape): priced against the fp32 peak, the same 157.3 TFLOP/s for vector and f32-input MFMA on "
                                  "gfx950; timed with HIP events on the launch stream in a single-stream pass",

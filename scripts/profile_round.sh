@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round profile on the GPU box: kernel trace (+stats) and the two HBM-traffic PMC passes of the SAME bench command.
+# usage: scripts/profile_round.sh <tag>      -> gpurun_out/<tag>_kernel_stats.csv, <tag>_pmc_{fetch,write}.csv
+# (rocprofv3 gets the program itself after `--`; counters run separately from the trace, one TCC counter per pass.)
+tag=${1:-rX}
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+CMD="python3 bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline"
+mkdir -p gpurun_out
+rm -rf gpurun_out/kt gpurun_out/pmc_f gpurun_out/pmc_w
+timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/kt -o kt -- $CMD > gpurun_out/${tag}_kt.log 2>&1
+python3 scripts/rocprof_summary.py gpurun_out/kt/kt_results.db gpurun_out/${tag}_kernel_stats.csv
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o f -- $CMD > gpurun_out/${tag}_pmc_f.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o w -- $CMD > gpurun_out/${tag}_pmc_w.log 2>&1
+find gpurun_out/pmc_f -name "*counter_collection.csv" | head -1 | xargs head -3
+python3 scripts/pmc_summary.py gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/${tag}_pmc_traffic.csv
+rm -rf gpurun_out/kt gpurun_out/pmc_f gpurun_out/pmc_w
+tail -1 gpurun_out/${tag}_kt.log | cut -c1-400
