@@ -145,21 +145,51 @@ __device__ __forceinline__ void tri_col_range(float y0, float y1, float y2, floa
 //      column's needed voxels, XOR-ed into the column's parity word (LDS atomic; XOR is order-free)
 //   -> phi = 0 for outside voxels, inside voxels appended to the batch-wide list.
 // Triangle-parallel on purpose: no per-column triangle lists, no dependent LDS chains, balanced lanes.
-// t > 0 test of the needed voxels of one column against one triangle (already known to pass the (u,v) test);
-// returns the hit mask.  Same operation order as oracle/sdf_grid.c ray_hit_px.
+// t of the +x ray from voxel centre i of a column against one triangle (already known to pass the (u,v) test).
+// Same operation order as oracle/sdf_grid.c ray_hit_px.
+__device__ __forceinline__ float sdf_ray_t(int i, float ax, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
+                                           float inv, float sy, float sz, float qx) {
+    const float px = (float)(2 * i + 1) / (float)SDF_G - 1.0f;
+    const float sx = px - ax;
+    const float qy = __builtin_fmaf(sz, e1x, -(sx * e1z));
+    const float qz = __builtin_fmaf(sx, e1y, -(sy * e1x));
+    return DOT3(e2x, e2y, e2z, qx, qy, qz) * inv;
+}
+
+// t > 0 test of the needed voxels of one column; returns the hit mask, bit for bit what evaluating sdf_ray_t for
+// every needed voxel gives -- without the per-voxel loop.  In real arithmetic t_i = x* - px_i: it falls by exactly
+// 1/16 per voxel (up to the rounding of det and 1/det, delta below), so one evaluation at the lowest needed
+// voxel places the crossing index ic = lo + 16 t_lo.  Voxels a whole index away from ic have |t| >= 1/16, far
+// above the rounding error E of the float expression (bounded term by term below), so their sign is known;
+// the (at most two) voxels next to the crossing are evaluated with the exact expression.  Whenever the bound
+// does not hold (near-degenerate triangles: huge 1/det) every needed voxel is evaluated.
 __device__ __forceinline__ unsigned sdf_ray_hits(unsigned need, float ax, float e1x, float e1y, float e1z, float e2x, float e2y,
                                                  float e2z, float inv, float sy, float sz, float qx) {
-    unsigned hits = 0, rem = need;
-    while (rem) {
-        const int i = __ffs((int)rem) - 1;
-        rem &= rem - 1;
-        const float px = (float)(2 * i + 1) / (float)SDF_G - 1.0f;
-        const float sx = px - ax;
-        const float qy = __builtin_fmaf(sz, e1x, -(sx * e1z));
-        const float qz = __builtin_fmaf(sx, e1y, -(sy * e1x));
-        const float tt = DOT3(e2x, e2y, e2z, qx, qy, qz) * inv;
-        if (tt > 0.0f) hits |= 1u << i;
+    const float U = 5.9604645e-8f;   // 2^-24
+    const int lo = __ffs((int)need) - 1, hi = 31 - __clz((int)need);
+    const float t_lo = sdf_ray_t(lo, ax, e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx);
+    const float ainv = fabsf(inv);
+    const float smax = fmaxf(fabsf((float)(2 * lo + 1) / (float)SDF_G - 1.0f - ax), fabsf((float)(2 * hi + 1) / (float)SDF_G - 1.0f - ax));
+    const float S = fabsf(e2x * qx) + fabsf(e2y) * (fabsf(sz * e1x) + smax * fabsf(e1z)) +
+                    fabsf(e2z) * (smax * fabsf(e1y) + fabsf(sy * e1x));
+    const float E = 16.0f * U * S * ainv;                                                    // |float t - real t|
+    const float delta = 4.0f * U * (fabsf(e1z * e2y) + fabsf(e1y * e2z)) * ainv + 4.0f * U;  // |det_real / det_float - 1|
+    if (!(E + 2.0f * delta < (1.0f / 64.0f))) {
+        unsigned hits = 0, rem = need;
+        while (rem) {
+            const int i = __ffs((int)rem) - 1;
+            rem &= rem - 1;
+            if (sdf_ray_t(i, ax, e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx) > 0.0f) hits |= 1u << i;
+        }
+        return hits;
     }
+    const float ic = fminf(fmaxf((float)lo + 16.0f * t_lo, -2.0f), 34.0f);
+    const int i1 = (int)floorf(ic), i2 = i1 + 1;
+    unsigned hits = need & (i1 <= 0 ? 0u : (i1 >= 32 ? 0xffffffffu : ((1u << i1) - 1u)));   // voxels below the crossing: t > 0
+    if (i1 >= 0 && i1 < SDF_G && ((need >> i1) & 1u) &&
+        sdf_ray_t(i1, ax, e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx) > 0.0f) hits |= 1u << i1;
+    if (i2 >= 0 && i2 < SDF_G && ((need >> i2) & 1u) &&
+        sdf_ray_t(i2, ax, e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx) > 0.0f) hits |= 1u << i2;
     return hits;
 }
 
@@ -291,22 +321,26 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
 #ifdef IHMR_TIMING
         { int ncol_ = (k1 - k0 + 1) * (j1 - j0 + 1); for (int o = 32; o > 0; o >>= 1) ncol_ = max(ncol_, __shfl_xor(ncol_, o)); if (blockIdx.x == 0 && lane == 0) g_dbg[160 + wave + 16 * it] = ncol_; }
 #endif
-        for (int k = k0; k <= k1; ++k) {
+        // one flat loop over the bounding box's columns: a wave then iterates max(ncol) times, not
+        // max(k range) * max(j range) as two nested divergent loops would
+        const int ncol = (j1 >= j0 && k1 >= k0) ? (k1 - k0 + 1) * (j1 - j0 + 1) : 0;
+        int j = j0, k = k0;
+        for (int cidx = 0; cidx < ncol; ++cidx) {
+            const int col = k * SDF_G + j;
+            const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
             const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
-            for (int j = j0; j <= j1; ++j) {
-                const unsigned need = needed[k * SDF_G + j];
-                if (!need) continue;
-                const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
-                const float sy = py - a[1], sz = pz - a[2];
-                const float uu = __builtin_fmaf(sz, e2y, -(sy * e2z)) * inv;
-                const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y));
-                const float vv = qx * inv;
-                st_tests += 1;
-                if (!((uu >= 0.0f) && (uu <= 1.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f))) continue;
-                const unsigned hits = sdf_ray_hits(need, a[0], e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx);
-                st_tests += __popc(need);
-                if (hits) atomicXor(&parity[k * SDF_G + j], hits);
-            }
+            if (++j > j1) { j = j0; ++k; }
+            const unsigned need = needed[col];
+            if (!need) continue;
+            const float sy = py - a[1], sz = pz - a[2];
+            const float uu = __builtin_fmaf(sz, e2y, -(sy * e2z)) * inv;
+            const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y));
+            const float vv = qx * inv;
+            st_tests += 1;
+            if (!((uu >= 0.0f) && (uu <= 1.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f))) continue;
+            const unsigned hits = sdf_ray_hits(need, a[0], e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx);
+            st_tests += __popc(need);
+            if (hits) atomicXor(&parity[col], hits);
         }
     }
 #ifdef IHMR_TIMING
