@@ -310,7 +310,8 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             dx = bb[0] - gx; dy = bb[1] - gy; dz = bb[2] - gz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
             dx = c[0] - gx; dy = c[1] - gy; dz = c[2] - gz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
         }
-        sph[f] = make_float4(gx, gy, gz, f < NF ? sqrtf(r2) * 1.0001f + 1e-6f : -1.0f);  // radius < 0 marks padding
+        // padding triangles (f >= NF): parked at 1e18 with radius 0, so the distance kernel culls them by arithmetic alone
+        sph[f] = f < NF ? make_float4(gx, gy, gz, sqrtf(r2) * 1.0001f + 1e-6f) : make_float4(1e18f, 1e18f, 1e18f, 0.0f);
 #ifdef IHMR_TIMING
         if (blockIdx.x == 0 && lane == 0) g_dbg[120 + wave + 16 * it] = clock64() - g_dbg[22];
 #endif
@@ -448,6 +449,7 @@ __device__ __forceinline__ float sdf_point_tri_dist2(const float* a, const float
 // takes 8 voxels.  Per voxel: wave-level min-reduction over the mesh (lanes across triangles) -- sphere pass
 // for the upper bound, cull, scan-compacted survivors, exact closest-point distance on dense lanes, DPP min.
 // Keeping the table in LDS instead of registers leaves ~70 VGPRs, i.e. 5 workgroups per CU to hide latency.
+typedef float sdf_v2f __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace ws, int collect_stats) {
     __shared__ float4 sph_s[NFP];
     __shared__ unsigned short surv[SDF_THREADS / WAVE][SDF_SURV_CAP];
@@ -470,68 +472,79 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
             curH = H;
         }
         const float4* abc = ws.abc + (size_t)H * NFP * 3;
-        for (int e = wave * (SDF_ITEM / 4); e < (wave + 1) * (SDF_ITEM / 4); ++e) {
-            const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)ent_l, e);
-            if (ent == 0xffffffffu) break;     // padding (only at the tail of a hand's run)
-            const int id = (int)(ent & 0xffffu);
-            const int col = id >> 5, i = id & 31, k = col >> 5, j = col & 31;
-            const float px = (float)(2 * i + 1) / (float)SDF_G - 1.0f;
-            const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
-            const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
-            float d2[NFP / WAVE];
-            float ub2 = INFINITY;
+        // two voxels at a time through the sphere passes: the table is read once for both and the arithmetic
+        // is on float pairs (packed fp32 instructions issue two lanes' worth per cycle)
+        for (int e = wave * (SDF_ITEM / 4); e < (wave + 1) * (SDF_ITEM / 4); e += 2) {
+            const unsigned ent0 = (unsigned)__builtin_amdgcn_readlane((int)ent_l, e);
+            const unsigned ent1r = (unsigned)__builtin_amdgcn_readlane((int)ent_l, e + 1);
+            if (ent0 == 0xffffffffu) break;     // padding (only at the tail of a hand's run)
+            const int nvox = ent1r != 0xffffffffu ? 2 : 1;
+            const int id0 = (int)(ent0 & 0xffffu), id1 = (int)((nvox == 2 ? ent1r : ent0) & 0xffffu);
+            const sdf_v2f PX = {(float)(2 * (id0 & 31) + 1) / (float)SDF_G - 1.0f, (float)(2 * (id1 & 31) + 1) / (float)SDF_G - 1.0f};
+            const sdf_v2f PY = {(float)(2 * ((id0 >> 5) & 31) + 1) / (float)SDF_G - 1.0f,
+                                (float)(2 * ((id1 >> 5) & 31) + 1) / (float)SDF_G - 1.0f};
+            const sdf_v2f PZ = {(float)(2 * (id0 >> 10) + 1) / (float)SDF_G - 1.0f, (float)(2 * (id1 >> 10) + 1) / (float)SDF_G - 1.0f};
+            sdf_v2f d2[NFP / WAVE];
+            sdf_v2f ub2 = {INFINITY, INFINITY};
 #pragma unroll
             for (int t = 0; t < NFP / WAVE; ++t) {
-                const float4 sp = sph_s[lane + WAVE * t];
-                const float dx = px - sp.x, dy = py - sp.y, dz = pz - sp.z;
-                d2[t] = dx * dx + dy * dy + dz * dz;
-                if (sp.w >= 0.0f) ub2 = fminf(ub2, d2[t]);
+                const float4 sp = sph_s[lane + WAVE * t];   // padding triangles sit at 1e18: never the minimum, always culled
+                const sdf_v2f dx = PX - sp.x, dy = PY - sp.y, dz = PZ - sp.z;
+                d2[t] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                ub2 = __builtin_elementwise_min(ub2, d2[t]);
             }
-            ub2 = wave_reduce_min(ub2);  // the centroid is a point of the triangle: dist <= |p - centroid|
-            const float ub_lim = sqrtf(ub2) * 1.0001f + 1e-6f;
-            unsigned keepmask = 0;
+            // the centroid is a point of the triangle: dist <= |p - centroid|
+            const float ub_a = sqrtf(wave_reduce_min(ub2.x)) * 1.0001f + 1e-6f, ub_b = sqrtf(wave_reduce_min(ub2.y)) * 1.0001f + 1e-6f;
+            const sdf_v2f ub_lim = {ub_a, ub_b};
+            unsigned keep_a = 0, keep_b = 0;
 #pragma unroll
             for (int t = 0; t < NFP / WAVE; ++t) {
                 const float r = sph_s[lane + WAVE * t].w;
-                const float lim = ub_lim + r;
+                const sdf_v2f lim = ub_lim + r;
+                const sdf_v2f lim2 = lim * lim * 1.00001f;
                 // cull iff |p - centroid| - radius > upper bound (exact: such a triangle cannot be the minimum)
-                const bool keep = (r >= 0.0f) && !(d2[t] > lim * lim * 1.00001f);
-                keepmask |= keep ? (1u << t) : 0u;
+                keep_a |= !(d2[t].x > lim2.x) ? (1u << t) : 0u;
+                keep_b |= !(d2[t].y > lim2.y) ? (1u << t) : 0u;
             }
-            int cnt;
-            const int mine = __popc(keepmask);
-            int off = wave_incl_scan(mine, cnt) - mine;
-            float best = INFINITY;
-            if (cnt <= SDF_SURV_CAP) {
-                while (keepmask) {
-                    const int t = __ffs((int)keepmask) - 1;
-                    keepmask &= keepmask - 1;
-                    mylist[off++] = (unsigned short)(lane + WAVE * t);
+            for (int v = 0; v < nvox; ++v) {
+                unsigned keepmask = v ? keep_b : keep_a;
+                const int id = v ? id1 : id0;
+                const float px = v ? PX.y : PX.x, py = v ? PY.y : PY.x, pz = v ? PZ.y : PZ.x;
+                int cnt;
+                const int mine = __popc(keepmask);
+                int off = wave_incl_scan(mine, cnt) - mine;
+                float best = INFINITY;
+                if (cnt <= SDF_SURV_CAP) {
+                    while (keepmask) {
+                        const int t = __ffs((int)keepmask) - 1;
+                        keepmask &= keepmask - 1;
+                        mylist[off++] = (unsigned short)(lane + WAVE * t);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    for (int sidx = lane; sidx < cnt; sidx += WAVE) {
+                        const int f = mylist[sidx];
+                        const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
+                        const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
+                        best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
+                        st_dist += 1;
+                    }
+                } else {   // (degenerate geometry) more survivors than list slots: every lane walks its own triangles
+                    while (keepmask) {
+                        const int t = __ffs((int)keepmask) - 1;
+                        keepmask &= keepmask - 1;
+                        const int f = lane + WAVE * t;
+                        const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
+                        const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
+                        best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
+                        st_dist += 1;
+                    }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                best = wave_reduce_min(best);
+                if (lane == 0) ws.phi[(size_t)H * SDF_NVOX + id] = sqrtf(best);
                 __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                for (int sidx = lane; sidx < cnt; sidx += WAVE) {
-                    const int f = mylist[sidx];
-                    const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
-                    const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
-                    best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
-                    st_dist += 1;
-                }
-            } else {   // (degenerate geometry) more survivors than list slots: every lane walks its own triangles
-                while (keepmask) {
-                    const int t = __ffs((int)keepmask) - 1;
-                    keepmask &= keepmask - 1;
-                    const int f = lane + WAVE * t;
-                    const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
-                    const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
-                    best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
-                    st_dist += 1;
-                }
             }
-            best = wave_reduce_min(best);
-            if (lane == 0) ws.phi[(size_t)H * SDF_NVOX + id] = sqrtf(best);
-            __builtin_amdgcn_wave_barrier();
         }
     }
     TSTAMP(41);
