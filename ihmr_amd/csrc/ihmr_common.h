@@ -92,6 +92,18 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// the same sum without LDS traffic: DPP row rotations, then lanes 0 / 16 / 32 / 48 through scalar registers (fixed order)
+__device__ __forceinline__ float wave_reduce_sum_dpp(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(8), 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(4), 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(2), 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(1), 0xf, 0xf, false));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ unsigned wave_reduce_xor(unsigned v) {
     v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_ROR(8), 0xf, 0xf, false);
     v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_ROR(4), 0xf, 0xf, false);

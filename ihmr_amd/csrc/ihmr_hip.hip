@@ -200,10 +200,9 @@ extern "C" size_t ihmr_sdf_workspace_bytes(int B) { return sdf_ws_bytes(2 * B) +
 static int g_collect_stats = 0;
 
 static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const int32_t* faces_l_soa, int B, SdfWorkspace ws,
-                      float robustifier, float* loss, float* per_vert, float* origin, float* dval, float* gverts,
-                      const float* gscale, const float* hand_type, bool dense, hipStream_t st) {
-    // the per-XCD inside-voxel counters are zeroed by the sample kernel of the previous call (and once at
-    // workspace set-up, see sdf_reset); the prep kernel appends to them
+                      float robustifier, float* loss, float* per_vert, float* origin, float* dval, bool dense, hipStream_t st) {
+    // the inside-voxel counter is zero on entry (faces_to_soa_kernel / the sample kernel of the previous call /
+    // the memset at the head of a refinement stage); the prep kernel appends to it
     if (dense)
         hipLaunchKernelGGL(sdf_prep_kernel<true>, dim3(2 * B), dim3(SDF_PREP_THREADS), 0, st, vl, B, faces_r_soa, faces_l_soa, ws,
                            g_collect_stats);
@@ -225,7 +224,7 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
     }
     if (loss)
         hipLaunchKernelGGL(sdf_sample_kernel, dim3(B), dim3(SDF_SAMPLE_THREADS), 0, st, vl, ws, robustifier, loss, per_vert, origin,
-                           dval, gverts, B, gscale, hand_type);
+                           dval, B);
     return (int)hipGetLastError();
 }
 
@@ -248,7 +247,7 @@ extern "C" int ihmr_sdf_collision(const int32_t* faces_right, const int32_t* fac
     hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa, ws.inside_count);
     hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP, (int*)nullptr);
     VertLayout vl{hand_verts, (long)2 * NV3, (long)NV3};
-    return sdf_launch(vl, soa, soa + 3 * NFP, B, ws, robustifier, loss, per_vert, origin_scale, dval, nullptr, nullptr, nullptr, false, st);
+    return sdf_launch(vl, soa, soa + 3 * NFP, B, ws, robustifier, loss, per_vert, origin_scale, dval, false, st);
 }
 
 extern "C" int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
@@ -260,7 +259,7 @@ extern "C" int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* fa
     hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa, ws.inside_count);
     hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP, (int*)nullptr);
     VertLayout vl{hand_verts, (long)2 * NV3, (long)NV3};
-    int rc = sdf_launch(vl, soa, soa + 3 * NFP, B, ws, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, st);
+    int rc = sdf_launch(vl, soa, soa + 3 * NFP, B, ws, 0.f, nullptr, nullptr, nullptr, nullptr, true, st);
     if (rc) return rc;
     // workspace order is hand = hnd*B + b; the caller's grid is (B,2,...)
     for (int b = 0; b < B; ++b)
@@ -277,11 +276,18 @@ static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
                        const ihmr_opt_weights& w, hipStream_t st) {
     lbs_forward_launch(m, true, io->orient, io->pose, io->shape, io->trans, 2 * B, B, io->verts, wk.joints_raw, wk.lbs, st);
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
-    hipLaunchKernelGGL(opt_loss_kernel, dim3(B), dim3(LOSS_THREADS), 0, st, *io, wk, B, w, ws.inside_count);
     VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
-    // loss_batch[2] = collision loss per sample, masked by hand type inside the sample kernel
-    return sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, B, ws, 0.f, io->loss_batch + 2 * B, io->coll_per_vert, io->coll_origin_scale,
-                      nullptr, wk.g_verts, wk.gscale, io->hand_type_array, false, st);
+    int rc = sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, B, ws, 0.f, nullptr, nullptr, nullptr, nullptr, false, st);
+    if (rc) return rc;
+    // collision sampling (loss_batch[2], masked by hand type; gradient -> g_verts) and the joint losses in one launch
+    hipLaunchKernelGGL(opt_sample_loss_kernel, dim3(B), dim3(SDF_SAMPLE_THREADS), 0, st, *io, wk, B, w, vl, ws);
+    return (int)hipGetLastError();
+}
+
+// the collision kernels expect the inside-voxel counter at zero; afterwards every sample kernel re-arms it
+static hipError_t opt_arm(const OptWork& wk, int B, hipStream_t st) {
+    SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
+    return hipMemsetAsync(ws.inside_count, 0, SDF_NXCD * sizeof(int), st);
 }
 
 extern "C" int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
@@ -289,6 +295,7 @@ extern "C" int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_le
     if (!m || !io || !w || B <= 0) return -1;
     hipStream_t st = (hipStream_t)stream;
     OptWork wk = opt_carve(io->workspace, B);
+    HIP_TRY(opt_arm(wk, B, st));
     int rc = opt_forward(m, m_left, io, wk, B, *w, st);
     if (rc) return rc;
     return (int)hipGetLastError();
@@ -302,6 +309,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     OptWork wk = opt_carve(io->workspace, B);
     HIP_TRY(hipMemsetAsync(io->adam_m, 0, (size_t)B * OPT_PMAX * 4, st));
     HIP_TRY(hipMemsetAsync(io->adam_v, 0, (size_t)B * OPT_PMAX * 4, st));
+    HIP_TRY(opt_arm(wk, B, st));
     const int P = group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
     const int need_mask = group == IHMR_GROUP_TRANS ? 8 : (group == IHMR_GROUP_ORIENT ? 1 : (group == IHMR_GROUP_POSE ? 2 : 4));
     int S = 0;
@@ -396,6 +404,7 @@ extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, c
     ihmr_kernel_timer* keep = g_timer;
     g_timer = nullptr;
     g_collect_stats = 1;
+    HIP_TRY(opt_arm(wk, B, st));
     int rc = opt_forward(m, m_left, io, wk, B, *w, st);
     g_collect_stats = 0;
     g_timer = keep;

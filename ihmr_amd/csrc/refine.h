@@ -20,7 +20,6 @@ struct OptWork {  // carved from ihmr_opt_io.workspace
     float* g_pose;      // (2,B,45)
     float* g_shape;     // (2,B,10)
     float* g_trans;     // (B,3)
-    float* gscale;      // (B)
     void* sdf_ws;
 };
 
@@ -48,7 +47,6 @@ static inline OptWork opt_carve(void* ws, int B) {
     w.g_pose = (float*)take((size_t)B * 90 * 4);
     w.g_shape = (float*)take((size_t)B * 20 * 4);
     w.g_trans = (float*)take((size_t)B * 3 * 4);
-    w.gscale = (float*)take((size_t)B * 4);
     w.sdf_ws = (void*)p;
     return w;
 }
@@ -65,21 +63,31 @@ __device__ __forceinline__ void cross3(const float* a, const float* b, float* o)
 // root of loss_utils.py:90-98: weight > 0.5 -> joint 0, weight < 1e-7 -> joint 21, else no alignment
 __device__ __forceinline__ int align_root(float w) { return w > 0.5f ? 0 : (w < 1e-7f ? 21 : -1); }
 
-// grid = B, block = 64: thread j < 42 owns joint j.
-__global__ __launch_bounds__(LOSS_THREADS) void opt_loss_kernel(ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,
-                                                                int* zero8) {
-    __shared__ float raw[42][3], p1[42][3], p2[42][3], g2[42][3], acc[8][LOSS_THREADS], gsum[2][3];
-    const int b = blockIdx.x, j = threadIdx.x;
-    if (b == 0 && j < 8) zero8[j] = 0;  // per-XCD inside-voxel counters of the collision kernels that follow
+// ONE wave per sample: lane j < 42 owns joint j (the steps are separated by wave-level barriers only, so the
+// wave can run beside the collision sampling of the same workgroup, see opt_sample_loss_kernel).
+struct LossShared {
+    float raw[42][3], p1[42][3], p2[42][3], g2[42][3], acc[8][LOSS_THREADS], gsum[2][3];
+};
+// LDS hand-off between the lanes of one wave: DS operations of a wave execute in order, the fences only stop the
+// compiler from moving them
+#define LOSS_SYNC()                                                  \
+    do {                                                             \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       \
+        __builtin_amdgcn_wave_barrier();                             \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       \
+    } while (0)
+
+__device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWork& wk, int B, const ihmr_opt_weights& w,
+                                              LossShared& sh, int b, int j) {
     const bool act = j < 42;
     const float* cam = io.cam + b * 3;
     const float cs = cam[0], ctx = cam[1], cty = cam[2];
     float r[3] = {0.f, 0.f, 0.f};
     if (act) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { r[k] = wk.joints_raw[(b * 42 + j) * 3 + k]; raw[j][k] = r[k]; }
+        for (int k = 0; k < 3; ++k) { r[k] = wk.joints_raw[(b * 42 + j) * 3 + k]; sh.raw[j][k] = r[k]; }
     }
-    __syncthreads();
+    LOSS_SYNC();
 
     // ---- 2D: projection of the un-aligned joints (transform_utils.py:47-54, optimize_model.py:263)
     float l2d_p = 0.f, l2d_gt = 0.f, g_raw[3] = {0.f, 0.f, 0.f};
@@ -105,9 +113,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void opt_loss_kernel(ihmr_opt_io io, 
     float a1[3], a2[3], l3d_gt = 0.f, l3d_p = 0.f;
     if (act) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { a1[k] = root1 >= 0 ? r[k] - raw[root1][k] : r[k]; p1[j][k] = a1[k]; }
+        for (int k = 0; k < 3; ++k) { a1[k] = root1 >= 0 ? r[k] - sh.raw[root1][k] : r[k]; sh.p1[j][k] = a1[k]; }
     }
-    __syncthreads();
+    LOSS_SYNC();
     if (act) {
         const float* tg = io.gt_joints_3d + (b * 42 + j) * 4;
         const float* tg0 = io.gt_joints_3d + (b * 42 + (root1 >= 0 ? root1 : 0)) * 4;
@@ -116,17 +124,17 @@ __global__ __launch_bounds__(LOSS_THREADS) void opt_loss_kernel(ihmr_opt_io io, 
         const float s3 = w.joints_3d / (float)(B * 42 * 3);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            a2[k] = root2 >= 0 ? a1[k] - p1[root2][k] : a1[k];
-            p2[j][k] = a2[k];
+            a2[k] = root2 >= 0 ? a1[k] - sh.p1[root2][k] : a1[k];
+            sh.p2[j][k] = a2[k];
             const float gg = (root1 >= 0 ? tg[k] - tg0[k] : tg[k]) - a1[k];
             l3d_gt += gg * gg * tg[3];
             const float gi = (root2 >= 0 ? ti[k] - ti0[k] : ti[k]) - a2[k];
             l3d_p += gi * gi * ti[3];
-            g2[j][k] = -2.0f * s3 * gi * ti[3];
+            sh.g2[j][k] = -2.0f * s3 * gi * ti[3];
             io.joints_3d[(b * 42 + j) * 3 + k] = a2[k];
         }
     }
-    __syncthreads();
+    LOSS_SYNC();
 
     // ---- finger regulariser on the aligned joints (loss_utils.py:138-171); thread f < 10 owns a finger
     float lfin = 0.f;
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void opt_loss_kernel(ihmr_opt_io io, 
                   it = c_finger_ids[4 * fi + 3] + off;
         float f0[3], f1[3], f2[3], n1[3], n2[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { f0[k] = p2[ia][k] - p2[ib][k]; f1[k] = p2[ib][k] - p2[ic][k]; f2[k] = p2[ic][k] - p2[it][k]; }
+        for (int k = 0; k < 3; ++k) { f0[k] = sh.p2[ia][k] - sh.p2[ib][k]; f1[k] = sh.p2[ib][k] - sh.p2[ic][k]; f2[k] = sh.p2[ic][k] - sh.p2[it][k]; }
         cross3(f0, f1, n1);
         cross3(f1, f2, n2);
         const float C1 = f2[0] * n1[0] + f2[1] * n1[1] + f2[2] * n1[2];
@@ -160,52 +168,52 @@ __global__ __launch_bounds__(LOSS_THREADS) void opt_loss_kernel(ihmr_opt_io io, 
                 const float d1 = k1 * t1[k] + k2 * (t3[k] + t4[k]);
                 const float d2 = k1 * n1[k] + k2 * t5[k];
                 // every joint belongs to exactly one finger, so these writes never collide
-                g2[ia][k] += d0;
-                g2[ib][k] += d1 - d0;
-                g2[ic][k] += d2 - d1;
-                g2[it][k] += -d2;
+                sh.g2[ia][k] += d0;
+                sh.g2[ib][k] += d1 - d0;
+                sh.g2[ic][k] += d2 - d1;
+                sh.g2[it][k] += -d2;
             }
         }
     }
-    __syncthreads();
+    LOSS_SYNC();
 
     // ---- back through the two alignments: g_in = g_out - [j == root] * sum_j g_out
     if (j < 3) {
         float s = 0.f;
-        for (int q = 0; q < 42; ++q) s += g2[q][j];
-        gsum[0][j] = s;
+        for (int q = 0; q < 42; ++q) s += sh.g2[q][j];
+        sh.gsum[0][j] = s;
     }
-    __syncthreads();
+    LOSS_SYNC();
     float g1[3];
     if (act) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            g1[k] = g2[j][k] - ((root2 >= 0 && j == root2) ? gsum[0][k] : 0.f);
-            p1[j][k] = g1[k];  // reuse as scratch for the second sum
+            g1[k] = sh.g2[j][k] - ((root2 >= 0 && j == root2) ? sh.gsum[0][k] : 0.f);
+            sh.p1[j][k] = g1[k];  // reuse as scratch for the second sum
         }
     }
-    __syncthreads();
+    LOSS_SYNC();
     if (j < 3) {
         float s = 0.f;
-        for (int q = 0; q < 42; ++q) s += p1[q][j];
-        gsum[1][j] = s;
+        for (int q = 0; q < 42; ++q) s += sh.p1[q][j];
+        sh.gsum[1][j] = s;
     }
-    __syncthreads();
+    LOSS_SYNC();
     if (act) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float g0 = g1[k] - ((root1 >= 0 && j == root1) ? gsum[1][k] : 0.f);
+            const float g0 = g1[k] - ((root1 >= 0 && j == root1) ? sh.gsum[1][k] : 0.f);
             wk.g_joints[(b * 42 + j) * 3 + k] = g0 + g_raw[k];
         }
     }
 
     // ---- per-sample reductions (fixed order: thread 0 sums 42 entries)
-    acc[0][j] = l2d_p; acc[1][j] = l3d_p; acc[2][j] = lfin; acc[3][j] = l2d_gt; acc[4][j] = l3d_gt;
-    __syncthreads();
+    sh.acc[0][j] = l2d_p; sh.acc[1][j] = l3d_p; sh.acc[2][j] = lfin; sh.acc[3][j] = l2d_gt; sh.acc[4][j] = l3d_gt;
+    LOSS_SYNC();
     if (j < 5) {
         float s = 0.f;
         const int n = j == 2 ? 10 : 42;
-        for (int q = 0; q < n; ++q) s += acc[j][q];
+        for (int q = 0; q < n; ++q) s += sh.acc[j][q];
         if (j == 0) io.loss_batch[0 * B + b] = s / 84.f * w.joints_2d;
         if (j == 1) io.loss_batch[1 * B + b] = s / 126.f * w.joints_3d;
         if (j == 2) io.loss_batch[3 * B + b] = s;
@@ -229,9 +237,25 @@ __global__ __launch_bounds__(LOSS_THREADS) void opt_loss_kernel(ihmr_opt_io io, 
         }
         io.loss_batch[6 * B + b] = lp / 3.f;
         io.loss_batch[7 * B + b] = lg / 3.f;
-        const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
-        wk.gscale[b] = w.collision * mask / (4.0f * (float)B);
     }
+}
+
+// Collision sampling + joint / translation / finger losses of sample b in one launch.  grid = B, block = 1024:
+// waves 0-14 sample the two distance grids at the other hand's vertices (value, gradient -> g_verts), wave 15
+// evaluates the joint losses and their gradient (-> g_joints); the two halves share nothing but the launch.
+#define OPT_SAMPLE_WORKERS (SDF_SAMPLE_THREADS - WAVE)
+__global__ __launch_bounds__(SDF_SAMPLE_THREADS) void opt_sample_loss_kernel(ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,
+                                                                             VertLayout vl, SdfWorkspace ws) {
+    __shared__ LossShared sh;
+    __shared__ float red16[SDF_SAMPLE_THREADS / WAVE];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid >= OPT_SAMPLE_WORKERS) opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS);
+    // collision gradient scale: weight * [two-hand sample] / (num_hands^2 * B)   (loss_utils.py:186-188)
+    const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
+    const float gs = w.collision * mask / (4.0f * (float)B);
+    sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, io.coll_per_vert, io.coll_origin_scale, nullptr, wk.g_verts, B, gs,
+                     io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
+    if (b == 0 && tid < SDF_NXCD) ws.inside_count[tid] = 0;   // ready for the next iteration's prep kernel
 }
 
 // Adds the direct (non-MANO) gradient terms, takes the snapshot (before the step, as

@@ -557,23 +557,21 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
 }
 
 // ------------------------------------------------------------------------------------- sample
-// grid = B, block = 256.  Entry e = hnd*778 + v samples phi of hand `hnd` at vertex v of hand 1-hnd.
+// One workgroup of SDF_SAMPLE_THREADS per sample b; threads tid < nworkers share the 1556 entries.  Entry
+// e = hnd*778 + v samples phi of hand `hnd` at vertex v of hand 1-hnd.
 // Writes per_vert / origin_scale (B,1556), dval (B,1556,3) = d per_vert / d vertex, loss (B)
 // (x mask[b] = [hand_type_array sum > 1.5] when hand_type != nullptr, loss_utils.py:186-188).
-// If gverts != nullptr: fused-path gradient gverts[(1-hnd), b, v, :] = gscale[b] * dval  (layout (2,B,778,3)).
+// If gverts != nullptr: fused-path gradient gverts[(1-hnd), b, v, :] = gs * dval  (layout (2,B,778,3)).
 #define SDF_SAMPLE_THREADS 1024
-__global__ __launch_bounds__(SDF_SAMPLE_THREADS) void sdf_sample_kernel(VertLayout vl, SdfWorkspace ws, float robustifier,
-                                                                 float* __restrict__ loss, float* __restrict__ per_vert,
-                                                                 float* __restrict__ origin, float* __restrict__ dval,
-                                                                 float* __restrict__ gverts, int B,
-                                                                 const float* __restrict__ gscale,
-                                                                 const float* __restrict__ hand_type) {
-    __shared__ float red[SDF_SAMPLE_THREADS];
-    const int b = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const SdfWorkspace& ws, float robustifier,
+                                                 float* __restrict__ loss, float* __restrict__ per_vert,
+                                                 float* __restrict__ origin, float* __restrict__ dval,
+                                                 float* __restrict__ gverts, int B, float gs,
+                                                 const float* __restrict__ hand_type, float* red16, int b, int nworkers) {
+    const int tid = threadIdx.x;
     TSTAMP(50);
     float acc = 0.f;
-    const float gs = gscale ? gscale[b] : 0.f;
-    for (int e = tid; e < 2 * NV; e += SDF_SAMPLE_THREADS) {
+    for (int e = tid; e < 2 * NV && tid < nworkers; e += nworkers) {
         const int hnd = e / NV, v = e % NV;
         const int H = hnd * B + b;
         const float4 bx = *reinterpret_cast<const float4*>(ws.box + H * 4);
@@ -632,11 +630,25 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void sdf_sample_kernel(VertLayo
         acc += val;
     }
     TSTAMP(51);
-    const float tot = block_reduce_sum(acc, red);
+    // fixed-order block sum: DPP inside each wave, the 16 wave totals through LDS
+    const float wsum = wave_reduce_sum_dpp(acc);
+    if (tid % WAVE == 0) red16[tid / WAVE] = wsum;
+    __syncthreads();
     TSTAMP(52);
     if (tid == 0) {
+        float tot = 0.f;
+        for (int wv = 0; wv < SDF_SAMPLE_THREADS / WAVE; ++wv) tot += red16[wv];
         float mask = 1.0f;
         if (hand_type) mask = (hand_type[b * 2] + hand_type[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
         loss[b] = tot / 4.0f * mask;  // parent project: sum / num_hands^2
     }
+}
+
+// seam B: grid = B, block = 1024
+__global__ __launch_bounds__(SDF_SAMPLE_THREADS) void sdf_sample_kernel(VertLayout vl, SdfWorkspace ws, float robustifier,
+                                                                 float* __restrict__ loss, float* __restrict__ per_vert,
+                                                                 float* __restrict__ origin, float* __restrict__ dval, int B) {
+    __shared__ float red16[SDF_SAMPLE_THREADS / WAVE];
+    sdf_sample_block(vl, ws, robustifier, loss, per_vert, origin, dval, nullptr, B, 0.f, nullptr, red16, blockIdx.x, SDF_SAMPLE_THREADS);
+    if (blockIdx.x == 0 && threadIdx.x < SDF_NXCD) ws.inside_count[threadIdx.x] = 0;   // ready for the next call's prep kernel
 }

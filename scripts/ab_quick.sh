@@ -10,4 +10,4 @@ for lib in "$@"; do
   python3 scripts/rocprof_summary.py gpurun_out/ab/ab_results.db /tmp/ab.csv | grep -E "${ABK:-sdf_dist|sdf_prep}"
 done
 cp /tmp/keep.so ihmr_amd/libihmr_hip.so
-rm -rf gpurun_out/ab
+mv gpurun_out/ab/ab_results.db /tmp/ab_last.db; rm -rf gpurun_out/ab
