@@ -272,9 +272,12 @@ extern "C" int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* fa
 // ------------------------------------------------------------------------------------------ seam C
 extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
 
+// `prev` = the Adam step of the previous iteration (group < 0: none), applied at the head of the skeleton kernel
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
-                       const ihmr_opt_weights& w, hipStream_t st) {
-    lbs_forward_launch(m, true, io->orient, io->pose, io->shape, io->trans, 2 * B, B, io->verts, wk.joints_raw, wk.lbs, st);
+                       const ihmr_opt_weights& w, const AdamStep& prev, hipStream_t st) {
+    hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev);
+    hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m, (const float*)wk.lbs.skel,
+                       2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
     VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
     int rc = sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, B, ws, 0.f, nullptr, nullptr, nullptr, nullptr, false, st);
@@ -296,7 +299,7 @@ extern "C" int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_le
     hipStream_t st = (hipStream_t)stream;
     OptWork wk = opt_carve(io->workspace, B);
     HIP_TRY(opt_arm(wk, B, st));
-    int rc = opt_forward(m, m_left, io, wk, B, *w, st);
+    int rc = opt_forward(m, m_left, io, wk, B, *w, AdamStep{-1, 0.f, 0.f, 1.f, -1}, st);
     if (rc) return rc;
     return (int)hipGetLastError();
 }
@@ -313,18 +316,17 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     const int P = group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
     const int need_mask = group == IHMR_GROUP_TRANS ? 8 : (group == IHMR_GROUP_ORIENT ? 1 : (group == IHMR_GROUP_POSE ? 2 : 4));
     int S = 0;
+    AdamStep step{-1, 0.f, 0.f, 1.f, -1};
     for (int it = 0; it < n_iters; ++it) {
-        int rc = opt_forward(m, m_left, io, wk, B, *w, st);
+        int rc = opt_forward(m, m_left, io, wk, B, *w, step, st);   // applies the step of iteration it - 1 first
         if (rc) return rc;
-            lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
+        lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
                             wk.lbs, st);
-        const int snap = (it % save_freq == 0) ? S++ : -1;
         const double t = (double)(it + 1);
         const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
-        const float step_size = (float)((double)lr / bc1), bc2s = (float)sqrt(bc2);
-        hipLaunchKernelGGL(opt_adam_kernel, dim3((B * P + 255) / 256), dim3(256), 0, st, *io, wk, B, group, w->shape_reg,
-                           step_size, bc2s, snap);
+        step = AdamStep{group, w->shape_reg, (float)((double)lr / bc1), (float)sqrt(bc2), (it % save_freq == 0) ? S++ : -1};
     }
+    hipLaunchKernelGGL(opt_adam_kernel, dim3(B), dim3(128), 0, st, *io, wk, B, step);
     hipLaunchKernelGGL(opt_select_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B, group, S, filter_factor_j3d,
                        filter_factor_coll, select_on_collision);
     return (int)hipGetLastError();
@@ -405,7 +407,7 @@ extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, c
     g_timer = nullptr;
     g_collect_stats = 1;
     HIP_TRY(opt_arm(wk, B, st));
-    int rc = opt_forward(m, m_left, io, wk, B, *w, st);
+    int rc = opt_forward(m, m_left, io, wk, B, *w, AdamStep{-1, 0.f, 0.f, 1.f, -1}, st);
     g_collect_stats = 0;
     g_timer = keep;
     if (rc) return rc;

@@ -124,15 +124,14 @@ __device__ __forceinline__ void rodrigues_bwd(const float* r, const float* dR, f
 }
 
 // ------------------------------------------------------------------------------------- skeleton
-// grid = N hands, block = 192.  TWO_HAND: hands [0,B) right, [B,2B) left of sample (h - B); joints out
-// is (B,42,3) (posed joints only; the 5 tips are written by the skin kernel), else (N,16,3).
+// 192 threads per hand h (tid = 0..191; every thread of the workgroup must call it: block-wide barriers inside).
+// TWO_HAND: hands [0,B) right, [B,2B) left of sample (h - B); joints out is (B,42,3) (posed joints only; the
+// 5 tips are written by the skin kernel), else (N,16,3).  sk = SK_STRIDE floats of LDS owned by this hand.
 template <bool TWO_HAND>
-__global__ __launch_bounds__(192) void lbs_skel_kernel(ihmr_mano m, const float* __restrict__ orient,
-                                                       const float* __restrict__ pose, const float* __restrict__ betas,
-                                                       const float* __restrict__ trans, int B, float* __restrict__ skel,
-                                                       float* __restrict__ joints) {
-    __shared__ float sk[SK_STRIDE];
-    const int h = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void lbs_skel_hand(const ihmr_mano& m, const float* __restrict__ orient,
+                                              const float* __restrict__ pose, const float* __restrict__ betas,
+                                              const float* __restrict__ trans, int B, float* __restrict__ skel,
+                                              float* __restrict__ joints, float* sk, int h, int tid) {
     const bool left = TWO_HAND && h >= B;
     float* sR = sk + SK_R; float* sJ = sk + SK_J; float* sG = sk + SK_G; float* sA = sk + SK_A;
     float* sPF = sk + SK_PF; float* sPose = sk + SK_POSE; float* sBeta = sk + SK_BETA; float* sShift = sk + SK_SHIFT;
@@ -208,6 +207,16 @@ __global__ __launch_bounds__(192) void lbs_skel_kernel(ihmr_mano m, const float*
             joints[((size_t)b * 42 + (left ? 21 : 0) + j) * 3 + k] = val;
         }
     }
+}
+
+// seam A / generic: grid = N hands, block = 192
+template <bool TWO_HAND>
+__global__ __launch_bounds__(192) void lbs_skel_kernel(ihmr_mano m, const float* __restrict__ orient,
+                                                       const float* __restrict__ pose, const float* __restrict__ betas,
+                                                       const float* __restrict__ trans, int B, float* __restrict__ skel,
+                                                       float* __restrict__ joints) {
+    __shared__ float sk[SK_STRIDE];
+    lbs_skel_hand<TWO_HAND>(m, orient, pose, betas, trans, B, skel, joints, sk, blockIdx.x, threadIdx.x);
 }
 
 // hand i of group (x, s): x + 8 * (8 s + i) -- all hands of a group share (hand % 8), i.e. the XCD that ran

@@ -258,16 +258,21 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void opt_sample_loss_kernel(ihm
     if (b == 0 && tid < SDF_NXCD) ws.inside_count[tid] = 0;   // ready for the next iteration's prep kernel
 }
 
-// Adds the direct (non-MANO) gradient terms, takes the snapshot (before the step, as
-// optimize_model.py:401-403) and applies torch.optim.Adam's single-tensor update.
-// grid = ceil(B*P/256); element (b, e): e < P, hand = e / D, d = e % D.
-__global__ void opt_adam_kernel(ihmr_opt_io io, OptWork wk, int B, int group, float w_shape_reg, float step_size,
-                                float bc2_sqrt, int snap_idx) {
-    const int P = group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
+// One Adam step of parameter e (< P) of sample b: adds the direct (non-MANO) gradient terms, takes the snapshot
+// (before the step, as optimize_model.py:401-403) and applies torch.optim.Adam's single-tensor update.
+// Element e: hand = e / D, d = e % D.
+struct AdamStep {
+    int group;            // IHMR_GROUP_*, or < 0: no update
+    float w_shape_reg, step_size, bc2_sqrt;
+    int snap_idx;         // >= 0: snapshot slot of this iteration
+};
+__device__ __forceinline__ int adam_group_size(int group) {
+    return group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
+}
+__device__ __forceinline__ void opt_adam_apply(const ihmr_opt_io& io, const OptWork& wk, int B, const AdamStep& st, int b, int e) {
+    const int group = st.group, P = adam_group_size(group);
     const int D = group == IHMR_GROUP_TRANS ? 3 : P / 2;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * P) return;
-    const int b = idx / P, e = idx % P, hnd = e / D, d = e % D;
+    const int hnd = e / D, d = e % D;
     float* p;
     float g;
     if (group == IHMR_GROUP_TRANS) {
@@ -284,25 +289,44 @@ __global__ void opt_adam_kernel(ihmr_opt_io io, OptWork wk, int B, int group, fl
         g = wk.g_shape[((size_t)hnd * B + b) * 10 + d];
         // shape regulariser mean((beta_r - beta_l)^2) (loss_utils.py:121-128)
         const float diff = io.shape[(size_t)b * 10 + d] - io.shape[((size_t)B + b) * 10 + d];
-        const float gr = 2.0f * w_shape_reg / (float)(B * 10) * diff;
+        const float gr = 2.0f * st.w_shape_reg / (float)(B * 10) * diff;
         g += hnd == 0 ? gr : -gr;
     }
     const float x = *p;
-    if (snap_idx >= 0) {
-        io.snap_params[((size_t)snap_idx * B + b) * OPT_PMAX + e] = x;
+    if (st.snap_idx >= 0) {
+        io.snap_params[((size_t)st.snap_idx * B + b) * OPT_PMAX + e] = x;
         if (e == 0) {
-            io.snap_loss[((size_t)snap_idx * 2 + 0) * B + b] = io.loss_batch[1 * B + b];
-            io.snap_loss[((size_t)snap_idx * 2 + 1) * B + b] = io.loss_batch[2 * B + b];
+            io.snap_loss[((size_t)st.snap_idx * 2 + 0) * B + b] = io.loss_batch[1 * B + b];
+            io.snap_loss[((size_t)st.snap_idx * 2 + 1) * B + b] = io.loss_batch[2 * B + b];
         }
     }
     float m = io.adam_m[b * OPT_PMAX + e], v = io.adam_v[b * OPT_PMAX + e];
     m = m + 0.1f * (g - m);                  // exp_avg.lerp_(grad, 1 - beta1)
     v = v * 0.999f;                          // exp_avg_sq.mul_(beta2)
     v = v + (0.001f * g) * g;                //            .addcmul_(grad, grad, value = 1 - beta2)
-    const float denom = sqrtf(v) / bc2_sqrt + 1e-8f;
+    const float denom = sqrtf(v) / st.bc2_sqrt + 1e-8f;
     io.adam_m[b * OPT_PMAX + e] = m;
     io.adam_v[b * OPT_PMAX + e] = v;
-    *p = x + (-step_size) * (m / denom);     // param.addcdiv_(exp_avg, denom, value = -step_size)
+    *p = x + (-st.step_size) * (m / denom);  // param.addcdiv_(exp_avg, denom, value = -step_size)
+}
+
+// stand-alone step (the last iteration of a stage): grid = B, block = 128, thread e < P.  The shape group reads
+// both hands' values of a sample while updating them: its 20 threads sit in one wave, reads before writes.
+__global__ __launch_bounds__(128) void opt_adam_kernel(ihmr_opt_io io, OptWork wk, int B, AdamStep st) {
+    if ((int)threadIdx.x < adam_group_size(st.group)) opt_adam_apply(io, wk, B, st, blockIdx.x, threadIdx.x);
+}
+
+// Head of a refinement iteration: the Adam step that closes the PREVIOUS iteration (its gradients and losses are
+// still in place), then both skeletons of sample b from the updated parameters.  grid = B, block = 2 x 192
+// (threads [0,192) right hand, [192,384) left hand).  The whole sample lives in one workgroup because the left
+// hand's wrist shift reads the right hand's shape and the shared translation (optimize_model.py:196-206).
+__global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_opt_io io, OptWork wk, int B, AdamStep st) {
+    __shared__ float sk[2][SK_STRIDE];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (st.group >= 0 && tid < adam_group_size(st.group)) opt_adam_apply(io, wk, B, st, b, tid);
+    __syncthreads();   // the updated parameters are read back below by other threads of this workgroup
+    const int hl = tid / 192;
+    lbs_skel_hand<true>(m, io.orient, io.pose, io.shape, io.trans, B, wk.lbs.skel, wk.joints_raw, sk[hl], hl * B + b, tid % 192);
 }
 
 // utils/opt_utils.py:104-153: validity filter, 1e11 for invalid rows, row 0 restored, first argmin,
