@@ -219,6 +219,8 @@ __global__ __launch_bounds__(192) void lbs_skel_kernel(ihmr_mano m, const float*
     lbs_skel_hand<TWO_HAND>(m, orient, pose, betas, trans, B, skel, joints, sk, blockIdx.x, threadIdx.x);
 }
 
+typedef float lbs_v2f __attribute__((ext_vector_type(2)));
+
 // hand i of group (x, s): x + 8 * (8 s + i) -- all hands of a group share (hand % 8), i.e. the XCD that ran
 // their skeleton workgroup and will run their collision / backward workgroups (speed only).
 __device__ __forceinline__ int lbs_group_hand(int x, int s, int i) { return x + 8 * (8 * s + i); }
@@ -257,48 +259,77 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
     const int v = tile * LBS_TILE_V + tid;
     if (tid >= LBS_TILE_V || v >= NV) return;
 
-    // shape blend: v_shaped = v_template + shapedirs . beta   (8 hands at once)
-    float vp[LBS_HG][3];
+    // shape blend: v_shaped = v_template + shapedirs . beta   (8 hands at once, as 4 hand PAIRS: packed fp32 FMAs
+    // do two hands per instruction and give the same IEEE results as scalar ones)
+    lbs_v2f vq[LBS_HG / 2][3];
     {
         const float4 t = m.vt4[v];
         float4 sd[10];
 #pragma unroll
         for (int l = 0; l < 10; ++l) sd[l] = m.sd4[l * NVP + v];
 #pragma unroll
-        for (int hh = 0; hh < LBS_HG; ++hh) { vp[hh][0] = t.x; vp[hh][1] = t.y; vp[hh][2] = t.z; }
+        for (int q = 0; q < LBS_HG / 2; ++q) { vq[q][0] = lbs_v2f{t.x, t.x}; vq[q][1] = lbs_v2f{t.y, t.y}; vq[q][2] = lbs_v2f{t.z, t.z}; }
 #pragma unroll
         for (int l = 0; l < 10; ++l) {
 #pragma unroll
-            for (int hh = 0; hh < LBS_HG; ++hh) {
-                const float bl = beta_s[l][hh];
-                vp[hh][0] = __builtin_fmaf(sd[l].x, bl, vp[hh][0]);
-                vp[hh][1] = __builtin_fmaf(sd[l].y, bl, vp[hh][1]);
-                vp[hh][2] = __builtin_fmaf(sd[l].z, bl, vp[hh][2]);
+            for (int q = 0; q < LBS_HG / 2; ++q) {
+                const lbs_v2f bl = *reinterpret_cast<const lbs_v2f*>(&beta_s[l][2 * q]);
+                vq[q][0] = __builtin_elementwise_fma(lbs_v2f{sd[l].x, sd[l].x}, bl, vq[q][0]);
+                vq[q][1] = __builtin_elementwise_fma(lbs_v2f{sd[l].y, sd[l].y}, bl, vq[q][1]);
+                vq[q][2] = __builtin_elementwise_fma(lbs_v2f{sd[l].z, sd[l].z}, bl, vq[q][2]);
             }
         }
     }
     TSTAMP(2);
-    // pose blend: v_posed = v_shaped + pose_feature . posedirs.  The basis rows are fetched 9 at a time
-    // (explicit register batch + scheduling barrier: left alone, hipcc issues one load per use and waits
-    // vmcnt(0) on each -- measured 37 us of exposed latency for this loop).
-#pragma unroll 1
-    for (int e0 = 0; e0 < NPF; e0 += 9) {
-        float4 p[9];
+    // pose blend: v_posed = v_shaped + pose_feature . posedirs.  The basis rows are fetched 9 at a time into two
+    // register batches, the next batch in flight while the current one is consumed (explicit batches +
+    // scheduling barriers: left alone, hipcc issues one load per use and waits vmcnt(0) on each).
+    {
+        // a basis row is fetched as two aligned float pairs (x,y) (z,pad): packed FMAs take their broadcast operand
+        // straight from either half of such a pair, no register shuffling between the load and its use
+        struct Row { lbs_v2f xy, zw; };
+        Row pa[9], pb[9];
+        auto fetch = [&](Row* p, int e0) {
 #pragma unroll
-        for (int u = 0; u < 9; ++u) p[u] = m.pd4[(e0 + u) * NVP + v];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            const float4 f0 = pfT[e0 + u][0], f1 = pfT[e0 + u][1];
-            const float f[LBS_HG] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-#pragma unroll
-            for (int hh = 0; hh < LBS_HG; ++hh) {
-                vp[hh][0] = __builtin_fmaf(f[hh], p[u].x, vp[hh][0]);
-                vp[hh][1] = __builtin_fmaf(f[hh], p[u].y, vp[hh][1]);
-                vp[hh][2] = __builtin_fmaf(f[hh], p[u].z, vp[hh][2]);
+            for (int u = 0; u < 9; ++u) {
+                const lbs_v2f* src = reinterpret_cast<const lbs_v2f*>(&m.pd4[(e0 + u) * NVP + v]);
+                p[u].xy = src[0];
+                p[u].zw = src[1];
             }
+        };
+        auto consume = [&](const Row* p, int e0) {
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                const float4 f0 = pfT[e0 + u][0], f1 = pfT[e0 + u][1];
+                const lbs_v2f f[LBS_HG / 2] = {lbs_v2f{f0.x, f0.y}, lbs_v2f{f0.z, f0.w}, lbs_v2f{f1.x, f1.y}, lbs_v2f{f1.z, f1.w}};
+#pragma unroll
+                for (int q = 0; q < LBS_HG / 2; ++q) {
+                    vq[q][0] = __builtin_elementwise_fma(f[q], __builtin_shufflevector(p[u].xy, p[u].xy, 0, 0), vq[q][0]);
+                    vq[q][1] = __builtin_elementwise_fma(f[q], __builtin_shufflevector(p[u].xy, p[u].xy, 1, 1), vq[q][1]);
+                    vq[q][2] = __builtin_elementwise_fma(f[q], __builtin_shufflevector(p[u].zw, p[u].zw, 0, 0), vq[q][2]);
+                }
+            }
+        };
+        static_assert(NPF % 9 == 0 && (NPF / 9) % 2 == 1, "15 batches of 9: 7 double steps + 1");
+        fetch(pa, 0);
+#pragma unroll 1
+        for (int e0 = 0; e0 + 9 < NPF; e0 += 18) {
+            fetch(pb, e0 + 9);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(pa, e0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(pa, e0 + 18);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(pb, e0 + 9);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        consume(pa, NPF - 9);
     }
+    float vp[LBS_HG][3];
+#pragma unroll
+    for (int q = 0; q < LBS_HG / 2; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { vp[2 * q][c] = vq[q][c].x; vp[2 * q + 1][c] = vq[q][c].y; }
     TSTAMP(3);
     float w[NJ];
     {
