@@ -232,7 +232,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
                                                                float* __restrict__ verts, float* __restrict__ joints,
                                                                float* __restrict__ v_posed_ws) {
     __shared__ float4 pfT[136][2];        // [e][hands 0-3 | 4-7]
-    __shared__ float A_s[LBS_HG][192];
+    __shared__ float A_s[LBS_HG / 2][192][2];   // skinning matrices, the two hands of a pair interleaved
     __shared__ float beta_s[10][LBS_HG];  // [l][hand]
     __shared__ float shift_s[LBS_HG][4];
     const int tid = threadIdx.x, gx = blockIdx.x, tile = blockIdx.y % 4, gs = blockIdx.y / 4;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
     }
     for (int idx = tid; idx < LBS_HG * 192; idx += LBS_THREADS) {
         const int hh = idx / 192, e = idx % 192, hid = lbs_group_hand(gx, gs, hh);
-        A_s[hh][e] = hid < N ? skel[(size_t)hid * SK_STRIDE + SK_A + e] : 0.f;
+        A_s[hh / 2][e][hh % 2] = hid < N ? skel[(size_t)hid * SK_STRIDE + SK_A + e] : 0.f;
     }
     if (tid < LBS_HG * 10) {
         const int hh = tid / 10, l = tid % 10, hid = lbs_group_hand(gx, gs, hh);
@@ -325,11 +325,6 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
         }
         consume(pa, NPF - 9);
     }
-    float vp[LBS_HG][3];
-#pragma unroll
-    for (int q = 0; q < LBS_HG / 2; ++q)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { vp[2 * q][c] = vq[q][c].x; vp[2 * q + 1][c] = vq[q][c].y; }
     TSTAMP(3);
     float w[NJ];
     {
@@ -343,40 +338,47 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
         for (int t = 0; t < IHMR_NUM_TIPS; ++t)
             if (v == m.tip_ids[t]) tip = t;
     }
+    // skinning, one hand pair at a time: T = sum_j w_j A_j over all 16 joints without branches (a zero weight adds an
+    // exact zero), the pair's matrices read from LDS as broadcast 16-byte rows, packed FMAs
 #pragma unroll
-    for (int hh = 0; hh < LBS_HG; ++hh) {
-        const int h = lbs_group_hand(gx, gs, hh);
-        if (h >= N) continue;
-        const float vp0 = vp[hh][0], vp1 = vp[hh][1], vp2 = vp[hh][2];
-        float T[12];
+    for (int q = 0; q < LBS_HG / 2; ++q) {
+        lbs_v2f T[12];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int e = 0; e < 12; ++e) T[e] = lbs_v2f{0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const float wj = w[j];
-            if (wj != 0.f) {
-                const float* A = &A_s[hh][12 * j];
+            const lbs_v2f wj = {w[j], w[j]};
+            const float4* A4 = reinterpret_cast<const float4*>(&A_s[q][12 * j][0]);   // {A[e] h0, A[e] h1, A[e+1] h0, A[e+1] h1}
 #pragma unroll
-                for (int e = 0; e < 12; ++e) T[e] = __builtin_fmaf(wj, A[e], T[e]);
+            for (int e2 = 0; e2 < 6; ++e2) {
+                const float4 a = A4[e2];
+                T[2 * e2] = __builtin_elementwise_fma(wj, lbs_v2f{a.x, a.y}, T[2 * e2]);
+                T[2 * e2 + 1] = __builtin_elementwise_fma(wj, lbs_v2f{a.z, a.w}, T[2 * e2 + 1]);
             }
         }
-        float out[3];
+        lbs_v2f o2[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) out[r] = T[4 * r + 0] * vp0 + T[4 * r + 1] * vp1 + T[4 * r + 2] * vp2 + T[4 * r + 3];
-        float* ws = v_posed_ws + ((size_t)h * NV + v) * 3;
-        ws[0] = vp0; ws[1] = vp1; ws[2] = vp2;
-        const bool left = TWO_HAND && h >= B;
-        if (left) {  // optimize_model.py:210-211, 222-228
-            out[0] = -out[0] + shift_s[hh][0];
-            out[1] = out[1] + shift_s[hh][1];
-            out[2] = out[2] + shift_s[hh][2];
-        }
-        float* dst = verts + ((size_t)h * NV + v) * 3;
-        dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2];
-        if (TWO_HAND && tip >= 0) {  // fingertip joints are vertices (:201-202)
-            const int b = left ? h - B : h;
-            float* jd = joints + ((size_t)b * 42 + (left ? 21 : 0) + NJ + tip) * 3;
-            jd[0] = out[0]; jd[1] = out[1]; jd[2] = out[2];
+        for (int r = 0; r < 3; ++r) o2[r] = T[4 * r + 0] * vq[q][0] + T[4 * r + 1] * vq[q][1] + T[4 * r + 2] * vq[q][2] + T[4 * r + 3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hh = 2 * q + i, h = lbs_group_hand(gx, gs, hh);
+            if (h >= N) continue;
+            float out[3] = {i ? o2[0].y : o2[0].x, i ? o2[1].y : o2[1].x, i ? o2[2].y : o2[2].x};
+            float* ws = v_posed_ws + ((size_t)h * NV + v) * 3;
+            ws[0] = i ? vq[q][0].y : vq[q][0].x; ws[1] = i ? vq[q][1].y : vq[q][1].x; ws[2] = i ? vq[q][2].y : vq[q][2].x;
+            const bool left = TWO_HAND && h >= B;
+            if (left) {  // optimize_model.py:210-211, 222-228
+                out[0] = -out[0] + shift_s[hh][0];
+                out[1] = out[1] + shift_s[hh][1];
+                out[2] = out[2] + shift_s[hh][2];
+            }
+            float* dst = verts + ((size_t)h * NV + v) * 3;
+            dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2];
+            if (TWO_HAND && tip >= 0) {  // fingertip joints are vertices (:201-202)
+                const int b = left ? h - B : h;
+                float* jd = joints + ((size_t)b * 42 + (left ? 21 : 0) + NJ + tip) * 3;
+                jd[0] = out[0]; jd[1] = out[1]; jd[2] = out[2];
+            }
         }
     }
     TSTAMP(4);
