@@ -388,7 +388,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
 // One workgroup per hand.  Inputs are gradients w.r.t. the forward OUTPUTS (final verts / joints).
 // need_mask: bit0 orient, bit1 pose, bit2 betas, bit3 trans.
 struct LbsBwdShared {
-    float sk[SK_STRIDE];
+    __attribute__((aligned(16))) float sk[SK_STRIDE];
     float g[NV3];         // d L / d verts (raw hand frame)
     float vp[NV3];        // v_posed (saved by the forward)
     float dvp[NV3];       // d L / d v_posed
@@ -401,27 +401,9 @@ struct LbsBwdShared {
     float gj[21][3];      // joint gradients (raw hand frame)
     float red[LBS_THREADS];
     float part[LBS_SEG_CAP][12];  // per-segment partial sums of dA
+    int par[NJ], dep[NJ];         // kinematic tree (parents, depth), staged once: the chain loops read them many times
+    float wsum[LBS_THREADS / WAVE][4];
 };
-
-__device__ __forceinline__ void lbs_blend_lds(const ihmr_mano& m, const float* sA, int v, float* T) {
-#pragma unroll
-    for (int e = 0; e < 12; ++e) T[e] = 0.f;
-    const float4* w4 = reinterpret_cast<const float4*>(m.weights + v * NJ);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 w = w4[q];
-        const float ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float wj = ws[i];
-            if (wj != 0.f) {
-                const float* A = sA + 12 * (4 * q + i);
-#pragma unroll
-                for (int e = 0; e < 12; ++e) T[e] = __builtin_fmaf(wj, A[e], T[e]);
-            }
-        }
-    }
-}
 
 template <bool TWO_HAND>
 __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsWork wk, int B,
@@ -436,33 +418,78 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
     const bool need_orient = need_mask & 1, need_pose = need_mask & 2, need_betas = need_mask & 4, need_trans = need_mask & 8;
 
     TSTAMP(10);
+    // constants this workgroup reads later, requested first so their latency hides behind the phases in between:
+    // the skinning weights of this thread's (up to 4) vertices and the kinematic tree
+    constexpr int VR = (NV + LBS_THREADS - 1) / LBS_THREADS;
+    float4 wreg[VR][4];
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+        const int v = min(tid + r * LBS_THREADS, NV - 1);
+        const float4* w4 = reinterpret_cast<const float4*>(m.weights + v * NJ);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wreg[r][q] = w4[q];
+    }
+    if (tid < NJ) { bw.par[tid] = m.parents[tid]; bw.dep[tid] = m.depth[tid]; }
     // ---- TWO_HAND: d L / d shift = sum over the LEFT hand's vertex and joint gradients of this sample
     if (TWO_HAND) {
         const float* gl = d_verts + ((size_t)(B + b) * NV) * 3;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int v = tid; v < NV; v += LBS_THREADS) { s0 += gl[3 * v]; s1 += gl[3 * v + 1]; s2 += gl[3 * v + 2]; }
+        float gl0[VR][3];
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            const int v = tid + r * LBS_THREADS;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gl0[r][k] = v < NV ? gl[3 * v + k] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < VR; ++r) { s0 += gl0[r][0]; s1 += gl0[r][1]; s2 += gl0[r][2]; }
         if (tid < 21) {
             const float* gj = d_joints + ((size_t)b * 42 + 21 + tid) * 3;
             s0 += gj[0]; s1 += gj[1]; s2 += gj[2];
         }
-        s0 = block_reduce_sum(s0, bw.red);
-        s1 = block_reduce_sum(s1, bw.red);
-        s2 = block_reduce_sum(s2, bw.red);
-        if (tid == 0) { bw.gsum[0] = s0; bw.gsum[1] = s1; bw.gsum[2] = s2; }
-        if (left && need_trans && tid < 3) d_trans[b * 3 + tid] = tid == 0 ? s0 : (tid == 1 ? s1 : s2);
+        // fixed-order block sum: DPP inside each wave, then the 4 wave totals in index order
+        s0 = wave_reduce_sum_dpp(s0); s1 = wave_reduce_sum_dpp(s1); s2 = wave_reduce_sum_dpp(s2);
+        if (tid % WAVE == 0) { bw.wsum[tid / WAVE][0] = s0; bw.wsum[tid / WAVE][1] = s1; bw.wsum[tid / WAVE][2] = s2; }
         __syncthreads();
+        if (tid < 3) {
+            float t = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < LBS_THREADS / WAVE; ++wv) t += bw.wsum[wv][tid];
+            bw.gsum[tid] = t;
+            if (left && need_trans) d_trans[b * 3 + tid] = t;
+        }
         if ((need_mask & 7) == 0) return;  // stage 0: only the translation moves
     }
 
     TSTAMP(11);
-    // ---- skeleton record of this iteration's forward, output gradients into the raw hand frame
-    for (int i = tid; i < SK_STRIDE; i += LBS_THREADS) bw.sk[i] = wk.skel[(size_t)h * SK_STRIDE + i];
-
-    for (int i = tid; i < NV3; i += LBS_THREADS) {
-        float gv = d_verts[(size_t)h * NV3 + i];
-        if (left && (i % 3) == 0) gv = -gv;
-        bw.g[i] = gv;
-        bw.vp[i] = wk.v_posed[(size_t)h * NV3 + i];
+    // ---- skeleton record of this iteration's forward, output gradients into the raw hand frame (all loads issued
+    //      before the first LDS store)
+    {
+        constexpr int NR = (NV3 + LBS_THREADS - 1) / LBS_THREADS, SR = (SK_STRIDE + LBS_THREADS - 1) / LBS_THREADS;
+        float rg[NR], rv[NR], rs[SR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = min(tid + r * LBS_THREADS, NV3 - 1);
+            rg[r] = d_verts[(size_t)h * NV3 + i];
+            rv[r] = wk.v_posed[(size_t)h * NV3 + i];
+        }
+#pragma unroll
+        for (int r = 0; r < SR; ++r) rs[r] = wk.skel[(size_t)h * SK_STRIDE + min(tid + r * LBS_THREADS, SK_STRIDE - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = tid + r * LBS_THREADS;
+            if (i < NV3) {
+                bw.g[i] = (left && (i % 3) == 0) ? -rg[r] : rg[r];
+                bw.vp[i] = rv[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            const int i = tid + r * LBS_THREADS;
+            if (i < SK_STRIDE) bw.sk[i] = rs[r];
+        }
     }
     if (tid < 21 * 3) {
         const int j = tid / 3, k = tid % 3;
@@ -484,10 +511,28 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
     const float* sR = bw.sk + SK_R; const float* sJ = bw.sk + SK_J; const float* sG = bw.sk + SK_G; const float* sA = bw.sk + SK_A;
 
     TSTAMP(12);
-    // ---- per vertex: d v_posed = T.R^T g
-    for (int v = tid; v < NV; v += LBS_THREADS) {
+    // ---- per vertex: d v_posed = T.R^T g, T.R = sum_j w_j A_j.R over all 16 joints (no branches: a zero weight adds
+    //      an exact zero), the matrices read from LDS as broadcast rows
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+        const int v = tid + r * LBS_THREADS;
+        if (v >= NV) break;
+        const float w[NJ] = {wreg[r][0].x, wreg[r][0].y, wreg[r][0].z, wreg[r][0].w, wreg[r][1].x, wreg[r][1].y, wreg[r][1].z, wreg[r][1].w,
+                             wreg[r][2].x, wreg[r][2].y, wreg[r][2].z, wreg[r][2].w, wreg[r][3].x, wreg[r][3].y, wreg[r][3].z, wreg[r][3].w};
         float T[12];
-        lbs_blend_lds(m, sA, v, T);
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float4* A4 = reinterpret_cast<const float4*>(sA + 12 * j);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float4 a = A4[q];
+                T[4 * q] = __builtin_fmaf(w[j], a.x, T[4 * q]);
+                T[4 * q + 1] = __builtin_fmaf(w[j], a.y, T[4 * q + 1]);
+                T[4 * q + 2] = __builtin_fmaf(w[j], a.z, T[4 * q + 2]);
+            }
+        }
         const float g0 = bw.g[3 * v], g1 = bw.g[3 * v + 1], g2 = bw.g[3 * v + 2];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -563,8 +608,8 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
         // children at depth d: dR_j = Gp.R^T dG_j.R ; drel_j = Gp.R^T dG_j.t
         if (tid < NJ * 12) {
             const int j = tid / 12, e = tid % 12;
-            if (m.depth[j] == d) {
-                const float* Gp = sG + 12 * m.parents[j];
+            if (bw.dep[j] == d) {
+                const float* Gp = sG + 12 * bw.par[j];
                 const float* dGj = bw.dG[j];
                 if (e < 9) {
                     const int c = e / 3, c2 = e % 3;
@@ -581,7 +626,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
             const int p = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
             float acc = 0.f, accJ = 0.f;
             for (int j = p + 1; j < NJ; ++j) {
-                if (m.parents[j] != p || m.depth[j] != d) continue;
+                if (bw.par[j] != p || bw.dep[j] != d) continue;
                 const float* dGj = bw.dG[j];
                 if (c < 3) {
                     const float* Rj = sR + 9 * j;
@@ -597,7 +642,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
         }
         if (tid >= 192 && tid < 192 + NJ * 3) {
             const int j = (tid - 192) / 3, c = (tid - 192) % 3;
-            if (m.depth[j] == d) bw.dJ[j][c] += bw.drel[j][c];
+            if (bw.dep[j] == d) bw.dJ[j][c] += bw.drel[j][c];
         }
         __syncthreads();
     }
