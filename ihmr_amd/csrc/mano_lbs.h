@@ -402,6 +402,7 @@ struct LbsBwdShared {
     float red[LBS_THREADS];
     float part[LBS_SEG_CAP][12];  // per-segment partial sums of dA
     int par[NJ], dep[NJ];         // kinematic tree (parents, depth), staged once: the chain loops read them many times
+    int nchild[NJ], child[NJ][NJ];  // children of every joint in index order (built in-kernel from par)
     float wsum[LBS_THREADS / WAVE][4];
 };
 
@@ -509,6 +510,13 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
     }
     __syncthreads();
     const float* sR = bw.sk + SK_R; const float* sJ = bw.sk + SK_J; const float* sG = bw.sk + SK_G; const float* sA = bw.sk + SK_A;
+    if (tid >= LBS_THREADS - NJ) {   // last wave, off the critical path: child lists for the chain gathers (par[] is visible since the barriers above)
+        const int p = tid - (LBS_THREADS - NJ);
+        int n = 0;
+        for (int j = p + 1; j < NJ; ++j)
+            if (bw.par[j] == p) bw.child[p][n++] = j;
+        bw.nchild[p] = n;
+    }
 
     TSTAMP(12);
     // ---- per vertex: d v_posed = T.R^T g, T.R = sum_j w_j A_j.R over all 16 joints (no branches: a zero weight adds
@@ -625,8 +633,9 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
         if (tid < NJ * 12) {
             const int p = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
             float acc = 0.f, accJ = 0.f;
-            for (int j = p + 1; j < NJ; ++j) {
-                if (bw.par[j] != p || bw.dep[j] != d) continue;
+            const int nc = bw.dep[p] + 1 == d ? bw.nchild[p] : 0;   // a joint's children all sit one level below it
+            for (int q = 0; q < nc; ++q) {
+                const int j = bw.child[p][q];
                 const float* dGj = bw.dG[j];
                 if (c < 3) {
                     const float* Rj = sR + 9 * j;
