@@ -109,9 +109,6 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
     rc |= upload(&m->pose_mean, pm); rc |= upload(&m->parents, par); rc |= upload(&m->depth, depth);
     rc |= upload(&m->tip_ids, tips); rc |= upload(&m->wj_start, start); rc |= upload(&m->wj_vert, wv);
     rc |= upload(&m->wj_w, ww); rc |= upload(&m->seg_q, seg_q); rc |= upload(&m->jseg_start, jseg); rc |= upload(&m->faces, fsoa); rc |= upload(&m->J_regressor, jr);
-    // lbs_bwd2 keeps a 110 KB basis tile in the CU's 160 KB LDS: above the default dynamic-LDS cap
-    (void)hipFuncSetAttribute((const void*)lbs_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((NPF * (LBS_CHUNK + 1) + LBS_HG * LBS_CHUNK) * sizeof(float)));
     m->max_depth = maxd;
     m->nnz = (int)wv.size();
     m->nseg = (int)seg_q.size() - 1;
@@ -172,8 +169,7 @@ static void lbs_backward_launch(const ihmr_mano* m, bool two_hand, int N, int B,
         hipLaunchKernelGGL(lbs_bwd1_kernel<false>, dim3(N), dim3(LBS_THREADS), 0, st, *m, wk, B, d_verts, d_joints, d_orient,
                            d_betas, d_trans, need_mask);
     if (need_mask & 2) {
-        const size_t lds = (size_t)(NPF * (LBS_CHUNK + 1) + LBS_HG * LBS_CHUNK) * sizeof(float);
-        hipLaunchKernelGGL(lbs_bwd2_kernel, dim3(8, LBS_NCHUNK * ((N + 63) / 64)), dim3(LBS_THREADS), lds, st, *m, wk, N);
+        hipLaunchKernelGGL(lbs_bwd2_kernel, dim3(5, (N + 31) / 32, LBS_KG), dim3(64), 0, st, *m, wk, N);
         if (two_hand) hipLaunchKernelGGL(lbs_bwd3_kernel<true>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
         else hipLaunchKernelGGL(lbs_bwd3_kernel<false>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
     }

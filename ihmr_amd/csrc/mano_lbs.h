@@ -24,8 +24,8 @@
 #define LBS_THREADS 256
 #define LBS_HG 8          // hands per skin / bwd2 workgroup
 #define LBS_TILE_V 195    // vertices per skin workgroup (4 x 195 = 780 >= 778)
-#define LBS_NCHUNK 13     // 13 x 192 = 2496 >= 2334 basis columns
-#define LBS_CHUNK 192
+#define LBS_KG 25         // bwd2: K groups (split-K partial sums, reduced in fixed order by bwd3)
+#define LBS_KC 3          // bwd2: 32-column chunks per K group: 25 x 3 x 32 = 2400 >= 2334 basis columns
 #define LBS_SEG 13         // CSR entries per dA segment
 #define LBS_SEG_CAP 1024   // >= 778*16/13 + 16: every weight matrix fits
 #define LBS_CSR_CAP 4096   // non-zero skinning weights staged in LDS by bwd1 (MANO-like: <= 4-5 per vertex); else read from L2
@@ -46,11 +46,11 @@ struct LbsWork {       // carved from the caller's workspace
     float* v_posed;    // [N][2334]
     float* dvp;        // [N][2334]
     float* chain;      // [N][192]: dR [16][9] from the chain, dJ [16][3]
-    float* dpf_part;   // [LBS_NCHUNK][N][136]
+    float* dpf_part;   // [LBS_KG][N][136]
 };
 
 static inline size_t lbs_ws_bytes(int N) {
-    size_t n = (size_t)N * (SK_STRIDE + 2 * NV3 + 192 + LBS_NCHUNK * 136) * sizeof(float);
+    size_t n = (size_t)N * (SK_STRIDE + 2 * NV3 + 192 + LBS_KG * 136) * sizeof(float);
     return ((n + 255) & ~(size_t)255) + 5 * 256;
 }
 
@@ -62,7 +62,7 @@ static inline LbsWork lbs_carve(void* ws, int N) {
     w.v_posed = take((size_t)N * NV3 * 4);
     w.dvp = take((size_t)N * NV3 * 4);
     w.chain = take((size_t)N * 192 * 4);
-    w.dpf_part = take((size_t)LBS_NCHUNK * N * 136 * 4);
+    w.dpf_part = take((size_t)LBS_KG * N * 136 * 4);
     return w;
 }
 
@@ -134,6 +134,7 @@ __device__ __forceinline__ void lbs_skel_hand(const ihmr_mano& m, const float* _
                                               float* __restrict__ joints, float* sk, int h, int tid) {
     const bool left = TWO_HAND && h >= B;
     float* sR = sk + SK_R; float* sJ = sk + SK_J; float* sG = sk + SK_G; float* sA = sk + SK_A;
+    const int my_depth = m.depth[tid / 12], my_parent = m.parents[tid / 12];   // kinematic tree: read once, up front
     float* sPF = sk + SK_PF; float* sPose = sk + SK_POSE; float* sBeta = sk + SK_BETA; float* sShift = sk + SK_SHIFT;
     if (tid < 48) {
         float v = tid < 3 ? orient[h * 3 + tid] : pose[h * 45 + tid - 3];
@@ -175,8 +176,8 @@ __device__ __forceinline__ void lbs_skel_hand(const ihmr_mano& m, const float* _
     // kinematic chain, level by level (MANO: depth <= 3); 12 lanes per joint
     for (int d = 1; d <= m.max_depth; ++d) {
         const int j = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
-        if (m.depth[j] == d) {
-            const int p = m.parents[j];
+        if (my_depth == d) {
+            const int p = my_parent;
             const float* Gp = sG + 12 * p;
             float acc;
             if (c < 3) {
@@ -706,52 +707,91 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
 }
 
 // ------------------------------------------------------------------------------------- backward 2
-// d pose_feature partials: part[c][hand][e] = sum_{i in chunk c} posedirs[e][i] * dvp[hand][i]
-// grid = (8, 13 column chunks x ceil(N/64) groups), block = 256; the 135 x 192 basis tile sits in LDS.
-__global__ __launch_bounds__(LBS_THREADS) void lbs_bwd2_kernel(ihmr_mano m, LbsWork wk, int N) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* pdt = smem;                       // [135][193]
-    float* dv = smem + NPF * (LBS_CHUNK + 1);  // [8][192]
-    const int tid = threadIdx.x, gx = blockIdx.x, c = blockIdx.y % LBS_NCHUNK, gs = blockIdx.y / LBS_NCHUNK, i0 = c * LBS_CHUNK;
-    for (int idx = tid; idx < NPF * LBS_CHUNK; idx += LBS_THREADS) {
-        const int e = idx / LBS_CHUNK, i = idx % LBS_CHUNK;
-        pdt[e * (LBS_CHUNK + 1) + i] = (i0 + i < NV3) ? m.posedirs[(size_t)e * NV3 + i0 + i] : 0.f;
+// d pose_feature = posedirs (135 x 2334) . d v_posed^T (2334 x N): a GEMM, on the matrix cores.
+// v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate = a k-ordered fmaf chain): M = pose features (5 tiles of 32),
+// N = hands (tiles of 32), K = vertex coordinates, split into LBS_KG groups of LBS_KC 32-column chunks whose
+// partial sums part[kg][hand][e] are added in index order by bwd3 (bit-reproducible, no atomics).
+// grid = (5, ceil(N/32), LBS_KG), block = one wave.  Lane l feeds row/column l % 32; the K index of a chunk is
+// permuted so that lane half l / 32 owns 16 CONSECUTIVE columns (k = k0 + 16 (l/32) + s at MFMA step s): every
+// lane then streams 64 contiguous bytes of its basis row / its hand's gradient row, no LDS staging.
+typedef float lbs_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(64) void lbs_bwd2_kernel(ihmr_mano m, LbsWork wk, int N) {
+    const int lane = threadIdx.x, l31 = lane & 31, kp = lane >> 5;
+    const int e = blockIdx.x * 32 + l31, hand = blockIdx.y * 32 + l31, kg = blockIdx.z;
+    const float* arow = m.posedirs + (size_t)min(e, NPF - 1) * NV3;
+    const float* brow = wk.dvp + (size_t)min(hand, N - 1) * NV3;
+    const bool a_ok = e < NPF, b_ok = hand < N;
+    lbs_v2f av[LBS_KC][8], bv[LBS_KC][8];
+#pragma unroll
+    for (int c = 0; c < LBS_KC; ++c) {
+        const int k0 = (kg * LBS_KC + c) * 32 + 16 * kp;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = min(k0 + 2 * q, NV3 - 2);          // NV3 is even: a float pair never straddles the end
+            av[c][q] = *reinterpret_cast<const lbs_v2f*>(arow + k);
+            bv[c][q] = *reinterpret_cast<const lbs_v2f*>(brow + k);
+        }
     }
-    for (int idx = tid; idx < LBS_HG * LBS_CHUNK; idx += LBS_THREADS) {
-        const int hh = idx / LBS_CHUNK, i = idx % LBS_CHUNK, hid = lbs_group_hand(gx, gs, hh);
-        dv[idx] = (hid < N && i0 + i < NV3) ? wk.dvp[(size_t)hid * NV3 + i0 + i] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    lbs_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < LBS_KC; ++c) {
+        const int k0 = (kg * LBS_KC + c) * 32 + 16 * kp;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool k_ok = k0 + 2 * q < NV3;
+            const float a0 = (a_ok && k_ok) ? av[c][q].x : 0.f, a1 = (a_ok && k_ok) ? av[c][q].y : 0.f;
+            const float b0 = (b_ok && k_ok) ? bv[c][q].x : 0.f, b1 = (b_ok && k_ok) ? bv[c][q].y : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+        }
     }
-    __syncthreads();
-    for (int p = tid; p < LBS_HG * NPF; p += LBS_THREADS) {
-        const int hh = p / NPF, e = p % NPF, hid = lbs_group_hand(gx, gs, hh);
-        if (hid >= N) continue;
-        const float* row = pdt + e * (LBS_CHUNK + 1);
-        const float* d = dv + hh * LBS_CHUNK;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < LBS_CHUNK; ++i) acc = __builtin_fmaf(row[i], d[i], acc);
-        wk.dpf_part[((size_t)c * N + hid) * 136 + e] = acc;
+    // C/D layout: column (hand) = lane & 31, row (feature) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    if (b_ok) {
+        float* dst = wk.dpf_part + ((size_t)kg * N + hand) * 136 + blockIdx.x * 32 + 4 * kp;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int e4 = blockIdx.x * 32 + 4 * kp + 8 * r4;
+            if (e4 + 3 < 136) *reinterpret_cast<float4*>(dst + 8 * r4) = make_float4(acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------- backward 3
-// finger-pose gradients: dR_j = chain part + pose-feature part (chunk sums in fixed order), through Rodrigues.
-// grid = N, block = 64 (lanes 1..15 = joints).
+// finger-pose gradients: dR_j = chain part + pose-feature part (K-group sums in fixed order), through Rodrigues.
+// grid = N, block = 64: the wave first reduces the LBS_KG partial rows (coalesced, all loads in flight at once),
+// then lanes 1..15 = joints.
 template <bool TWO_HAND>
 __global__ __launch_bounds__(64) void lbs_bwd3_kernel(LbsWork wk, int N, int B, float* __restrict__ d_pose) {
+    __shared__ float dpf[192];
     const int h = blockIdx.x, j = threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int e = j + 64 * t;
+        if (e >= 136) break;
+        float part[LBS_KG];
+#pragma unroll
+        for (int c = 0; c < LBS_KG; ++c) part[c] = wk.dpf_part[((size_t)c * N + h) * 136 + e];
+        __builtin_amdgcn_sched_barrier(0);
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < LBS_KG; ++c) acc += part[c];
+        dpf[e] = acc;
+    }
+    float r[3] = {0.f, 0.f, 0.f}, chain[9];
+    const int jj = min(max(j, 1), NJ - 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = wk.skel[(size_t)h * SK_STRIDE + SK_POSE + 3 * jj + k];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) chain[e] = wk.chain[(size_t)h * 192 + 9 * jj + e];
+    __syncthreads();
     if (j < 1 || j >= NJ) return;
     const bool left = TWO_HAND && h >= B;
-    float dR[9];
+    float dR[9], dr[3];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) {
-        float acc = 0.f;
-        for (int c = 0; c < LBS_NCHUNK; ++c) acc += wk.dpf_part[((size_t)c * N + h) * 136 + (j - 1) * 9 + e];
-        dR[e] = wk.chain[(size_t)h * 192 + 9 * j + e] + acc;
-    }
-    float r[3], dr[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) r[k] = wk.skel[(size_t)h * SK_STRIDE + SK_POSE + 3 * j + k];
+    for (int e = 0; e < 9; ++e) dR[e] = chain[e] + dpf[(j - 1) * 9 + e];
     rodrigues_bwd(r, dR, dr);
     if (left) { dr[1] = -dr[1]; dr[2] = -dr[2]; }
     float* dst = d_pose + (size_t)h * 45 + 3 * (j - 1);
