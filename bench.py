@@ -88,11 +88,14 @@ def pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--epoch", type=int, default=49, help="opt_default epoch per stage (49 -> 200 iterations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse", type=int, default=2,
+                    help="batches of --batch samples carried by ONE launch sequence (opt.fuse_batches; per-sample arithmetic "
+                         "identical to separate batches); batches in flight = streams x fuse")
     ap.add_argument("--streams", type=int, default=4,
                     help="independent batches in flight per GPU (each step is still one full pass over one batch of --batch samples)")
     args = ap.parse_args()
@@ -116,38 +119,53 @@ def main():
     from ihmr_amd.synthetic import synthetic_opt_batch
 
     B, freq = args.batch, 10
-    S = max(1, args.streams)
-    # one model instance (own buffers / workspace) and one HIP stream per batch in flight: the kernels of a
-    # 64-sample batch are latency-bound and fill at most half of the 256 CUs, so independent batches overlap
-    models = [OptimizeModel(make_opt(B, args.epoch, freq, rank if world > 1 else -1)) for _ in range(S)]
+    S, G = max(1, args.streams), max(1, args.fuse)
+    # Batches in flight = S x G.  The kernels of one 64-sample batch are latency-bound and fill at most half of the
+    # 256 CUs, so independent batches are overlapped two ways: S HIP streams (one model instance each; the hardware
+    # runs four compute queues side by side, more streams than that lose) and G batches carried by one launch
+    # sequence (opt.fuse_batches: per-sample arithmetic identical to separate batches, tests/test_gpu_parity.py).
+    def make_model(fuse):
+        o = make_opt(B, args.epoch, freq, rank if world > 1 else -1)
+        o.fuse_batches = fuse
+        return OptimizeModel(o)
+
+    fused = [make_model(G) for _ in range(S)]
+    singles = fused if G == 1 else []          # G > 1: built on demand for a remainder of fewer than G batches
     streams = [torch.cuda.Stream() for _ in range(S)]
-    model = models[0]
+    model = fused[0] if G == 1 else make_model(1)   # single-batch instance: remainder runs, roofline timing, work counters
     fwd = lambda p, s, t: two_hand.forward_from_packed(model.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
     batch_cpu = synthetic_opt_batch(B, fwd, seed=1234 + rank, first_index=rank * B)
     batch = {k: v.cuda() for k, v in batch_cpu.items()}   # resident in HBM before timing
+    batch_g = batch if G == 1 else {k: torch.cat([v] * G, dim=0) for k, v in batch.items()}
     torch.cuda.synchronize()
 
     def run_steps(n):
-        """n full passes (set_input -> init_optimize -> optimize -> get_pred_result), up to S in flight."""
+        """n full passes over one batch each (set_input -> init_optimize -> optimize -> get_pred_result), up to S x G in flight."""
         res = None
-        done = 0
-        while done < n:
-            g = min(S, n - done)
-            for i in range(g):
-                with torch.cuda.stream(streams[i]):
-                    models[i].set_input(batch)
-                    models[i].init_optimize()
+        left = n
+        while left > 0:
+            jobs = []                              # (model, stream, input)
+            for i in range(S):
+                if left >= G:
+                    jobs.append((fused[i], streams[i], batch_g)); left -= G
+                elif left > 0:
+                    while len(singles) <= i:
+                        singles.append(model if len(singles) == 0 and G > 1 else make_model(1))
+                    jobs.append((singles[i], streams[i], batch)); left -= 1
+            for mdl, st, inp in jobs:
+                with torch.cuda.stream(st):
+                    mdl.set_input(inp)
+                    mdl.init_optimize()
             for stage in model.strategy:          # interleave the stages so the host keeps every stream fed
-                for i in range(g):
-                    with torch.cuda.stream(streams[i]):
-                        models[i].run_stage(stage)
-            for i in range(g):
-                with torch.cuda.stream(streams[i]):
-                    models[i].forward_losses(models[i].default_loss_weights)
-            for i in range(g):
-                with torch.cuda.stream(streams[i]):
-                    res = models[i].get_pred_result()   # device -> host copies, as the reference's loop does
-            done += g
+                for mdl, st, _ in jobs:
+                    with torch.cuda.stream(st):
+                        mdl.run_stage(stage)
+            for mdl, st, _ in jobs:
+                with torch.cuda.stream(st):
+                    mdl.forward_losses(mdl.default_loss_weights)
+            for mdl, st, _ in jobs:
+                with torch.cuda.stream(st):
+                    res = mdl.get_pred_result()   # device -> host copies, as the reference's loop does
         return res
 
     def step():
@@ -226,7 +244,8 @@ def main():
             dtype="f32", data="synthetic",
             config=dict(workload=f"IHMR-OPT opt_default epoch={args.epoch} ({n_iters} refine iterations + final forward), "
                                  f"save_mid_freq={freq}, batch {B}/GPU, synthetic MANO-shaped asset seed 0",
-                        global_batch=world * B, refine_iters=n_iters, batches_in_flight_per_gpu=S,
+                        global_batch=world * B, refine_iters=n_iters, batches_in_flight_per_gpu=S * G, launch_streams=S,
+                        batches_per_launch_sequence=G,
                         parallelism=f"dp{world} (independent samples, no collective)"),
             roofline=roofline, cpu_baseline=cpu,
             parity=dict(mean_penetration_depth_m=float(np.mean(res["collision_loss_origin_scale"]))),

@@ -197,8 +197,8 @@ static int g_collect_stats = 0;
 
 static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const int32_t* faces_l_soa, int B, SdfWorkspace ws,
                       float robustifier, float* loss, float* per_vert, float* origin, float* dval, bool dense, hipStream_t st) {
-    // the inside-voxel counter is zero on entry (faces_to_soa_kernel / the sample kernel of the previous call /
-    // the memset at the head of a refinement stage); the prep kernel appends to it
+    // the inside-voxel counter is zero on entry (faces_to_soa_kernel on seam B, the skeleton kernel of the iteration
+    // on seam C); the prep kernel appends to it
     if (dense)
         hipLaunchKernelGGL(sdf_prep_kernel<true>, dim3(2 * B), dim3(SDF_PREP_THREADS), 0, st, vl, B, faces_r_soa, faces_l_soa, ws,
                            g_collect_stats);
@@ -271,7 +271,7 @@ extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
 // `prev` = the Adam step of the previous iteration (group < 0: none), applied at the head of the skeleton kernel
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
                        const ihmr_opt_weights& w, const AdamStep& prev, hipStream_t st) {
-    hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev);
+    hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B).inside_count);
     hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m, (const float*)wk.lbs.skel,
                        2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
@@ -283,19 +283,12 @@ static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
     return (int)hipGetLastError();
 }
 
-// the collision kernels expect the inside-voxel counter at zero; afterwards every sample kernel re-arms it
-static hipError_t opt_arm(const OptWork& wk, int B, hipStream_t st) {
-    SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
-    return hipMemsetAsync(ws.inside_count, 0, SDF_NXCD * sizeof(int), st);
-}
-
 extern "C" int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                                        const ihmr_opt_weights* w, void* stream) {
     if (!m || !io || !w || B <= 0) return -1;
     hipStream_t st = (hipStream_t)stream;
     OptWork wk = opt_carve(io->workspace, B);
-    HIP_TRY(opt_arm(wk, B, st));
-    int rc = opt_forward(m, m_left, io, wk, B, *w, AdamStep{-1, 0.f, 0.f, 1.f, -1}, st);
+    int rc = opt_forward(m, m_left, io, wk, B, *w, AdamStep{-1, 0.f, 0.f, 1.f, -1, 0}, st);
     if (rc) return rc;
     return (int)hipGetLastError();
 }
@@ -306,13 +299,10 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     if (!m || !io || !w || B <= 0 || group < 0 || group > 3 || n_iters <= 0 || save_freq <= 0) return -1;
     hipStream_t st = (hipStream_t)stream;
     OptWork wk = opt_carve(io->workspace, B);
-    HIP_TRY(hipMemsetAsync(io->adam_m, 0, (size_t)B * OPT_PMAX * 4, st));
-    HIP_TRY(hipMemsetAsync(io->adam_v, 0, (size_t)B * OPT_PMAX * 4, st));
-    HIP_TRY(opt_arm(wk, B, st));
     const int P = group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
     const int need_mask = group == IHMR_GROUP_TRANS ? 8 : (group == IHMR_GROUP_ORIENT ? 1 : (group == IHMR_GROUP_POSE ? 2 : 4));
     int S = 0;
-    AdamStep step{-1, 0.f, 0.f, 1.f, -1};
+    AdamStep step{-1, 0.f, 0.f, 1.f, -1, 1};   // iteration 0: no step yet, zero the Adam moments
     for (int it = 0; it < n_iters; ++it) {
         int rc = opt_forward(m, m_left, io, wk, B, *w, step, st);   // applies the step of iteration it - 1 first
         if (rc) return rc;
@@ -320,7 +310,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
                             wk.lbs, st);
         const double t = (double)(it + 1);
         const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
-        step = AdamStep{group, w->shape_reg, (float)((double)lr / bc1), (float)sqrt(bc2), (it % save_freq == 0) ? S++ : -1};
+        step = AdamStep{group, w->shape_reg, (float)((double)lr / bc1), (float)sqrt(bc2), (it % save_freq == 0) ? S++ : -1, 0};
     }
     hipLaunchKernelGGL(opt_adam_kernel, dim3(B), dim3(128), 0, st, *io, wk, B, step);
     hipLaunchKernelGGL(opt_select_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B, group, S, filter_factor_j3d,
@@ -402,8 +392,7 @@ extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, c
     ihmr_kernel_timer* keep = g_timer;
     g_timer = nullptr;
     g_collect_stats = 1;
-    HIP_TRY(opt_arm(wk, B, st));
-    int rc = opt_forward(m, m_left, io, wk, B, *w, AdamStep{-1, 0.f, 0.f, 1.f, -1}, st);
+    int rc = opt_forward(m, m_left, io, wk, B, *w, AdamStep{-1, 0.f, 0.f, 1.f, -1, 0}, st);
     g_collect_stats = 0;
     g_timer = keep;
     if (rc) return rc;

@@ -80,6 +80,7 @@ struct LossShared {
 __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWork& wk, int B, const ihmr_opt_weights& w,
                                               LossShared& sh, int b, int j) {
     const bool act = j < 42;
+    const int Bn = io.norm_batch > 0 ? io.norm_batch : B;   // the batch the reference's means run over
     const float* cam = io.cam + b * 3;
     const float cs = cam[0], ctx = cam[1], cty = cam[2];
     float r[3] = {0.f, 0.f, 0.f};
@@ -100,7 +101,7 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
         const float dx = t[0] - px, dy = t[1] - py;
         l2d_p = (fabsf(dx) + fabsf(dy)) * t[2];
         l2d_gt = (fabsf(tg[0] - px) + fabsf(tg[1] - py)) * tg[2];
-        const float s2 = w.joints_2d / (float)(B * 42 * 2);
+        const float s2 = w.joints_2d / (float)(Bn * 42 * 2);
         // d|t - p|/dp = -sign(t - p); dp/dX = cam scale
         const float sx = dx > 0.f ? -1.f : (dx < 0.f ? 1.f : 0.f), sy = dy > 0.f ? -1.f : (dy < 0.f ? 1.f : 0.f);
         g_raw[0] = s2 * sx * t[2] * cs;
@@ -121,7 +122,7 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
         const float* tg0 = io.gt_joints_3d + (b * 42 + (root1 >= 0 ? root1 : 0)) * 4;
         const float* ti = io.init_joints_3d + (b * 42 + j) * 4;
         const float* ti0 = io.init_joints_3d + (b * 42 + (root2 >= 0 ? root2 : 0)) * 4;
-        const float s3 = w.joints_3d / (float)(B * 42 * 3);
+        const float s3 = w.joints_3d / (float)(Bn * 42 * 3);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             a2[k] = root2 >= 0 ? a1[k] - sh.p1[root2][k] : a1[k];
@@ -151,7 +152,7 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
         const float C2 = n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2];
         lfin = fabsf(C1) - fminf(0.f, C2);
         if (w.finger_reg != 0.f) {
-            const float sf = w.finger_reg / (float)B;
+            const float sf = w.finger_reg / (float)Bn;
             const float k1 = sf * (C1 > 0.f ? 1.f : (C1 < 0.f ? -1.f : 0.f));
             const float k2 = C2 < 0.f ? -sf : 0.f;
             // dC1/df0 = f1 x f2 = n2, dC1/df1 = f2 x f0, dC1/df2 = n1
@@ -226,7 +227,7 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
         const float* tg = io.gt_hand_trans + b * 4;
         const float* tr = io.trans + b * 3;
         float lp = 0.f, lg = 0.f;
-        const float st = w.trans / (float)(B * 3);
+        const float st = w.trans / (float)(Bn * 3);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float d = tp[k] - tr[k];
@@ -252,10 +253,9 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void opt_sample_loss_kernel(ihm
     if (tid >= OPT_SAMPLE_WORKERS) opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS);
     // collision gradient scale: weight * [two-hand sample] / (num_hands^2 * B)   (loss_utils.py:186-188)
     const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
-    const float gs = w.collision * mask / (4.0f * (float)B);
+    const float gs = w.collision * mask / (4.0f * (float)(io.norm_batch > 0 ? io.norm_batch : B));
     sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, io.coll_per_vert, io.coll_origin_scale, nullptr, wk.g_verts, B, gs,
                      io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
-    if (b == 0 && tid < SDF_NXCD) ws.inside_count[tid] = 0;   // ready for the next iteration's prep kernel
 }
 
 // One Adam step of parameter e (< P) of sample b: adds the direct (non-MANO) gradient terms, takes the snapshot
@@ -265,6 +265,7 @@ struct AdamStep {
     int group;            // IHMR_GROUP_*, or < 0: no update
     float w_shape_reg, step_size, bc2_sqrt;
     int snap_idx;         // >= 0: snapshot slot of this iteration
+    int reset_state;      // first iteration of a stage: zero the Adam moments instead of stepping
 };
 __device__ __forceinline__ int adam_group_size(int group) {
     return group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
@@ -289,7 +290,7 @@ __device__ __forceinline__ void opt_adam_apply(const ihmr_opt_io& io, const OptW
         g = wk.g_shape[((size_t)hnd * B + b) * 10 + d];
         // shape regulariser mean((beta_r - beta_l)^2) (loss_utils.py:121-128)
         const float diff = io.shape[(size_t)b * 10 + d] - io.shape[((size_t)B + b) * 10 + d];
-        const float gr = 2.0f * st.w_shape_reg / (float)(B * 10) * diff;
+        const float gr = 2.0f * st.w_shape_reg / (float)((io.norm_batch > 0 ? io.norm_batch : B) * 10) * diff;
         g += hnd == 0 ? gr : -gr;
     }
     const float x = *p;
@@ -320,9 +321,13 @@ __global__ __launch_bounds__(128) void opt_adam_kernel(ihmr_opt_io io, OptWork w
 // still in place), then both skeletons of sample b from the updated parameters.  grid = B, block = 2 x 192
 // (threads [0,192) right hand, [192,384) left hand).  The whole sample lives in one workgroup because the left
 // hand's wrist shift reads the right hand's shape and the shared translation (optimize_model.py:196-206).
-__global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_opt_io io, OptWork wk, int B, AdamStep st) {
+__global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_opt_io io, OptWork wk, int B, AdamStep st,
+                                                            int* inside_count) {
     __shared__ float sk[2][SK_STRIDE];
     const int b = blockIdx.x, tid = threadIdx.x;
+    // the collision kernels of this iteration append to the inside-voxel counter: start it at zero
+    if (b == 0 && tid >= 192 && tid < 192 + SDF_NXCD) inside_count[tid - 192] = 0;
+    if (st.reset_state && tid < OPT_PMAX) { io.adam_m[b * OPT_PMAX + tid] = 0.f; io.adam_v[b * OPT_PMAX + tid] = 0.f; }
     if (st.group >= 0 && tid < adam_group_size(st.group)) opt_adam_apply(io, wk, B, st, b, tid);
     __syncthreads();   // the updated parameters are read back below by other threads of this workgroup
     const int hl = tid / 192;

@@ -45,7 +45,7 @@ class OptIO(C.Structure):
         "init_joints_2d", "init_joints_3d", "init_hand_trans_j", "gt_joints_2d", "gt_joints_3d", "gt_hand_trans",
         "hand_type_array",
         "verts", "joints_3d", "joints_2d", "loss_batch", "coll_per_vert", "coll_origin_scale",
-        "snap_params", "snap_loss", "selected", "adam_m", "adam_v", "workspace")]
+        "snap_params", "snap_loss", "selected", "adam_m", "adam_v", "workspace")] + [("norm_batch", C.c_int)]
 
 
 class OptWeights(C.Structure):

@@ -72,7 +72,11 @@ class OptimizeModel:
         self.opt = opt
         self.process_rank = getattr(opt, "process_rank", -1)
         self.inputSize = opt.inputSize
-        self.batch_size = opt.batchSize
+        # opt.fuse_batches = k: one instance (one launch sequence) carries k consecutive batches of opt.batchSize samples;
+        # every sample gets exactly the arithmetic of a batchSize call (ihmr_opt_io.norm_batch), only the launches are shared
+        self.fuse_batches = int(getattr(opt, "fuse_batches", 1) or 1)
+        self.norm_batch = int(opt.batchSize)
+        self.batch_size = self.norm_batch * self.fuse_batches
         assert opt.total_params_dim == opt.cam_params_dim + opt.trans_params_dim + opt.pose_params_dim + opt.shape_params_dim
         assert getattr(opt, "optimizer", "adam") == "adam", "the fused refinement step implements Adam (the reference default)"
         self.device = torch.device("cuda", torch.cuda.current_device())
@@ -114,7 +118,7 @@ class OptimizeModel:
             selected=torch.zeros(B, device=dev, dtype=torch.int32), adam_m=z(B, hip.OPT_PMAX), adam_v=z(B, hip.OPT_PMAX),
             workspace=torch.empty(hip.lib().ihmr_opt_workspace_bytes(B), device=dev, dtype=torch.uint8),
         )
-        self.io = hip.OptIO(**{k: v.data_ptr() for k, v in self.buf.items()})
+        self.io = hip.OptIO(**{k: v.data_ptr() for k, v in self.buf.items()}, norm_batch=self.norm_batch)
         self.mano_params_weight = z(B, 2)
         self.init = {}
 
@@ -123,7 +127,7 @@ class OptimizeModel:
         B = self.batch_size
         dev = self.device
         g = lambda k: input[k].to(dev, dtype=torch.float32, non_blocking=True)
-        assert input["init_cam"].shape[0] == B, "batch size is fixed at construction (opt.batchSize)"
+        assert input["init_cam"].shape[0] == B, "batch size is fixed at construction (opt.batchSize x opt.fuse_batches)"
         self.buf["hand_type_array"].copy_(g("hand_type_array"))
         self.buf["gt_joints_2d"].copy_(g("joints_2d"))
         self.buf["gt_joints_3d"].copy_(g("joints_3d"))

@@ -116,6 +116,10 @@ typedef struct ihmr_opt_io {
     float* adam_m;       /* (B,90) */
     float* adam_v;       /* (B,90) */
     void* workspace;     /* ihmr_opt_workspace_bytes(B) */
+    /* batch size the reference's batch-mean losses are averaged over (optimize_model.py:276-330); 0 = B.
+       With norm_batch = 64 and B = k * 64 one launch carries k independent batches of 64, each with exactly the
+       arithmetic of a B = 64 call (samples never interact except through these 1/batch factors). */
+    int norm_batch;
 } ihmr_opt_io;
 
 typedef struct ihmr_opt_weights { /* strategies/opt_default.py loss_weights */

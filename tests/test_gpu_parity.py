@@ -273,3 +273,48 @@ def test_opt_trajectory_matches_oracle(mano_arrays):
     mean_pen_got = float(g["collision_loss_origin_scale"].mean())
     print(f"[parity] mean penetration depth ref={mean_pen_ref:.6e} got={mean_pen_got:.6e}")
     assert abs(mean_pen_ref - mean_pen_got) < 1e-4
+
+
+def test_opt_fused_batches_are_bit_identical(mano_arrays):
+    """``opt.fuse_batches = 2``: one launch sequence over two batches gives, sample for sample, the bits of two
+    separate batch-size calls (the batch-mean factors come from ``ihmr_opt_io.norm_batch``, nothing else couples
+    samples) -- parameters, meshes, losses and the snapshot selection."""
+    from ihmr_amd.optimize_model import OptimizeModel
+    B, epoch, freq = 8, 3, 2
+    _, b1 = _two_hand_verts(mano_arrays, B, 11)
+    _, b2 = _two_hand_verts(mano_arrays, B, 12)
+    single = OptimizeModel(_make_opt(B, epoch=epoch, save_mid_freq=freq))
+    outs = []
+    for bt in (b1, b2):
+        single.set_input(bt); single.init_optimize(); single.optimize()
+        torch.cuda.synchronize()
+        outs.append((single.get_pred_result(), torch.stack(single.selected_history).cpu().numpy()))
+    opt = _make_opt(B, epoch=epoch, save_mid_freq=freq)
+    opt.fuse_batches = 2
+    fused = OptimizeModel(opt)
+    both = {k: torch.cat([b1[k], b2[k]], dim=0) for k in b1}
+    fused.set_input(both); fused.init_optimize(); fused.optimize()
+    torch.cuda.synchronize()
+    got, sel = fused.get_pred_result(), torch.stack(fused.selected_history).cpu().numpy()
+    for i, (ref, sel_ref) in enumerate(outs):
+        sl = slice(i * B, (i + 1) * B)
+        assert np.array_equal(sel[:, sl], sel_ref)
+        for k in ("pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "pred_left_hand_verts",
+                  "pred_joints_3d", "collision_loss", "collision_loss_origin_scale"):
+            assert np.array_equal(got[k][sl], ref[k]), f"{k} of batch {i} differs between the fused and the separate run"
+
+
+def test_opt_replay_is_deterministic(mano_arrays):
+    """A model instance is reused batch after batch (``src/optimize.py`` loop): the second pass replays the cached
+    stage graphs on the same (default) stream and must reproduce the first pass bit for bit."""
+    from ihmr_amd.optimize_model import OptimizeModel
+    B = 8
+    _, batch = _two_hand_verts(mano_arrays, B, 21)
+    model = OptimizeModel(_make_opt(B, epoch=3, save_mid_freq=2))
+    outs = []
+    for _ in range(3):
+        model.set_input(batch); model.init_optimize(); model.optimize()
+        torch.cuda.synchronize()
+        outs.append(model.get_pred_result())
+    for k in ("pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "collision_loss_origin_scale"):
+        assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[0][k], outs[2][k]), k
