@@ -32,6 +32,8 @@ def main(argv=None):
     ap.add_argument("--save_mid_freq", type=int, default=10)
     ap.add_argument("--strategy", type=str, default="opt_default")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--fuse_batches", type=int, default=1,
+                    help="consecutive batches carried by one launch sequence (per-sample results identical to separate batches)")
     args = ap.parse_args(argv)
 
     rank, world = D.init_dist()
@@ -42,23 +44,33 @@ def main(argv=None):
                                 shape_params_dim=20, trans_params_dim=3, model_root="", strategy=args.strategy,
                                 save_mid_freq=args.save_mid_freq, optimizer="adam", opt_epoch=args.opt_epoch)
     model = OptimizeModel(opt)
+    G = max(1, args.fuse_batches)
+    model_g = model if G == 1 else OptimizeModel(types.SimpleNamespace(**vars(opt), fuse_batches=G))
     evaluator = Evaluator(model.mano_models)
     fwd = lambda p, s, t: two_hand.forward_from_packed(model.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
 
     idx, is_pad = D.shard_indices(args.num_samples, args.batchSize, rank, world)
+    Bsz = args.batchSize
+    n_batches = len(idx) // Bsz
     t0 = time.time()
-    for s in range(0, len(idx), args.batchSize):
-        sel, pad = idx[s:s + args.batchSize], is_pad[s:s + args.batchSize]
+    done = 0
+    while done < n_batches:
+        g = G if n_batches - done >= G else 1          # a remainder of fewer than G batches runs batch by batch
+        s0 = done * Bsz
+        sel, pad = idx[s0:s0 + g * Bsz], is_pad[s0:s0 + g * Bsz]
         # the synthetic "dataset": sample i is generated from seed + i's batch; padding entries repeat sample 0's batch row
-        data = synthetic_opt_batch(args.batchSize, fwd, seed=args.seed + int(sel[0]), first_index=int(sel[0]))
-        model.set_input(data)
-        model.init_optimize()
-        model.optimize(s // args.batchSize, len(idx) // args.batchSize, verbose=False)
-        pred = model.get_pred_result()
+        parts = [synthetic_opt_batch(Bsz, fwd, seed=args.seed + int(sel[q * Bsz]), first_index=int(sel[q * Bsz])) for q in range(g)]
+        data = parts[0] if g == 1 else {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
+        mdl = model_g if g == G else model
+        mdl.set_input(data)
+        mdl.init_optimize()
+        mdl.optimize(done, n_batches, verbose=False)
+        pred = mdl.get_pred_result()
         n0 = len(evaluator.pred_results)
         evaluator.update(sel, pred)
         new = evaluator.pred_results[n0:]
         evaluator.pred_results = evaluator.pred_results[:n0] + [p for p, k in zip(new, ~pad) if k]   # drop padding duplicates
+        done += g
     sums = D.reduce_metrics(evaluator.metric_sums())
     elapsed = time.time() - t0
     if rank == 0:
@@ -68,6 +80,7 @@ def main(argv=None):
         print(json.dumps(dict(num_samples=args.num_samples, world=world, seconds=elapsed, **m)))
     if world > 1:
         torch.distributed.destroy_process_group()
+    return Evaluator.metrics_from_sums(sums)
 
 
 if __name__ == "__main__":

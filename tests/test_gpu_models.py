@@ -116,3 +116,15 @@ def test_baseline_model_matches_oracle(mano_arrays):
     _report("baseline gt right verts [m]", res["gt_right_hand_verts"], grv, atol=1e-6)
     _report("baseline gt left verts [m]", res["gt_left_hand_verts"], glv, atol=1e-6)
     _report("baseline penetration depth [m]", res["collision_loss_origin_scale"], os_, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_run_optimize_fused_batches_same_metrics():
+    """The ``src/optimize.py`` counterpart end to end on 3 synthetic batches: refining two batches per launch
+    sequence (+ the remainder alone) reports exactly the metrics of the batch-by-batch run."""
+    from ihmr_amd import run_optimize
+    base = ["--num_samples", "24", "--batchSize", "8", "--opt_epoch", "2", "--save_mid_freq", "1"]
+    m1 = run_optimize.main(base)
+    m2 = run_optimize.main(base + ["--fuse_batches", "2"])
+    for k in ("mpjpe_3d", "inter_mpjpe_3d", "collision_ave", "collision_max"):
+        assert m1[k] == m2[k], (k, m1[k], m2[k])
