@@ -9,15 +9,15 @@
 // GEMM view: Y[M = N*Ho*Wo][Cout] = A[M][K = kh*kw*Cin] . Wt[K][Cout], A gathered on the fly (never stored).
 // MFMA: v_mfma_f32_32x32x2_f32 -- f32 in / f32 accumulate, bit-for-bit a k-ordered fmaf chain, 157 TFLOP/s
 // peak on MI355X; the reference is fp32 end to end, so no reduced-precision path is needed for parity.
-// Tile: 128 x BN (BN = 64 | 128) x 16 per workgroup of 4 waves; A is staged K-major in LDS so that the 32
-// lanes of an MFMA row read consecutive addresses; global loads for tile t+1 are issued before the MFMAs of
-// tile t and written to LDS after them.
+// Tile: BM x BN x 16 per workgroup (BM = 64 | 128, BN = 64 | 128), one wave per 64 x 32 sub-tile (2 to 8 waves);
+// A is staged K-major in LDS so that the 32 lanes of an MFMA row read consecutive addresses; LDS is
+// double-buffered: the global loads of tile t+1 are issued before the MFMAs of tile t and stored to the other
+// buffer after them, ONE barrier per K step.  The host picks the largest tile that still gives >= 1.5 workgroups
+// per CU (the 14x14 / 7x7 layers of a 64-image batch have only 12544 / 3136 rows).
 #pragma once
 #include "ihmr_common.h"
 
-#define CONV_BM 128
 #define CONV_BK 16
-#define CONV_THREADS 256
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -32,129 +32,125 @@ struct ConvArgs {
     int act;                // 0 none, 1 relu, 2 sigmoid
 };
 
-template <int BN>
-__global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvArgs a) {
-    constexpr int WN_WAVES = BN == 128 ? 2 : 1;            // waves along n
-    constexpr int WM_WAVES = 4 / WN_WAVES;                 // waves along m
-    constexpr int WM = CONV_BM / WM_WAVES;                 // 64 (BN=128) or 32 (BN=64)
-    constexpr int WN = BN / WN_WAVES;                      // 64
-    constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int LDA = CONV_BM + 5, LDB = BN + 4;   // 8*LDA % 32 != 0: the two k-halves of a row hit different banks
-    __shared__ float As[CONV_BK][LDA];
-    __shared__ float Bs[CONV_BK][LDB];
+template <int BM, int BN>
+__global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int WN_WAVES = BN / 32;                      // waves along n; each wave owns a 64 x 32 sub-tile
+    constexpr int THREADS = (BM / 64) * WN_WAVES * 64;
+    constexpr int LDA = BM + 5, LDB = BN + 4;              // 8*LDA % 32 != 0: the two k-halves of a row hit different banks
+    constexpr int A_F4 = BM * CONV_BK / 4 / THREADS;       // float4 loads of A per thread (1 or 2)
+    constexpr int B_F4 = CONV_BK * BN / 4 / THREADS;       // float4 loads of B per thread (1 or 2)
+    __shared__ float As[2][CONV_BK][LDA];
+    __shared__ float Bs[2][CONV_BK][LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
     const int M = a.N * a.Ho * a.Wo, K = a.kh * a.kw * a.Cin, Kpad = (K + CONV_BK - 1) / CONV_BK * CONV_BK;
-    const int m0 = blockIdx.x * CONV_BM, n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const bool fast = (a.Cin % CONV_BK) == 0;              // a 16-wide K chunk never straddles a filter tap
 
-    // ---- A loader: thread -> (row, 8 consecutive k)
-    const int arow = tid >> 1, akoff = (tid & 1) * 8;
-    const int am = m0 + arow;
-    const bool am_ok = am < M;
-    int an = 0, aho = 0, awo = 0;
-    if (am_ok) { an = am / (a.Ho * a.Wo); const int r = am % (a.Ho * a.Wo); aho = r / a.Wo; awo = r % a.Wo; }
-    // ---- B loader: thread -> (k row(s), 4 consecutive n)
-    constexpr int B_F4_PER_ROW = BN / 4;                   // 32 or 16
-    constexpr int B_ROWS_PER_PASS = CONV_THREADS / B_F4_PER_ROW;  // 8 or 16
-    constexpr int B_PASSES = CONV_BK / B_ROWS_PER_PASS;    // 2 or 1
-    const int bk = tid / B_F4_PER_ROW, bn4 = (tid % B_F4_PER_ROW) * 4;
+    // ---- A loader: float4 f = tid + i*THREADS -> (row f / 4, 4 consecutive k at (f % 4) * 4)
+    int arow[A_F4], ak4[A_F4], an[A_F4], aho[A_F4], awo[A_F4];
+    bool am_ok[A_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        const int f = tid + i * THREADS;
+        arow[i] = f >> 2; ak4[i] = (f & 3) * 4;
+        const int am = m0 + arow[i];
+        am_ok[i] = am < M;
+        an[i] = 0; aho[i] = 0; awo[i] = 0;
+        if (am_ok[i]) { an[i] = am / (a.Ho * a.Wo); const int r = am % (a.Ho * a.Wo); aho[i] = r / a.Wo; awo[i] = r % a.Wo; }
+    }
+    // ---- B loader: float4 g = tid + i*THREADS -> (k row g / (BN/4), 4 consecutive n)
+    constexpr int B_F4_PER_ROW = BN / 4;
 
-    float areg[8];
-    float4 breg[B_PASSES];
+    float4 areg[A_F4], breg[B_F4];
+    int tap_h = 0, tap_w = 0, tap_c = 0;                   // filter tap / channel offset of the NEXT tile to load (fast path)
     auto load_tile = [&](int kc) {
         const int k0 = kc * CONV_BK;
-        if (fast) {
-            const int tap = k0 / a.Cin, c0 = k0 % a.Cin;
-            const int fh = tap / a.kw, fw = tap % a.kw;
-            const int hi = aho * a.stride + fh - a.pad, wi = awo * a.stride + fw - a.pad;
-            const bool ok = am_ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-            if (ok) {
-                const float4* p = reinterpret_cast<const float4*>(a.x + ((size_t)(an * a.H + hi) * a.W + wi) * a.ldx + c0 + akoff);
-                const float4 v0 = p[0], v1 = p[1];
-                areg[0] = v0.x; areg[1] = v0.y; areg[2] = v0.z; areg[3] = v0.w;
-                areg[4] = v1.x; areg[5] = v1.y; areg[6] = v1.z; areg[7] = v1.w;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            if (fast) {
+                const int hi = aho[i] * a.stride + tap_h - a.pad, wi = awo[i] * a.stride + tap_w - a.pad;
+                const bool ok = am_ok[i] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                areg[i] = ok ? *reinterpret_cast<const float4*>(a.x + ((size_t)(an[i] * a.H + hi) * a.W + wi) * a.ldx + tap_c + ak4[i])
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
+                float v[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) areg[e] = 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = k0 + akoff + e;
-                float v = 0.f;
-                if (am_ok && k < K) {
-                    const int c = k % a.Cin, tap = k / a.Cin, fh = tap / a.kw, fw = tap % a.kw;
-                    const int hi = aho * a.stride + fh - a.pad, wi = awo * a.stride + fw - a.pad;
-                    if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) v = a.x[((size_t)(an * a.H + hi) * a.W + wi) * a.ldx + c];
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + ak4[i] + e;
+                    v[e] = 0.f;
+                    if (am_ok[i] && k < K) {
+                        const int c = k % a.Cin, tap = k / a.Cin, fh = tap / a.kw, fw = tap % a.kw;
+                        const int hi = aho[i] * a.stride + fh - a.pad, wi = awo[i] * a.stride + fw - a.pad;
+                        if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) v[e] = a.x[((size_t)(an[i] * a.H + hi) * a.W + wi) * a.ldx + c];
+                    }
                 }
-                areg[e] = v;
+                areg[i] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
 #pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) {
-            const int k = k0 + bk + p * B_ROWS_PER_PASS;
-            breg[p] = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.ldw + n0 + bn4);   // ldw >= n0 + BN, zero padded
+        for (int i = 0; i < B_F4; ++i) {
+            const int g = tid + i * THREADS;
+            const int k = k0 + g / B_F4_PER_ROW, n4 = (g % B_F4_PER_ROW) * 4;
+            breg[i] = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.ldw + n0 + n4);   // ldw >= n0 + BN, zero padded
         }
+        tap_c += CONV_BK;                                   // advance to the next tile's tap (fast path only)
+        if (tap_c >= a.Cin) { tap_c = 0; if (++tap_w == a.kw) { tap_w = 0; ++tap_h; } }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) As[akoff + e][arow] = areg[e];
+        for (int i = 0; i < A_F4; ++i) {
+            As[buf][ak4[i] + 0][arow[i]] = areg[i].x; As[buf][ak4[i] + 1][arow[i]] = areg[i].y;
+            As[buf][ak4[i] + 2][arow[i]] = areg[i].z; As[buf][ak4[i] + 3][arow[i]] = areg[i].w;
+        }
 #pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) *reinterpret_cast<float4*>(&Bs[bk + p * B_ROWS_PER_PASS][bn4]) = breg[p];
+        for (int i = 0; i < B_F4; ++i) {
+            const int g = tid + i * THREADS;
+            *reinterpret_cast<float4*>(&Bs[buf][g / B_F4_PER_ROW][(g % B_F4_PER_ROW) * 4]) = breg[i];
+        }
     };
 
-    f32x16 acc[MI][NI];
+    f32x16 acc[2];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
     const int nk = Kpad / CONV_BK;
+    const int kl = lane >> 5, l31 = lane & 31;
     load_tile(0);
+    store_tile(0);
+    __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
-        __syncthreads();            // previous tile fully consumed
-        store_tile();
-        __syncthreads();
+        const int cur = kc & 1;
         if (kc + 1 < nk) load_tile(kc + 1);   // in flight during the MFMAs below
-        const int kl = lane >> 5, l31 = lane & 31;
 #pragma unroll
         for (int kk = 0; kk < CONV_BK; kk += 2) {
-            float af[MI], bf[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) af[mi] = As[kk + kl][wm * WM + mi * 32 + l31];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bf[ni] = Bs[kk + kl][wn * WN + ni * 32 + l31];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            const float a0 = As[cur][kk + kl][wm * 64 + l31], a1 = As[cur][kk + kl][wm * 64 + 32 + l31];
+            const float bf = Bs[cur][kk + kl][wn * 32 + l31];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf, acc[1], 0, 0, 0);
         }
+        if (kc + 1 < nk) store_tile(cur ^ 1);  // the other buffer: its readers finished before the previous barrier
+        __syncthreads();
     }
 
     // ---- epilogue: bias (+ residual) (+ activation); C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    const int n = n0 + wn * 32 + l31, rbase = 4 * kl;
+    if (n >= a.Cout) return;
+    const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wn * WN + ni * 32 + col;
-            if (n >= a.Cout) continue;
-            const float bv = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                if (m >= M) continue;
-                float v = acc[mi][ni][r] + bv;
-                if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
-                if (a.act == 1) v = fmaxf(v, 0.f);
-                else if (a.act == 2) v = 1.0f / (1.0f + expf(-v));
-                a.y[(size_t)m * a.ldy + n] = v;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+            if (m >= M) continue;
+            float v = acc[mi][r] + bv;
+            if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
+            if (a.act == 1) v = fmaxf(v, 0.f);
+            else if (a.act == 2) v = 1.0f / (1.0f + expf(-v));
+            a.y[(size_t)m * a.ldy + n] = v;
         }
 }
 

@@ -409,12 +409,18 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
     ConvArgs a{x, w, bias, residual, y, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, ldx, ldw, ldy, ldr, act};
     const int M = N * Ho * Wo;
     hipStream_t st = (hipStream_t)stream;
-    if (Cout > 64 && ldw % 128 == 0) {
-        hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3((M + CONV_BM - 1) / CONV_BM, (Cout + 127) / 128), dim3(CONV_THREADS), 0, st, a);
-    } else {
-        if (ldw % 64 != 0) return -1;
-        hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3((M + CONV_BM - 1) / CONV_BM, (Cout + 63) / 64), dim3(CONV_THREADS), 0, st, a);
-    }
+    // largest tile that still gives >= 1.5 workgroups per CU (384 on 256 CUs); wide tiles need ldw padded to 128
+    const bool wide_ok = Cout > 64 && ldw % 128 == 0;
+    if (!wide_ok && ldw % 64 != 0) return -1;
+    auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
+    if (wide_ok && blocks(128, 128) >= 384)
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 128>), dim3((M + 127) / 128, (Cout + 127) / 128), dim3(512), 0, st, a);
+    else if (wide_ok && blocks(64, 128) >= 384)
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 128>), dim3((M + 63) / 64, (Cout + 127) / 128), dim3(256), 0, st, a);
+    else if (blocks(128, 64) >= 384)
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 64>), dim3((M + 127) / 128, (Cout + 63) / 64), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 64>), dim3((M + 63) / 64, (Cout + 63) / 64), dim3(128), 0, st, a);
     return (int)hipGetLastError();
 }
 
