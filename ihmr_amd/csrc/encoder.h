@@ -30,6 +30,8 @@ struct ConvArgs {
     int N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad;
     int ldx, ldw, ldy, ldr;
     int act;                // 0 none, 1 relu, 2 sigmoid
+    float* partial;         // split-K: [ksplit][M][Cout] raw partial sums (bias / residual / activation applied by conv_splitk_reduce_kernel)
+    int ksplit;             // gridDim.z; 1 = no split
 };
 
 template <int BM, int BN>
@@ -117,13 +119,19 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
-    const int nk = Kpad / CONV_BK;
+    // split-K: this workgroup owns K tiles [kc0, kc1)
+    const int nk_all = Kpad / CONV_BK, nk_per = (nk_all + a.ksplit - 1) / a.ksplit;
+    const int kc0 = blockIdx.z * nk_per, kc1 = min(nk_all, kc0 + nk_per);
+    if (fast) { const int k0 = kc0 * CONV_BK, tap = k0 / a.Cin; tap_c = k0 % a.Cin; tap_h = tap / a.kw; tap_w = tap % a.kw; }
     const int kl = lane >> 5, l31 = lane & 31;
-    load_tile(0);
-    store_tile(0);
+    if (kc0 < kc1) {
+        load_tile(kc0);
+        store_tile(0);
+    }
     __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const int cur = kc & 1;
+    for (int kc = kc0; kc < kc1; ++kc) {
+        const int cur = (kc - kc0) & 1;
+        const int nk = kc1;
         if (kc + 1 < nk) load_tile(kc + 1);   // in flight during the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < CONV_BK; kk += 2) {
@@ -139,19 +147,61 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(
     // ---- epilogue: bias (+ residual) (+ activation); C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const int n = n0 + wn * 32 + l31, rbase = 4 * kl;
     if (n >= a.Cout) return;
+    if (a.ksplit > 1) {   // raw partial sums; the reduce kernel finishes the layer
+        float* part = a.partial + (size_t)blockIdx.z * M * a.Cout;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                if (m < M) part[(size_t)m * a.Cout + n] = acc[mi][r];
+            }
+        return;
+    }
     const float bv = a.bias ? a.bias[n] : 0.f;
+    // residual rows first, all loads in flight together (y may alias nothing here, but the compiler cannot know:
+    // interleaved with the stores it would issue them one by one)
+    float res[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+            res[mi][r] = (a.residual && m < M) ? a.residual[(size_t)m * a.ldr + n] : 0.f;
+        }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
             if (m >= M) continue;
-            float v = acc[mi][r] + bv;
-            if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
+            float v = acc[mi][r] + bv + res[mi][r];
             if (a.act == 1) v = fmaxf(v, 0.f);
             else if (a.act == 2) v = 1.0f / (1.0f + expf(-v));
             a.y[(size_t)m * a.ldy + n] = v;
         }
+}
+
+// split-K epilogue: y = act(sum_z partial[z] (fixed order) + bias + residual); one thread per 4 output channels
+__global__ void conv_splitk_reduce_kernel(ConvArgs a) {
+    const int M = a.N * a.Ho * a.Wo, c4 = a.Cout / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * c4) return;
+    const int m = (int)(idx / c4), n = (int)(idx % c4) * 4;
+    float4 s = *reinterpret_cast<const float4*>(a.partial + (size_t)m * a.Cout + n);
+    for (int z = 1; z < a.ksplit; ++z) {
+        const float4 p = *reinterpret_cast<const float4*>(a.partial + ((size_t)z * M + m) * a.Cout + n);
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] += a.bias ? a.bias[n + e] : 0.f;
+        if (a.residual) v[e] += a.residual[(size_t)m * a.ldr + n + e];
+        if (a.act == 1) v[e] = fmaxf(v[e], 0.f);
+        else if (a.act == 2) v[e] = 1.0f / (1.0f + expf(-v[e]));
+        a.y[(size_t)m * a.ldy + n + e] = v[e];
+    }
 }
 
 // MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (resnet.py:107,141); one thread per (pixel, 4 channels)

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "ihmr_common.h"
@@ -404,23 +405,49 @@ extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, c
 // ------------------------------------------------------------------------------------------ encoder
 extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias, const float* residual, float* y, int N, int H,
                                int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int ldx, int ldw,
-                               int ldy, int ldr, int act, void* stream) {
+                               int ldy, int ldr, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !y || N <= 0 || Cout <= 0) return -1;
-    ConvArgs a{x, w, bias, residual, y, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, ldx, ldw, ldy, ldr, act};
-    const int M = N * Ho * Wo;
+    ConvArgs a{x, w, bias, residual, y, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, ldx, ldw, ldy, ldr, act, (float*)workspace, 1};
+    const int M = N * Ho * Wo, nk = (kh * kw * Cin + CONV_BK - 1) / CONV_BK;
     hipStream_t st = (hipStream_t)stream;
-    // largest tile that still gives >= 1.5 workgroups per CU (384 on 256 CUs); wide tiles need ldw padded to 128
+    // Tile: the largest that still gives >= 1.5 workgroups per CU (384 on 256 CUs); wide tiles need ldw padded to 128.
+    // If no tile does (7x7 maps, the Linear layers of a 64-image batch), the K loop is split over gridDim.z into
+    // partial sums (caller workspace) that conv_splitk_reduce_kernel adds in fixed order.
     const bool wide_ok = Cout > 64 && ldw % 128 == 0;
     if (!wide_ok && ldw % 64 != 0) return -1;
-    auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
-    if (wide_ok && blocks(128, 128) >= 384)
-        hipLaunchKernelGGL((conv_igemm_kernel<128, 128>), dim3((M + 127) / 128, (Cout + 127) / 128), dim3(512), 0, st, a);
-    else if (wide_ok && blocks(64, 128) >= 384)
-        hipLaunchKernelGGL((conv_igemm_kernel<64, 128>), dim3((M + 63) / 64, (Cout + 127) / 128), dim3(256), 0, st, a);
-    else if (blocks(128, 64) >= 384)
-        hipLaunchKernelGGL((conv_igemm_kernel<128, 64>), dim3((M + 127) / 128, (Cout + 63) / 64), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<64, 64>), dim3((M + 63) / 64, (Cout + 63) / 64), dim3(128), 0, st, a);
+    const int tiles[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+    auto blocks = [&](int t) { return (long)((M + tiles[t][0] - 1) / tiles[t][0]) * ((Cout + tiles[t][1] - 1) / tiles[t][1]); };
+    auto waves = [&](int t) { return blocks(t) * (tiles[t][0] / 64) * (tiles[t][1] / 32); };   // one wave per 64 x 32 sub-tile
+    auto usable = [&](int t) { return tiles[t][1] == 64 || wide_ok; };
+    // enough work = every CU gets a workgroup (256) and every SIMD ~1.5 waves (1536)
+    int pick = -1, ksplit = 1;
+    for (int t = 0; t < 4 && pick < 0; ++t)
+        if (usable(t) && blocks(t) >= 256 && waves(t) >= 1536) pick = t;
+    if (pick < 0) {
+        const long kmax = std::min<long>(8, std::max(1, nk / 8));
+        const long cap = workspace && Cout % 4 == 0 ? (long)(workspace_bytes / ((size_t)M * Cout * sizeof(float))) : 1;
+        for (int t = 0; t < 4 && pick < 0; ++t) {
+            if (!usable(t)) continue;
+            const long want = std::max((256 + blocks(t) - 1) / blocks(t), (1536 + waves(t) - 1) / waves(t));
+            if (want <= std::min(kmax, cap)) { pick = t; ksplit = (int)want; }
+        }
+        if (pick < 0) {   // tiny layers (Linear at batch 64): widest usable tile, as much split as allowed
+            pick = wide_ok ? 1 : 3;
+            ksplit = (int)std::max<long>(1, std::min(kmax, cap));
+        }
+    }
+    a.ksplit = ksplit;
+    const dim3 grid((M + tiles[pick][0] - 1) / tiles[pick][0], (Cout + tiles[pick][1] - 1) / tiles[pick][1], ksplit);
+    switch (pick) {
+        case 0: hipLaunchKernelGGL((conv_igemm_kernel<128, 128>), grid, dim3(512), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((conv_igemm_kernel<64, 128>), grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((conv_igemm_kernel<128, 64>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((conv_igemm_kernel<64, 64>), grid, dim3(128), 0, st, a); break;
+    }
+    if (ksplit > 1) {
+        const long total = (long)M * (Cout / 4);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    }
     return (int)hipGetLastError();
 }
 

@@ -102,7 +102,7 @@ def lib():
         L.ihmr_opt_forward_graph_create.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(vp)]
         L.ihmr_graph_launch.argtypes = [vp, vp]
         L.ihmr_graph_destroy.argtypes = [vp]
-        L.ihmr_conv_igemm.argtypes = [vp, vp, vp, vp, vp] + [i] * 16 + [vp]
+        L.ihmr_conv_igemm.argtypes = [vp, vp, vp, vp, vp] + [i] * 16 + [vp, C.c_size_t, vp]
         L.ihmr_maxpool3x3s2.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.ihmr_avgpool_relu.argtypes = [vp, vp, i, i, i, i, vp]
         L.ihmr_opt_sdf_stats.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), vp, vp]

@@ -48,6 +48,17 @@ def _fold_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
     return conv.weight.detach() * scale[:, None, None, None], bn.bias.detach() - bn.running_mean.detach() * scale
 
 
+_WS = {}
+
+
+def _splitk_workspace(device):
+    """32 MB of scratch per (device, stream) for the split-K partial sums of the small layers (ihmr_conv_igemm)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _WS:
+        _WS[key] = torch.empty(8 * 1024 * 1024, device=device, dtype=torch.float32)
+    return _WS[key]
+
+
 def conv_igemm(x, pk: _Packed, N, H, W, ldx, out=None, ldy=None, residual=None, ldr=0, act=0):
     """x: device tensor holding NHWC activations (pixel stride ldx).  Returns (y, Ho, Wo)."""
     Ho = (H + 2 * pk.pad - pk.kh) // pk.stride + 1
@@ -55,9 +66,10 @@ def conv_igemm(x, pk: _Packed, N, H, W, ldx, out=None, ldy=None, residual=None, 
     if out is None:
         out = torch.empty(N * Ho * Wo, pk.cout, device=x.device, dtype=torch.float32)
         ldy = pk.cout
+    ws = _splitk_workspace(x.device)
     hip.check(hip.lib().ihmr_conv_igemm(hip.ptr(x), hip.ptr(pk.w), hip.ptr(pk.b), None if residual is None else residual.data_ptr(),
                                         out.data_ptr(), N, H, W, pk.cin, Ho, Wo, pk.cout, pk.kh, pk.kw, pk.stride, pk.pad,
-                                        ldx, pk.ldw, ldy, ldr, act, hip.stream_ptr()), "ihmr_conv_igemm")
+                                        ldx, pk.ldw, ldy, ldr, act, ws.data_ptr(), ws.numel() * 4, hip.stream_ptr()), "ihmr_conv_igemm")
     return out, Ho, Wo
 
 

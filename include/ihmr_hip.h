@@ -165,10 +165,12 @@ int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
  * implicit GEMM on the fp32 matrix cores: y[M = N*Ho*Wo][Cout] = act(A(x) . w + bias (+ residual)).
  * x: NHWC, pixel stride ldx floats;  w: [ceil16(kh*kw*Cin)][ldw] K-major with BatchNorm folded in, zero padded,
  * ldw a multiple of 64 (128 to use the wide tile) and >= Cout;  bias [Cout];  residual optional [M][ldr];
- * y [M][ldy];  act: 0 none, 1 ReLU, 2 sigmoid.  A Linear layer is the case H = W = kh = kw = 1. */
+ * y [M][ldy];  act: 0 none, 1 ReLU, 2 sigmoid.  A Linear layer is the case H = W = kh = kw = 1.
+ * workspace (optional, device, workspace_bytes): scratch for split-K partial sums -- layers too small to fill the
+ * GPU (7x7 maps, Linear layers) split their K loop over up to min(8, workspace_bytes / (M*Cout*4)) workgroups. */
 int ihmr_conv_igemm(const float* x, const float* w, const float* bias, const float* residual, float* y, int N, int H, int W,
                     int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int ldx, int ldw, int ldy, int ldr,
-                    int act, void* stream);
+                    int act, void* workspace, size_t workspace_bytes, void* stream);
 /* nn.MaxPool2d(3, stride 2, padding 1) (resnet.py:107) and AvgPool2d(7) + ReLU (resnet.py:111,149-151), NHWC */
 int ihmr_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int ihmr_avgpool_relu(const float* x, float* y, int N, int HW, int C, int ldy, void* stream);
