@@ -182,20 +182,21 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(
         }
 }
 
-// split-K epilogue: y = act(sum_z partial[z] (fixed order) + bias + residual); one thread per 4 output channels
+// split-K epilogue: y = act(sum_z partial[z] (fixed order) + bias + residual); one thread per VEC output channels
+template <int VEC>
 __global__ void conv_splitk_reduce_kernel(ConvArgs a) {
-    const int M = a.N * a.Ho * a.Wo, c4 = a.Cout / 4;
+    const int M = a.N * a.Ho * a.Wo, cv = a.Cout / VEC;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)M * c4) return;
-    const int m = (int)(idx / c4), n = (int)(idx % c4) * 4;
-    float4 s = *reinterpret_cast<const float4*>(a.partial + (size_t)m * a.Cout + n);
-    for (int z = 1; z < a.ksplit; ++z) {
-        const float4 p = *reinterpret_cast<const float4*>(a.partial + ((size_t)z * M + m) * a.Cout + n);
-        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-    }
-    float v[4] = {s.x, s.y, s.z, s.w};
+    if (idx >= (long)M * cv) return;
+    const int m = (int)(idx / cv), n = (int)(idx % cv) * VEC;
+    float v[VEC];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < VEC; ++e) v[e] = a.partial[(size_t)m * a.Cout + n + e];
+    for (int z = 1; z < a.ksplit; ++z)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] += a.partial[((size_t)z * M + m) * a.Cout + n + e];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
         v[e] += a.bias ? a.bias[n + e] : 0.f;
         if (a.residual) v[e] += a.residual[(size_t)m * a.ldr + n + e];
         if (a.act == 1) v[e] = fmaxf(v[e], 0.f);

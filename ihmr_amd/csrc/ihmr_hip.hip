@@ -425,7 +425,7 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
         if (usable(t) && blocks(t) >= 256 && waves(t) >= 1536) pick = t;
     if (pick < 0) {
         const long kmax = std::min<long>(8, std::max(1, nk / 8));
-        const long cap = workspace && Cout % 4 == 0 ? (long)(workspace_bytes / ((size_t)M * Cout * sizeof(float))) : 1;
+        const long cap = workspace ? (long)(workspace_bytes / ((size_t)M * Cout * sizeof(float))) : 1;
         for (int t = 0; t < 4 && pick < 0; ++t) {
             if (!usable(t)) continue;
             const long want = std::max((256 + blocks(t) - 1) / blocks(t), (1536 + waves(t) - 1) / waves(t));
@@ -445,8 +445,13 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
         default: hipLaunchKernelGGL((conv_igemm_kernel<64, 64>), grid, dim3(128), 0, st, a); break;
     }
     if (ksplit > 1) {
-        const long total = (long)M * (Cout / 4);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+        if (Cout % 4 == 0) {
+            const long total = (long)M * (Cout / 4);
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+        } else {
+            const long total = (long)M * Cout;
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+        }
     }
     return (int)hipGetLastError();
 }
