@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC ihmr_hip.hip -o libihmr_hip.so
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -410,30 +411,31 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
     ConvArgs a{x, w, bias, residual, y, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, ldx, ldw, ldy, ldr, act, (float*)workspace, 1};
     const int M = N * Ho * Wo, nk = (kh * kw * Cin + CONV_BK - 1) / CONV_BK;
     hipStream_t st = (hipStream_t)stream;
-    // Tile: the largest that still gives >= 1.5 workgroups per CU (384 on 256 CUs); wide tiles need ldw padded to 128.
-    // If no tile does (7x7 maps, the Linear layers of a 64-image batch), the K loop is split over gridDim.z into
-    // partial sums (caller workspace) that conv_splitk_reduce_kernel adds in fixed order.
+    // Tile and K split, from per-layer measurements on MI355X (scripts/prof_encoder.py with IHMR_CONV_FORCE):
+    // the 128 x 128 tile wins on every ResNet-50 layer, even when it leaves CUs without a workgroup -- smaller
+    // tiles move twice the operands through LDS per MFMA.  Occupancy is repaired with split-K instead: layers with
+    // fewer than 1.5 workgroups per CU and a long K loop run their K halves in separate workgroups (two resident
+    // workgroups per CU also hide each other's barriers); partial sums go to the caller's workspace and
+    // conv_splitk_reduce_kernel adds them in fixed order.  Single-image-row layers (the Linear layers at batch 64)
+    // take the 64-row tile and the deepest split the K loop allows.
     const bool wide_ok = Cout > 64 && ldw % 128 == 0;
     if (!wide_ok && ldw % 64 != 0) return -1;
     const int tiles[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
     auto blocks = [&](int t) { return (long)((M + tiles[t][0] - 1) / tiles[t][0]) * ((Cout + tiles[t][1] - 1) / tiles[t][1]); };
-    auto waves = [&](int t) { return blocks(t) * (tiles[t][0] / 64) * (tiles[t][1] / 32); };   // one wave per 64 x 32 sub-tile
     auto usable = [&](int t) { return tiles[t][1] == 64 || wide_ok; };
-    // enough work = every CU gets a workgroup (256) and every SIMD ~1.5 waves (1536)
-    int pick = -1, ksplit = 1;
-    for (int t = 0; t < 4 && pick < 0; ++t)
-        if (usable(t) && blocks(t) >= 256 && waves(t) >= 1536) pick = t;
-    if (pick < 0) {
-        const long kmax = std::min<long>(8, std::max(1, nk / 8));
-        const long cap = workspace ? (long)(workspace_bytes / ((size_t)M * Cout * sizeof(float))) : 1;
-        for (int t = 0; t < 4 && pick < 0; ++t) {
-            if (!usable(t)) continue;
-            const long want = std::max((256 + blocks(t) - 1) / blocks(t), (1536 + waves(t) - 1) / waves(t));
-            if (want <= std::min(kmax, cap)) { pick = t; ksplit = (int)want; }
-        }
-        if (pick < 0) {   // tiny layers (Linear at batch 64): widest usable tile, as much split as allowed
-            pick = wide_ok ? 1 : 3;
-            ksplit = (int)std::max<long>(1, std::min(kmax, cap));
+    const long cap = workspace ? (long)(workspace_bytes / ((size_t)M * Cout * sizeof(float))) : 1;
+    int pick = wide_ok ? 0 : 2, ksplit = 1;
+    if (M <= 64) {
+        pick = wide_ok ? 1 : 3;
+        ksplit = (int)std::max<long>(1, std::min<long>(std::min<long>(8, cap), nk / 8));
+    } else if (blocks(pick) < 384 && nk >= 64 && cap >= 2) {
+        ksplit = 2;
+    }
+    if (const char* force = getenv("IHMR_CONV_FORCE")) {   // experiments: "<tile 0-3> <ksplit>"
+        int ft = -1, fk = 1;
+        if (sscanf(force, "%d %d", &ft, &fk) >= 1 && ft >= 0 && ft < 4 && usable(ft)) {
+            pick = ft;
+            ksplit = (int)std::max<long>(1, std::min<long>(std::min<long>(fk, cap), std::max(1, nk / 4)));
         }
     }
     a.ksplit = ksplit;
