@@ -320,6 +320,12 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     return (int)hipGetLastError();
 }
 
+extern "C" int ihmr_opt_set_params(const ihmr_opt_io* io, const float* final_params, int B, void* stream) {
+    if (!io || !final_params || B <= 0) return -1;
+    hipLaunchKernelGGL(opt_unpack_params_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, *io, final_params, B);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ stage graphs
 // A stage is ~8 launches x n_iters with no host decision inside: capture it once into a hipGraph (per model
 // instance and stage -- the io pointers and the per-iteration Adam constants are baked into the nodes) and

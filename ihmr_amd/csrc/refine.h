@@ -334,6 +334,23 @@ __global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_op
     lbs_skel_hand<true>(m, io.orient, io.pose, io.shape, io.trans, B, wk.lbs.skel, wk.joints_raw, sk[hl], hl * B + b, tid % 192);
 }
 
+// The reference's packed prediction vector final_params (B,122) = [cam 3 | R orient 3 | R pose 45 | L orient 3 |
+// L pose 45 | R shape 10 | L shape 10 | trans 3] (baseline_model.py:262-270, mlp_model.py:426-439) scattered into
+// the per-group state buffers of ihmr_opt_io.  grid = B, block = 128.
+__global__ __launch_bounds__(128) void opt_unpack_params_kernel(ihmr_opt_io io, const float* __restrict__ packed, int B) {
+    const int b = blockIdx.x, e = threadIdx.x;
+    if (e >= 122) return;
+    const float v = packed[(size_t)b * 122 + e];
+    if (e < 3) io.cam[b * 3 + e] = v;
+    else if (e < 6) io.orient[(size_t)b * 3 + (e - 3)] = v;
+    else if (e < 51) io.pose[(size_t)b * 45 + (e - 6)] = v;
+    else if (e < 54) io.orient[((size_t)B + b) * 3 + (e - 51)] = v;
+    else if (e < 99) io.pose[((size_t)B + b) * 45 + (e - 54)] = v;
+    else if (e < 109) io.shape[(size_t)b * 10 + (e - 99)] = v;
+    else if (e < 119) io.shape[((size_t)B + b) * 10 + (e - 109)] = v;
+    else io.trans[b * 3 + (e - 119)] = v;
+}
+
 // utils/opt_utils.py:104-153: validity filter, 1e11 for invalid rows, row 0 restored, first argmin,
 // selected parameters written back.  grid = ceil(B/64), one thread per sample.
 __global__ void opt_select_kernel(ihmr_opt_io io, int B, int group, int S, float fac_j3d, float fac_coll,

@@ -12,6 +12,7 @@ as ``select_better_params`` prescribes (``:592-637``), store to the per-dataset-
 from __future__ import annotations
 
 import copy
+import ctypes as C
 import os.path as osp
 import types
 from collections import OrderedDict
@@ -25,6 +26,10 @@ from .optimize_model import OptimizeModel
 
 PARAM_DIMS = OrderedDict(pred_hand_trans=3, pred_left_orient=3, pred_right_orient=3, pred_left_pose_params=45,
                          pred_right_pose_params=45, pred_left_shape_params=10, pred_right_shape_params=10, pred_cam_params=3)
+# columns of the packed prediction vector final_params (B,122) (mlp_model.py:426-439): the whole refinement state
+COLS = OrderedDict(pred_cam_params=slice(0, 3), pred_right_orient=slice(3, 6), pred_right_pose_params=slice(6, 51),
+                   pred_left_orient=slice(51, 54), pred_left_pose_params=slice(54, 99), pred_right_shape_params=slice(99, 109),
+                   pred_left_shape_params=slice(109, 119), pred_hand_trans=slice(119, 122))
 LOSS_SLOT = dict(joints_2d_loss_p=0, joints_3d_loss_p=1, collision_loss=2)      # rows of ihmr_opt_io.loss_batch
 
 
@@ -54,10 +59,11 @@ class MLPModel:
             if n not in LOSS_SLOT:
                 raise ValueError(f"unsupported filter/select loss {n}")
         dev = self.device
+        # "prev" tables indexed by dataset index (mlp_model.py:337-356), kept packed: one row per sample
         self.data_idxs_all = torch.zeros(num_data, dtype=torch.bool, device=dev)
         self.img_feat_all = torch.zeros(num_data, 1024, device=dev)
-        self.prev_params = {n: torch.zeros(num_data, d, device=dev) for n, d in PARAM_DIMS.items()}
-        self.prev_losses = {n: torch.zeros(num_data, device=dev) for n in self.loss_names}
+        self.prev_final = torch.zeros(num_data, 122, device=dev)
+        self.prev_loss = torch.zeros(num_data, 3, device=dev)          # columns = LOSS_SLOT
 
     # mlp_model.py:370-405 (inference part)
     def add_new_network(self, stage_id):
@@ -97,75 +103,61 @@ class MLPModel:
         self.init_cam, self.init_pose_params = g("init_cam"), g("init_pose_params")
         self.init_shape_params, self.init_hand_trans = g("init_shape_params"), g("init_hand_trans").reshape(B, 3)
 
-    def _gather(self):  # mlp_model.py:426-439
-        self.pred_shape_params = torch.cat([self.pred_right_shape_params, self.pred_left_shape_params], 1)
-        self.pred_pose_params = torch.cat([self.pred_right_orient, self.pred_right_pose_params, self.pred_left_orient, self.pred_left_pose_params], 1)
-        self.final_params = torch.cat([self.pred_cam_params, self.pred_pose_params, self.pred_shape_params, self.pred_hand_trans], 1)
+    # reference-named views of the packed state (mlp_model.py:426-439)
+    @property
+    def pred_pose_params(self): return self.final_params[:, 3:99]
+    @property
+    def pred_shape_params(self): return self.final_params[:, 99:119]
 
-    def _forward_mano_and_losses(self):
-        """__forward_mano + the selection-relevant part of compute_loss: one captured launch of the fused kernels."""
-        c = self._core.buf
-        c["cam"].copy_(self.pred_cam_params)
-        c["trans"].copy_(self.pred_hand_trans)
-        c["orient"][0].copy_(self.pred_right_orient); c["orient"][1].copy_(self.pred_left_orient)
-        c["pose"][0].copy_(self.pred_right_pose_params); c["pose"][1].copy_(self.pred_left_pose_params)
-        c["shape"][0].copy_(self.pred_right_shape_params); c["shape"][1].copy_(self.pred_left_shape_params)
+    def _forward_mano_and_losses(self, final):
+        """__forward_mano + the selection-relevant part of compute_loss for the packed state `final` (B,122): one
+        scatter kernel + one captured launch of the fused kernels; returns the three per-sample losses (B,3)."""
+        hip.check(hip.lib().ihmr_opt_set_params(C.byref(self._core.io), final.data_ptr(), self.batch_size, hip.stream_ptr()),
+                  "ihmr_opt_set_params")
         self._core.forward_losses(self._w)
-        lb = c["loss_batch"]
-        self.joints_2d_loss_p_batch, self.joints_3d_loss_p_batch, self.collision_loss_batch = lb[0].clone(), lb[1].clone(), lb[2].clone()
+        return self._core.buf["loss_batch"][:3].t().contiguous()
 
-    def _save_prev(self):  # mlp_model.py:337-356
-        self.data_idxs_all[self.data_idxs] = True
-        self.img_feat_all[self.data_idxs] = self.img_feat
-        for n in PARAM_DIMS:
-            self.prev_params[n][self.data_idxs] = getattr(self, n)
-        for n in self.loss_names:
-            self.prev_losses[n][self.data_idxs] = getattr(self, n + "_batch")
-
-    def _select_better_params(self, stage):  # mlp_model.py:592-637
-        ok = torch.ones(self.batch_size, dtype=torch.bool, device=self.device)
-        for name, pct in stage["filter_loss"]:
-            ok &= getattr(self, name + "_batch") < self.prev_losses[name][self.data_idxs] * (1 + float(pct) / 100)
-        sel = stage["select_loss"]
-        ok &= getattr(self, sel + "_batch") <= self.prev_losses[sel][self.data_idxs]
-        rep = ~ok
-        for n in stage["update_params"]:
-            setattr(self, n, torch.where(rep[:, None], self.prev_params[n][self.data_idxs], getattr(self, n)))
-        for n in self.loss_names:
-            setattr(self, n + "_batch", torch.where(rep, self.prev_losses[n][self.data_idxs], getattr(self, n + "_batch")))
-        self.data_idxs_all[self.data_idxs] = False
-        self._gather()
-        self.kept = ok
+    def _save_prev(self, final, loss):  # mlp_model.py:337-356
+        idx = self.data_idxs
+        self.data_idxs_all[idx] = True
+        self.img_feat_all[idx] = self.img_feat
+        self.prev_final[idx] = final
+        self.prev_loss[idx] = loss
 
     # mlp_model.py:683-699
     @torch.no_grad()
     def test(self):
-        p, s = self.init_pose_params, self.init_shape_params
-        self.pred_cam_params, self.pred_hand_trans = self.init_cam.clone(), self.init_hand_trans.clone()
-        self.pred_right_orient, self.pred_left_orient = p[:, :3].clone(), p[:, 48:51].clone()
-        self.pred_right_pose_params, self.pred_left_pose_params = p[:, 3:48].clone(), p[:, 51:].clone()
-        self.pred_right_shape_params, self.pred_left_shape_params = s[:, :10].clone(), s[:, 10:].clone()
-        self._gather()
-        self._forward_mano_and_losses()
-        self._save_prev()
+        # mlp_model.py:204-216: [cam | pose 96 | shape 20 | trans] in the reference's order
+        final = torch.cat([self.init_cam, self.init_pose_params, self.init_shape_params, self.init_hand_trans], dim=1).contiguous()
+        loss = self._forward_mano_and_losses(final)
+        self._save_prev(final, loss)
         self.kept_history = []
+        idx = self.data_idxs
         for sid, stage in enumerate(self.strategy):
-            assert bool(torch.all(self.data_idxs_all[self.data_idxs]))
-            self.img_feat = self.img_feat_all[self.data_idxs]
-            for n in PARAM_DIMS:
-                setattr(self, n, self.prev_params[n][self.data_idxs].clone())
-            self._gather()
-            res = self.sub_network_list[sid](torch.cat([self.img_feat, self.final_params], dim=1))
+            feat, prev, prev_loss = self.img_feat_all[idx], self.prev_final[idx], self.prev_loss[idx]
+            res = self.sub_network_list[sid](torch.cat([feat, prev], dim=1))
+            new = prev.clone()
             o = 0
-            for n in stage["update_params"]:
-                setattr(self, n, getattr(self, n) + res[:, o:o + PARAM_DIMS[n]])
+            for n in stage["update_params"]:           # mlp_model.py:459-472
+                new[:, COLS[n]] += res[:, o:o + PARAM_DIMS[n]]
                 o += PARAM_DIMS[n]
-            self._gather()
-            self._forward_mano_and_losses()
-            self._select_better_params(stage)
-            self.kept_history.append(self.kept.clone())
-            self._save_prev()
-        self._forward_mano_and_losses()
+            new_loss = self._forward_mano_and_losses(new)
+            # select_better_params (mlp_model.py:592-637): keep the update of a sample only if every filter loss got
+            # strictly better than prev * (1 + pct/100) and the select loss did not get worse
+            ok = torch.ones(self.batch_size, dtype=torch.bool, device=self.device)
+            for name, pct in stage["filter_loss"]:
+                c = LOSS_SLOT[name]
+                ok &= new_loss[:, c] < prev_loss[:, c] * (1 + float(pct) / 100)
+            c = LOSS_SLOT[stage["select_loss"]]
+            ok &= new_loss[:, c] <= prev_loss[:, c]
+            final = torch.where(ok[:, None], new, prev)     # rejected samples fall back to their previous parameters
+            loss = torch.where(ok[:, None], new_loss, prev_loss)
+            self.kept_history.append(ok)
+            self._save_prev(final, loss)
+        self.final_params = final
+        self.collision_loss_batch = self._forward_mano_and_losses(final)[:, 2].clone()
+        for n, sl in COLS.items():
+            setattr(self, n, final[:, sl])
         c = self._core.buf
         self.pred_right_hand_verts, self.pred_left_hand_verts = c["verts"][0], c["verts"][1]
         self.pred_joints_3d, self.collision_loss_origin_scale = c["joints_3d"], c["coll_origin_scale"]
