@@ -40,7 +40,7 @@ def make_opt(B, epoch, freq, rank):
                                  optimizer="adam", opt_epoch=epoch)
 
 
-def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=16, iters_per_stage=4):
+def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=32, iters_per_stage=8):
     """The oracle (kind "port": same op graph as the reference -- torch LBS + losses + torch.optim.Adam,
     dense 32^3 voxel SDF in C/OpenMP) on the first `n_samples` samples of the same batch for
     `iters_per_stage` iterations per stage, extrapolated linearly to the full iteration count
