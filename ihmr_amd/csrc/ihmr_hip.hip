@@ -13,6 +13,7 @@
 #include "sdf_collision.h"
 #include "refine.h"
 #include "encoder.h"
+#include "evaluate.h"
 
 static ihmr_kernel_timer* g_timer = nullptr;
 struct TimedPair { hipEvent_t a, b; double flops; };
@@ -477,6 +478,15 @@ extern "C" int ihmr_avgpool_relu(const float* x, float* y, int N, int HW, int C,
 }
 
 // ------------------------------------------------------------------------------------------ misc
+// ------------------------------------------------------------------------------------------ evaluator
+extern "C" int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_joints_3d, const float* coll_origin_scale,
+                                 const float* sample_scale, const unsigned char* interacting, int B, double* out6, void* stream) {
+    if (!pred_joints_3d || !gt_joints_3d || !coll_origin_scale || !out6 || B <= 0) return -1;
+    hipLaunchKernelGGL(eval_metrics_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pred_joints_3d, gt_joints_3d, coll_origin_scale,
+                       sample_scale, interacting, B, out6);
+    return (int)hipGetLastError();
+}
+
 extern "C" int ihmr_set_kernel_timer(ihmr_kernel_timer* t) {
     g_timer = t;
     return 0;

@@ -5,6 +5,11 @@
 ``evaluator.py:38-97``; the four reported metrics are ``mpjpe_3d``, ``inter_mpjpe_3d``, ``collision_ave``,
 ``collision_max`` (``evaluator.py:149-181``, printed by ``optimize.py:98-102``).  For multi-GPU runs
 ``metric_sums()`` returns the additive form that :func:`ihmr_amd.dist.reduce_metrics` all-reduces.
+
+``Evaluator.update_device(...)`` is the same arithmetic on the GPU (``ihmr_eval_metrics``): it takes
+the DEVICE tensors of a model (no export to numpy), leaves (B,6) float64 partial results on the device and only
+adds them up when the metrics are asked for -- the per-sample Python loop and the 1 MB/batch device-to-host copies
+of ``get_pred_result()`` drop out of a throughput run.
 """
 from __future__ import annotations
 
@@ -47,9 +52,35 @@ class Evaluator:
         self.right_hand_faces = None if mano_models is None else mano_models["right"].faces
         self.data_list = data_list or {}
         self.pred_results = []
+        self._device_parts = []        # (B,6) float64 device tensors + keep masks, summed lazily
 
     def clear(self):
         self.pred_results = []
+        self._device_parts = []
+
+    def update_device(self, pred_joints_3d, gt_joints_3d, collision_loss_origin_scale, keep=None, interacting=None, scale=None):
+        """Metrics of one batch straight from device tensors: pred_joints_3d (B,42,3), gt_joints_3d (B,42,4),
+        collision_loss_origin_scale (B,1556); ``keep`` (B) bool masks out padding duplicates (evaluator.py:137-146),
+        ``interacting`` (B) bool = hand_type == 'interacting' (default all), ``scale`` (B) (default 1)."""
+        import ctypes as C
+
+        import torch
+
+        from . import hip
+        hip.require_gpu()
+        B, dev = pred_joints_3d.shape[0], pred_joints_3d.device
+        f = lambda t: t.detach().to(dev, torch.float32).contiguous()
+        p, g, c = f(pred_joints_3d), f(gt_joints_3d), f(collision_loss_origin_scale)
+        sc = None if scale is None else f(scale)
+        it = None if interacting is None else interacting.to(dev, torch.uint8).contiguous()
+        out = torch.empty(B, 6, device=dev, dtype=torch.float64)
+        hip.check(hip.lib().ihmr_eval_metrics(p.data_ptr(), g.data_ptr(), c.data_ptr(), None if sc is None else sc.data_ptr(),
+                                              None if it is None else it.data_ptr(), B, out.data_ptr(), hip.stream_ptr()), "ihmr_eval_metrics")
+        n_inter = torch.ones(B, device=dev, dtype=torch.float64) if it is None else it.to(torch.float64)
+        part = torch.cat([out, n_inter[:, None]], dim=1)      # [.., n_interacting]
+        if keep is not None:
+            part = part * keep.to(dev, torch.float64)[:, None]
+        self._device_parts.append(part)
 
     def gather_pred(self, pred_results):
         self.pred_results += pred_results
@@ -87,7 +118,12 @@ class Evaluator:
         ca = [np.mean(p["collision_loss_origin_scale"].astype(np.float64)) * 1000 for p in inter]
         cm = [np.max(p["collision_loss_origin_scale"].astype(np.float64)) * 1000 for p in inter]
         f64 = lambda x: float(np.sum(np.asarray(x, dtype=np.float64)))
-        return np.array([f64(e), len(e), f64(pa), len(pa), f64(ca), f64(cm), len(inter)], dtype=np.float64)
+        sums = np.array([f64(e), len(e), f64(pa), len(pa), f64(ca), f64(cm), len(inter)], dtype=np.float64)
+        if self._device_parts:
+            import torch
+            dsum = torch.stack([p.sum(dim=0) for p in self._device_parts]).sum(dim=0).cpu().numpy()
+            sums = sums + dsum
+        return sums
 
     @staticmethod
     def metrics_from_sums(s):

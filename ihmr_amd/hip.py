@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "ihmr_mano_lbs_bwd",
     "ihmr_sdf_workspace_bytes", "ihmr_sdf_collision", "ihmr_sdf_dense_grid", "ihmr_opt_workspace_bytes",
     "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_opt_sdf_stats", "ihmr_opt_stage_graph_create",
-    "ihmr_opt_forward_graph_create", "ihmr_graph_launch", "ihmr_graph_destroy", "ihmr_opt_set_params", "ihmr_conv_igemm", "ihmr_maxpool3x3s2",
+    "ihmr_opt_forward_graph_create", "ihmr_graph_launch", "ihmr_graph_destroy", "ihmr_opt_set_params", "ihmr_eval_metrics", "ihmr_conv_igemm", "ihmr_maxpool3x3s2",
     "ihmr_avgpool_relu", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
 ]
 
@@ -102,6 +102,7 @@ def lib():
         L.ihmr_opt_forward_graph_create.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(vp)]
         L.ihmr_graph_launch.argtypes = [vp, vp]
         L.ihmr_opt_set_params.argtypes = [C.POINTER(OptIO), vp, i, vp]
+        L.ihmr_eval_metrics.argtypes = [vp, vp, vp, vp, vp, i, vp, vp]
         L.ihmr_graph_destroy.argtypes = [vp]
         L.ihmr_conv_igemm.argtypes = [vp, vp, vp, vp, vp] + [i] * 16 + [vp, C.c_size_t, vp]
         L.ihmr_maxpool3x3s2.argtypes = [vp, vp, i, i, i, i, i, i, vp]

@@ -32,6 +32,9 @@ def main(argv=None):
     ap.add_argument("--save_mid_freq", type=int, default=10)
     ap.add_argument("--strategy", type=str, default="opt_default")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--host_eval", action="store_true",
+                    help="evaluate with the host (numpy) Evaluator on get_pred_result() exports, as the reference does; "
+                         "default: metrics on the device (ihmr_eval_metrics), no export")
     ap.add_argument("--fuse_batches", type=int, default=1,
                     help="consecutive batches carried by one launch sequence (per-sample results identical to separate batches)")
     args = ap.parse_args(argv)
@@ -65,11 +68,15 @@ def main(argv=None):
         mdl.set_input(data)
         mdl.init_optimize()
         mdl.optimize(done, n_batches, verbose=False)
-        pred = mdl.get_pred_result()
-        n0 = len(evaluator.pred_results)
-        evaluator.update(sel, pred)
-        new = evaluator.pred_results[n0:]
-        evaluator.pred_results = evaluator.pred_results[:n0] + [p for p, k in zip(new, ~pad) if k]   # drop padding duplicates
+        if args.host_eval:
+            pred = mdl.get_pred_result()
+            n0 = len(evaluator.pred_results)
+            evaluator.update(sel, pred)
+            new = evaluator.pred_results[n0:]
+            evaluator.pred_results = evaluator.pred_results[:n0] + [p for p, k in zip(new, ~pad) if k]   # drop padding duplicates
+        else:
+            evaluator.update_device(mdl.pred_joints_3d, mdl.buf["gt_joints_3d"], mdl.collision_loss_origin_scale,
+                                    keep=torch.from_numpy(~pad))
         done += g
     sums = D.reduce_metrics(evaluator.metric_sums())
     elapsed = time.time() - t0

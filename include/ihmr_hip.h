@@ -180,6 +180,15 @@ int ihmr_conv_igemm(const float* x, const float* w, const float* bias, const flo
 int ihmr_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int ihmr_avgpool_relu(const float* x, float* y, int N, int HW, int C, int ldy, void* stream);
 
+/* ------------------------------------------------------------------ evaluation metrics */
+/* Per-sample partial results of the four metrics `optimize.py:98-102` prints (utils/metric_utils.py:23-38,107-143,
+ * utils/evaluator.py:149-181), computed on the device from what `get_pred_result()` would export:
+ * pred_joints_3d (B,42,3), gt_joints_3d (B,42,4) [xyz, weight], coll_origin_scale (B,1556) [m];
+ * sample_scale (B) or NULL (= 1), interacting (B) bytes or NULL (= all interacting).
+ * out6 (B,6) float64: [sum MPJPE errors, count, sum aligned errors, count, mean depth mm, max depth mm]. */
+int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_joints_3d, const float* coll_origin_scale,
+                      const float* sample_scale, const unsigned char* interacting, int B, double* out6, void* stream);
+
 /* per-kernel timing hook for bench.py: when non-NULL, the library records hipEvents around the
  * dominant kernel on `stream` and accumulates (count, ms) here; host pointer, read after sync */
 typedef struct ihmr_kernel_timer { double ms_sdf_eval; long n_sdf_eval; double algo_flops_sdf_eval; } ihmr_kernel_timer;

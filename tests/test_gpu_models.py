@@ -128,3 +128,45 @@ def test_run_optimize_fused_batches_same_metrics():
     m2 = run_optimize.main(base + ["--fuse_batches", "2"])
     for k in ("mpjpe_3d", "inter_mpjpe_3d", "collision_ave", "collision_max"):
         assert m1[k] == m2[k], (k, m1[k], m2[k])
+
+
+def test_device_evaluator_matches_host_evaluator():
+    """`ihmr_eval_metrics` against the host Evaluator (itself pinned to the reference by
+    tests/golden/metrics.npz): random predictions with missing joints, a missing root, a sample with a single valid
+    joint (no aligned error), non-interacting samples and masked-out padding duplicates."""
+    from ihmr_amd.evaluator import Evaluator
+    rng = np.random.RandomState(3)
+    B = 9
+    pred = rng.randn(B, 42, 3).astype(np.float32) * 0.05
+    gt = np.concatenate([pred + rng.randn(B, 42, 3).astype(np.float32) * 0.01, np.ones((B, 42, 1), np.float32)], 2)
+    gt[1, 5:9, 3] = 0; gt[2, 0, 3] = 0; gt[3, 21, 3] = 0; gt[4, :, 3] = 0; gt[4, 7, 3] = 1; gt[5, 21:, 3] = 0
+    coll = np.abs(rng.randn(B, 1556)).astype(np.float32) * 1e-3 * (rng.rand(B, 1556) > 0.7)
+    inter = np.array([1, 1, 0, 1, 1, 1, 0, 1, 1], bool)
+    keep = np.array([1, 1, 1, 1, 1, 1, 1, 0, 1], bool)
+    host = Evaluator()
+    for i in range(B):
+        if not keep[i]:
+            continue
+        host.update([i], dict(pred_cam_params=np.zeros((1, 3)), pred_shape_params=np.zeros((1, 20)), pred_pose_params=np.zeros((1, 96)),
+                              pred_hand_trans=np.zeros((1, 1, 3)), pred_joints_3d=pred[i:i + 1], gt_joints_3d=gt[i:i + 1],
+                              collision_loss_origin_scale=coll[i:i + 1]), hand_type="interacting" if inter[i] else "right")
+    ref = host.metric_sums()
+    dev = Evaluator()
+    t = lambda x: torch.from_numpy(x).cuda()
+    dev.update_device(t(pred), t(gt), t(coll), keep=torch.from_numpy(keep), interacting=torch.from_numpy(inter))
+    got = dev.metric_sums()
+    print("[parity] metric sums host", ref.tolist(), "device", got.tolist())
+    assert got[1] == ref[1] and got[3] == ref[3] and got[6] == ref[6], "counts differ"
+    np.testing.assert_allclose(got[[0, 2, 4, 5]], ref[[0, 2, 4, 5]], rtol=2e-6)
+    m_ref, m_got = Evaluator.metrics_from_sums(ref), Evaluator.metrics_from_sums(got)
+    for k in m_ref:
+        assert abs(m_ref[k] - m_got[k]) <= 2e-6 * abs(m_ref[k]) + 1e-9, (k, m_ref[k], m_got[k])
+
+
+def test_run_optimize_device_and_host_eval_agree():
+    from ihmr_amd import run_optimize
+    base = ["--num_samples", "20", "--batchSize", "8", "--opt_epoch", "2", "--save_mid_freq", "1"]   # 20 -> padded to 24
+    m_dev = run_optimize.main(base)
+    m_host = run_optimize.main(base + ["--host_eval"])
+    for k in ("mpjpe_3d", "inter_mpjpe_3d", "collision_ave", "collision_max"):
+        assert abs(m_dev[k] - m_host[k]) <= 2e-6 * abs(m_host[k]) + 1e-9, (k, m_dev[k], m_host[k])
