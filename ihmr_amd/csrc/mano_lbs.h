@@ -647,8 +647,12 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
                     accJ += bw.drel[j][r];
                 }
             }
-            bw.dG[p][e] += acc;
-            if (c == 3) bw.dJ[p][r] -= accJ;
+            // only joints that gathered something touch their rows: the threads below update dJ of the depth-d joints
+            // in this same phase, and an unconditional "-= 0" here would race with them (lost update)
+            if (nc > 0) {
+                bw.dG[p][e] += acc;
+                if (c == 3) bw.dJ[p][r] -= accJ;
+            }
         }
         if (tid >= 192 && tid < 192 + NJ * 3) {
             const int j = (tid - 192) / 3, c = (tid - 192) % 3;

@@ -35,6 +35,8 @@ def main(argv=None):
     ap.add_argument("--host_eval", action="store_true",
                     help="evaluate with the host (numpy) Evaluator on get_pred_result() exports, as the reference does; "
                          "default: metrics on the device (ihmr_eval_metrics), no export")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="model instances driven side by side on their own HIP streams (the hardware runs 4 compute queues)")
     ap.add_argument("--fuse_batches", type=int, default=1,
                     help="consecutive batches carried by one launch sequence (per-sample results identical to separate batches)")
     args = ap.parse_args(argv)
@@ -47,8 +49,12 @@ def main(argv=None):
                                 shape_params_dim=20, trans_params_dim=3, model_root="", strategy=args.strategy,
                                 save_mid_freq=args.save_mid_freq, optimizer="adam", opt_epoch=args.opt_epoch)
     model = OptimizeModel(opt)
-    G = max(1, args.fuse_batches)
-    model_g = model if G == 1 else OptimizeModel(types.SimpleNamespace(**vars(opt), fuse_batches=G))
+    G, S = max(1, args.fuse_batches), max(1, args.streams)
+    # one model instance (own buffers, workspace, graphs) per stream; `model` doubles as the first single-batch instance
+    fused = [model if (G == 1 and i == 0) else OptimizeModel(types.SimpleNamespace(**vars(opt), fuse_batches=G)) for i in range(S)]
+    singles = [model] + [None] * (S - 1)                                      # remainder of fewer than G batches: batch by batch
+    main_stream = torch.cuda.current_stream()
+    streams = [torch.cuda.Stream() for _ in range(S)] if S > 1 else [main_stream]
     evaluator = Evaluator(model.mano_models)
     fwd = lambda p, s, t: two_hand.forward_from_packed(model.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
 
@@ -58,26 +64,48 @@ def main(argv=None):
     t0 = time.time()
     done = 0
     while done < n_batches:
-        g = G if n_batches - done >= G else 1          # a remainder of fewer than G batches runs batch by batch
-        s0 = done * Bsz
-        sel, pad = idx[s0:s0 + g * Bsz], is_pad[s0:s0 + g * Bsz]
-        # the synthetic "dataset": sample i is generated from seed + i's batch; padding entries repeat sample 0's batch row
-        parts = [synthetic_opt_batch(Bsz, fwd, seed=args.seed + int(sel[q * Bsz]), first_index=int(sel[q * Bsz])) for q in range(g)]
-        data = parts[0] if g == 1 else {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
-        mdl = model_g if g == G else model
-        mdl.set_input(data)
-        mdl.init_optimize()
-        mdl.optimize(done, n_batches, verbose=False)
-        if args.host_eval:
-            pred = mdl.get_pred_result()
-            n0 = len(evaluator.pred_results)
-            evaluator.update(sel, pred)
-            new = evaluator.pred_results[n0:]
-            evaluator.pred_results = evaluator.pred_results[:n0] + [p for p, k in zip(new, ~pad) if k]   # drop padding duplicates
-        else:
-            evaluator.update_device(mdl.pred_joints_3d, mdl.buf["gt_joints_3d"], mdl.collision_loss_origin_scale,
-                                    keep=torch.from_numpy(~pad))
-        done += g
+        jobs = []                                       # up to S launch sequences in flight
+        for i in range(S):
+            if done >= n_batches:
+                break
+            g = G if n_batches - done >= G else 1
+            s0 = done * Bsz
+            sel, pad = idx[s0:s0 + g * Bsz], is_pad[s0:s0 + g * Bsz]
+            # the synthetic "dataset": sample i is generated from seed + i's batch; padding entries repeat sample 0's batch row
+            parts = [synthetic_opt_batch(Bsz, fwd, seed=args.seed + int(sel[q * Bsz]), first_index=int(sel[q * Bsz])) for q in range(g)]
+            data = parts[0] if g == 1 else {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
+            if g == G:
+                mdl = fused[i]
+            else:
+                if singles[i] is None:
+                    singles[i] = OptimizeModel(opt)
+                mdl = singles[i]
+            jobs.append((mdl, streams[i], data, sel, pad))
+            done += g
+        for mdl, st, data, _, _ in jobs:
+            st.wait_stream(main_stream)                 # the synthetic data was produced on the caller's stream
+            with torch.cuda.stream(st):
+                mdl.set_input(data)
+                mdl.init_optimize()
+        for stage in model.strategy:                    # stage by stage over the jobs: every stream stays fed
+            for mdl, st, *_ in jobs:
+                with torch.cuda.stream(st):
+                    mdl.run_stage(stage)
+        for mdl, st, _, sel, pad in jobs:
+            with torch.cuda.stream(st):
+                mdl.forward_losses(mdl.default_loss_weights)
+                if args.host_eval:
+                    pred = mdl.get_pred_result()
+                    n0 = len(evaluator.pred_results)
+                    evaluator.update(sel, pred)
+                    new = evaluator.pred_results[n0:]
+                    evaluator.pred_results = evaluator.pred_results[:n0] + [p for p, k in zip(new, ~pad) if k]   # drop padding duplicates
+                else:
+                    evaluator.update_device(mdl.pred_joints_3d, mdl.buf["gt_joints_3d"], mdl.collision_loss_origin_scale,
+                                            keep=torch.from_numpy(~pad))
+        for _, st, *_ in jobs:
+            main_stream.wait_stream(st)                 # the next round's data generation reuses the instances' MANO handles
+    torch.cuda.synchronize()
     sums = D.reduce_metrics(evaluator.metric_sums())
     elapsed = time.time() - t0
     if rank == 0:

@@ -126,8 +126,10 @@ def test_run_optimize_fused_batches_same_metrics():
     base = ["--num_samples", "24", "--batchSize", "8", "--opt_epoch", "2", "--save_mid_freq", "1"]
     m1 = run_optimize.main(base)
     m2 = run_optimize.main(base + ["--fuse_batches", "2"])
+    m3 = run_optimize.main(base + ["--fuse_batches", "2", "--streams", "2"])
+    m4 = run_optimize.main(base + ["--streams", "3"])
     for k in ("mpjpe_3d", "inter_mpjpe_3d", "collision_ave", "collision_max"):
-        assert m1[k] == m2[k], (k, m1[k], m2[k])
+        assert m1[k] == m2[k] == m3[k] == m4[k], (k, m1[k], m2[k], m3[k], m4[k])
 
 
 def test_device_evaluator_matches_host_evaluator():

@@ -305,49 +305,20 @@ def test_opt_fused_batches_are_bit_identical(mano_arrays):
 
 
 def test_opt_replay_is_deterministic(mano_arrays):
-    """A model instance is reused batch after batch (``src/optimize.py`` loop): the second pass replays the cached
-    stage graphs on the same (default) stream and must reproduce the first pass bit for bit."""
+    """A model instance is reused batch after batch (``src/optimize.py`` loop): later passes replay the cached stage
+    graphs on the same (default) stream and must reproduce the first pass bit for bit -- and so must a second
+    instance.  Batch 64 x 40 iterations on purpose: a lost update between two threads of the chain backward once
+    made the shape stage differ from run to run, and it only showed at this size."""
     from ihmr_amd.optimize_model import OptimizeModel
-    B = 8
+    B = 64
     _, batch = _two_hand_verts(mano_arrays, B, 21)
-    model = OptimizeModel(_make_opt(B, epoch=3, save_mid_freq=2))
+    models = [OptimizeModel(_make_opt(B, epoch=9, save_mid_freq=5)) for _ in range(2)]
     outs = []
-    for _ in range(3):
+    for r in range(5):
+        model = models[r // 4]
         model.set_input(batch); model.init_optimize(); model.optimize()
         torch.cuda.synchronize()
         outs.append(model.get_pred_result())
     for k in ("pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "collision_loss_origin_scale"):
-        assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[0][k], outs[2][k]), k
-
-
-def test_opt_ragged_batch_mixed_hand_types_and_separated_hands(mano_arrays):
-    """Edge cases of the domain in one odd-sized batch (B = 5, not a multiple of the 8-hand tiles or of the XCD
-    count): sample 1 is a right-hand-only sample, sample 3 left-hand-only (collision term masked, origin-scale
-    values kept, loss_utils.py:186-189), sample 2 has its hands pulled 0.5 m apart (no voxel of either hand is
-    inside the other: empty work list for that sample), samples with missing 2D/3D joint annotations (weight 0)
-    and the alternative root (weight of joint 0 below 1e-7 -> align on joint 21).  Full refinement vs the oracle."""
-    B, epoch, freq = 5, 3, 2
-    orc, model, batch = _oracle_and_model(mano_arrays, B, epoch, freq, seed=77)
-    batch = {k: v.clone() for k, v in batch.items()}
-    batch["hand_type_array"][1] = torch.tensor([1.0, 0.0])
-    batch["hand_type_array"][3] = torch.tensor([0.0, 1.0])
-    batch["init_hand_trans"][2, 0, :3] = torch.tensor([0.5, 0.0, 0.0])
-    batch["init_joints_2d"][0, 5:9, 2] = 0.0          # unannotated joints
-    batch["init_joints_3d"][4, 30:, 3] = 0.0
-    batch["init_joints_3d"][1, 0, 3] = 0.0            # root weight < 1e-7: the left wrist (joint 21) becomes the root
-    orc.set_input(batch); orc.init_optimize(); orc.optimize()
-    model.set_input(batch); model.init_optimize(); model.optimize()
-    torch.cuda.synchronize()
-    r, g = orc.get_pred_result(), model.get_pred_result()
-    sel_ref, sel_got = np.stack(orc.selected), torch.stack(model.selected_history).cpu().numpy()
-    print(f"[parity] ragged batch: selection ref={sel_ref.tolist()} got={sel_got.tolist()}")
-    assert np.array_equal(sel_ref, sel_got)
-    assert float(np.abs(g["collision_loss"][[1, 3]]).max()) == 0.0, "single-hand samples carry no collision loss"
-    assert float(np.abs(g["collision_loss_origin_scale"][2]).max()) == 0.0, "separated hands do not penetrate"
-    _report("ragged pose", g["pred_pose_params"], r["pred_pose_params"], atol=2e-4)
-    _report("ragged shape", g["pred_shape_params"], r["pred_shape_params"], atol=2e-4)
-    _report("ragged trans", g["pred_hand_trans"], r["pred_hand_trans"], atol=2e-5)
-    _report("ragged right verts [m]", g["pred_right_hand_verts"], r["pred_right_hand_verts"], atol=1e-4)
-    _report("ragged left verts [m]", g["pred_left_hand_verts"], r["pred_left_hand_verts"], atol=1e-4)
-    _report("ragged collision loss", g["collision_loss"], r["collision_loss"], atol=1e-5, rtol=1e-4)
-    _report("ragged penetration depth [m]", g["collision_loss_origin_scale"], r["collision_loss_origin_scale"], atol=1e-4)
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][k], o[k]), k
