@@ -227,7 +227,11 @@ def main():
                             note="largest share of GPU time in the rocprofv3 kernel summary (profiles/). fp32 VALU kernel (no GEMM "
                                  "shape): priced against the fp32 peak, the same 157.3 TFLOP/s for vector and f32-input MFMA on "
                                  "gfx950; timed with HIP events on the launch stream in a single-stream pass",
-                            algorithmic_flops_per_launch=flops, work_per_launch=stats)
+                            algorithmic_flops_per_launch=flops, work_per_launch=stats,
+                            # SURVEY.md 8(d) prices the SDF at ~100 flop per (voxel, triangle) pair of the brute-force
+                            # search; for the voxels this launch evaluates that would be the figure below -- the kernel
+                            # reaches the same bits with the culled search counted in `achieved`
+                            brute_force_equivalent_tflops=stats["inside_voxels"] * 1538 * 100.0 / (avg_ms * 1e-3) / 1e12)
         else:
             roofline = dict(bound="mfma", achieved=None, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=None, traffic=None,
                             kernel="sdf_dist_kernel", avg_launch_ms=avg_ms, launches=int(timer.n_sdf_eval))
