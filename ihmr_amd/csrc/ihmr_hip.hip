@@ -165,11 +165,12 @@ static void lbs_forward_launch(const ihmr_mano* m, bool two_hand, const float* o
 static void lbs_backward_launch(const ihmr_mano* m, bool two_hand, int N, int B, const float* d_verts, const float* d_joints,
                                 float* d_orient, float* d_pose, float* d_betas, float* d_trans, int need_mask, const LbsWork& wk,
                                 hipStream_t st) {
+    const size_t part_lds = (size_t)m->nseg * 12 * sizeof(float);
     if (two_hand)
-        hipLaunchKernelGGL(lbs_bwd1_kernel<true>, dim3(N), dim3(LBS_THREADS), 0, st, *m, wk, B, d_verts, d_joints, d_orient,
+        hipLaunchKernelGGL(lbs_bwd1_kernel<true>, dim3(N), dim3(LBS_THREADS), part_lds, st, *m, wk, B, d_verts, d_joints, d_orient,
                            d_betas, d_trans, need_mask);
     else
-        hipLaunchKernelGGL(lbs_bwd1_kernel<false>, dim3(N), dim3(LBS_THREADS), 0, st, *m, wk, B, d_verts, d_joints, d_orient,
+        hipLaunchKernelGGL(lbs_bwd1_kernel<false>, dim3(N), dim3(LBS_THREADS), part_lds, st, *m, wk, B, d_verts, d_joints, d_orient,
                            d_betas, d_trans, need_mask);
     if (need_mask & 2) {
         hipLaunchKernelGGL(lbs_bwd2_kernel, dim3(5, (N + 31) / 32, LBS_KG), dim3(64), 0, st, *m, wk, N);

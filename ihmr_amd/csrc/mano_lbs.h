@@ -401,19 +401,21 @@ struct LbsBwdShared {
     float gsum[3];        // TWO_HAND: sum of the left-hand output gradients (= d L / d shift)
     float gj[21][3];      // joint gradients (raw hand frame)
     float red[LBS_THREADS];
-    float part[LBS_SEG_CAP][12];  // per-segment partial sums of dA
     int par[NJ], dep[NJ];         // kinematic tree (parents, depth), staged once: the chain loops read them many times
     int nchild[NJ], child[NJ][NJ];  // children of every joint in index order (built in-kernel from par)
     float wsum[LBS_THREADS / WAVE][4];
 };
 
+// dynamic LDS: float part[nseg][12] -- per-segment partial sums of dA (nseg is a property of the weight matrix:
+// 248 for 4 bones per vertex, up to LBS_SEG_CAP if dense); with it the workgroup needs ~49 KB, three fit a CU
 template <bool TWO_HAND>
-__global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsWork wk, int B,
+__global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, LbsWork wk, int B,
                                                                const float* __restrict__ d_verts,
                                                                const float* __restrict__ d_joints,
                                                                float* __restrict__ d_orient, float* __restrict__ d_betas,
                                                                float* __restrict__ d_trans, int need_mask) {
     __shared__ LbsBwdShared bw;
+    extern __shared__ __attribute__((aligned(16))) float bwd1_part[];   // [nseg][12]
     const int h = blockIdx.x, tid = threadIdx.x;
     const bool left = TWO_HAND && h >= B;
     const int b = TWO_HAND ? (left ? h - B : h) : 0;
@@ -531,8 +533,8 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
         float T[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+#pragma unroll 4
+        for (int j = 0; j < NJ; ++j) {   // 4 joints' rows in flight: unrolled further the LDS reads alone take ~190 VGPRs
             const float4* A4 = reinterpret_cast<const float4*>(sA + 12 * j);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -587,14 +589,14 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_bwd1_kernel(ihmr_mano m, LbsW
             }
         }
 #pragma unroll
-        for (int e = 0; e < 12; ++e) bw.part[sg][e] = acc[e];
+        for (int e = 0; e < 12; ++e) bwd1_part[sg * 12 + e] = acc[e];
     }
     __syncthreads();
     if (tid < NJ * 12) {
         const int j = tid / 12, e = tid % 12;
         float acc = 0.f;
         const int s1 = m.jseg_start[j + 1];
-        for (int sg = m.jseg_start[j]; sg < s1; ++sg) acc += bw.part[sg][e];
+        for (int sg = m.jseg_start[j]; sg < s1; ++sg) acc += bwd1_part[sg * 12 + e];
         bw.dA[j][e] = acc;
     }
     __syncthreads();
