@@ -21,7 +21,6 @@
 #define SDF_THREADS 256
 #define SDF_PREP_THREADS 1024
 #define SDF_NCOL (SDF_G * SDF_G)   // 1024 columns (k,j)
-#define SDF_BIN_CAP 32768          // (triangle, column) pairs per hand before falling back to a full scan
 #define SDF_EVAL_CHUNKS 8          // workgroups per hand in the parity kernel
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
 #ifndef SDF_DIST_BLOCKS
@@ -30,24 +29,21 @@
 #define SDF_SURV_CAP 512             // LDS slots per wave for the triangles surviving the sphere cull (typically ~40)
 #define SDF_ITEM 16                // inside voxels per work item of the distance kernel (one hand per item); power of two
 
-// Per-hand, per-iteration triangle tables (float4 records, so a random triangle costs one or three
-// 16 B loads instead of a cache line per SoA row):
-//   sph[f] = (centroid xyz, bounding radius; radius < 0 marks padding)
-//   par[f] = {ay, az, e1y, e1z} {e2y, e2z, 1/det (NaN = degenerate), ax} {e1x, e2x, 0, 0}   (+x ray test)
+// Per-hand, per-iteration triangle tables:
+//   sph[f] = (-2 cx, -2 cy, -2 cz, |c|^2) of the bounding sphere about the centroid c: the squared distance of a
+//            point p to c is |p|^2 + dot((p,1), sph[f]) -- three FMAs instead of three subtractions and three FMAs
+//            (the distance kernel uses it only for conservative culling, with a margin for the cancellation);
+//            padding triangles are parked at 1e18, so arithmetic alone culls them
+//   rad[f] = bounding radius (conservative)
 //   abc[f] = {a,0} {b,0} {c,0}                                                           (exact distance)
 struct SdfWorkspace {          // carved from the caller's workspace; H = 2B hands, hand id = hnd*B + b
     float* box;                // [H][4]  centre xyz, scale
     float4* sph;               // [H][NFP]
-    float4* par;               // [H][NFP][3]
+    float* rad;                // [H][NFP]
     float4* abc;               // [H][NFP][3]
-    float* phi;                // [H][32768]  (only `needed` entries are defined)
-    unsigned* needed;          // [H][1024] bitmask over i per column (k*32+j)
-    int* col_off;              // [H][1028] start of each column's triangle list (exclusive prefix)
-    unsigned short* col_tris;  // [H][SDF_BIN_CAP] triangle ids binned by column
-    unsigned short* vox_list;  // [H][32768] needed voxels, id = col*32 + i
-    int* counts;               // [H][4]: 0 = #needed voxels, 1 = #binned pairs (> SDF_BIN_CAP => overflow)
-    unsigned* inside_list;     // [8][xcd_cap] inside voxels per XCD: (hand << 16) | voxel id
-    int* inside_count;         // [8]
+    float* phi;                // [H][32768]  (only the voxels a sample reads are defined)
+    unsigned* inside_list;     // [xcd_cap] inside voxels of the whole batch: (hand << 16) | voxel id, 16-aligned run per hand
+    int* inside_count;         // [8] (slot 0 in use)
     unsigned long long* stats; // [8] optional work counters
     int xcd_cap;
 };
@@ -57,14 +53,10 @@ __host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)H * (SDF_N
 __host__ __device__ inline size_t sdf_ws_bytes(int H) {
     size_t n = 0;
     n += (size_t)H * 4 * sizeof(float);
-    n += (size_t)H * NFP * 7 * sizeof(float4);
+    n += (size_t)H * NFP * 4 * sizeof(float4);      // sph + abc
+    n += (size_t)H * NFP * sizeof(float);           // rad
     n += (size_t)H * SDF_NVOX * sizeof(float);
-    n += (size_t)H * SDF_NCOL * sizeof(unsigned);
-    n += (size_t)H * 1028 * sizeof(int);
-    n += (size_t)H * 4 * sizeof(int);
     n += sdf_xcd_cap(H) * sizeof(unsigned);
-    n += (size_t)H * SDF_BIN_CAP * sizeof(unsigned short);
-    n += (size_t)H * SDF_NVOX * sizeof(unsigned short);
     n += 128 + 256;
     return (n + 255) & ~(size_t)255;
 }
@@ -74,18 +66,13 @@ static inline SdfWorkspace sdf_carve(void* ws, int H) {
     char* p = (char*)ws;
     w.box = (float*)p; p += (size_t)H * 4 * sizeof(float);
     w.sph = (float4*)p; p += (size_t)H * NFP * sizeof(float4);
-    w.par = (float4*)p; p += (size_t)H * NFP * 3 * sizeof(float4);
     w.abc = (float4*)p; p += (size_t)H * NFP * 3 * sizeof(float4);
+    w.rad = (float*)p; p += (size_t)H * NFP * sizeof(float);
     w.phi = (float*)p; p += (size_t)H * SDF_NVOX * sizeof(float);
-    w.needed = (unsigned*)p; p += (size_t)H * SDF_NCOL * sizeof(unsigned);
-    w.col_off = (int*)p; p += (size_t)H * 1028 * sizeof(int);
-    w.counts = (int*)p; p += (size_t)H * 4 * sizeof(int);
     w.stats = (unsigned long long*)p; p += 64;
     w.inside_count = (int*)p; p += 64;
     w.xcd_cap = (int)sdf_xcd_cap(H);
-    w.inside_list = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
-    w.col_tris = (unsigned short*)p; p += (size_t)H * SDF_BIN_CAP * sizeof(unsigned short);
-    w.vox_list = (unsigned short*)p;
+    w.inside_list = (unsigned*)p;
     return w;
 }
 
@@ -284,6 +271,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     TSTAMP(22);
     // ---- lane = triangle: records for the distance kernel + ray parity of the needed voxels it can hit
     float4* sph = ws.sph + (size_t)H * NFP;
+    float* rad = ws.rad + (size_t)H * NFP;
     float4* abc = ws.abc + (size_t)H * NFP * 3;
     unsigned long long st_tests = 0;
 #pragma unroll
@@ -311,7 +299,11 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             dx = c[0] - gx; dy = c[1] - gy; dz = c[2] - gz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
         }
         // padding triangles (f >= NF): parked at 1e18 with radius 0, so the distance kernel culls them by arithmetic alone
-        sph[f] = f < NF ? make_float4(gx, gy, gz, sqrtf(r2) * 1.0001f + 1e-6f) : make_float4(1e18f, 1e18f, 1e18f, 0.0f);
+        {
+            const float qx = f < NF ? gx : 1e18f, qy = f < NF ? gy : 1e18f, qz = f < NF ? gz : 1e18f;
+            sph[f] = make_float4(-2.0f * qx, -2.0f * qy, -2.0f * qz, qx * qx + qy * qy + qz * qz);
+            rad[f] = f < NF ? sqrtf(r2) * 1.0001f + 1e-6f : 0.0f;
+        }
 #ifdef IHMR_TIMING
         if (blockIdx.x == 0 && lane == 0) g_dbg[120 + wave + 16 * it] = clock64() - g_dbg[22];
 #endif
@@ -452,6 +444,7 @@ __device__ __forceinline__ float sdf_point_tri_dist2(const float* a, const float
 typedef float sdf_v2f __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace ws, int collect_stats) {
     __shared__ float4 sph_s[NFP];
+    __shared__ float rad_s[NFP];
     __shared__ unsigned short surv[SDF_THREADS / WAVE][SDF_SURV_CAP];
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
     const int slot = blockIdx.x, nslot = gridDim.x;
@@ -467,7 +460,8 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
         if (H != curH) {             // uniform over the workgroup (same item for all waves)
             __syncthreads();
             const float4* sph = ws.sph + (size_t)H * NFP;
-            for (int f = tid; f < NFP; f += SDF_THREADS) sph_s[f] = sph[f];
+            const float* rad = ws.rad + (size_t)H * NFP;
+            for (int f = tid; f < NFP; f += SDF_THREADS) { sph_s[f] = sph[f]; rad_s[f] = rad[f]; }
             __syncthreads();
             curH = H;
         }
@@ -484,24 +478,30 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
             const sdf_v2f PY = {(float)(2 * ((id0 >> 5) & 31) + 1) / (float)SDF_G - 1.0f,
                                 (float)(2 * ((id1 >> 5) & 31) + 1) / (float)SDF_G - 1.0f};
             const sdf_v2f PZ = {(float)(2 * (id0 >> 10) + 1) / (float)SDF_G - 1.0f, (float)(2 * (id1 >> 10) + 1) / (float)SDF_G - 1.0f};
+            // d2[t] = |p - c|^2 - |p|^2 = dot((p,1), sph): three packed FMAs per triangle and voxel pair.  The
+            // cancellation costs at most ~1e-6 absolute (|p|, |c| <= 2), covered by the margin below: the bound and the
+            // cull stay conservative, the minimum over the survivors is computed exactly afterwards
+            const sdf_v2f P2 = PX * PX + PY * PY + PZ * PZ;
             sdf_v2f d2[NFP / WAVE];
             sdf_v2f ub2 = {INFINITY, INFINITY};
 #pragma unroll
             for (int t = 0; t < NFP / WAVE; ++t) {
-                const float4 sp = sph_s[lane + WAVE * t];   // padding triangles sit at 1e18: never the minimum, always culled
-                const sdf_v2f dx = PX - sp.x, dy = PY - sp.y, dz = PZ - sp.z;
-                d2[t] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                const float4 sp = sph_s[lane + WAVE * t];
+                const sdf_v2f sx = {sp.x, sp.x}, sy = {sp.y, sp.y}, sz = {sp.z, sp.z}, sw = {sp.w, sp.w};
+                d2[t] = __builtin_elementwise_fma(PX, sx, __builtin_elementwise_fma(PY, sy, __builtin_elementwise_fma(PZ, sz, sw)));
                 ub2 = __builtin_elementwise_min(ub2, d2[t]);
             }
-            // the centroid is a point of the triangle: dist <= |p - centroid|
-            const float ub_a = sqrtf(wave_reduce_min(ub2.x)) * 1.0001f + 1e-6f, ub_b = sqrtf(wave_reduce_min(ub2.y)) * 1.0001f + 1e-6f;
+            // the centroid is a point of the triangle: dist <= |p - centroid|   (+ 4e-6 for the cancellation)
+            const float ub_a = sqrtf(fmaxf(wave_reduce_min(ub2.x) + P2.x, 0.0f) + 4e-6f) * 1.0001f + 1e-6f;
+            const float ub_b = sqrtf(fmaxf(wave_reduce_min(ub2.y) + P2.y, 0.0f) + 4e-6f) * 1.0001f + 1e-6f;
             const sdf_v2f ub_lim = {ub_a, ub_b};
+            const sdf_v2f shift = sdf_v2f{4e-6f, 4e-6f} - P2;    // compare in the shifted frame: d2 + |p|^2 - 4e-6 > lim^2
             unsigned keep_a = 0, keep_b = 0;
 #pragma unroll
             for (int t = 0; t < NFP / WAVE; ++t) {
-                const float r = sph_s[lane + WAVE * t].w;
+                const float r = rad_s[lane + WAVE * t];
                 const sdf_v2f lim = ub_lim + r;
-                const sdf_v2f lim2 = lim * lim * 1.00001f;
+                const sdf_v2f lim2 = __builtin_elementwise_fma(lim * lim, sdf_v2f{1.00001f, 1.00001f}, shift);
                 // cull iff |p - centroid| - radius > upper bound (exact: such a triangle cannot be the minimum)
                 keep_a |= !(d2[t].x > lim2.x) ? (1u << t) : 0u;
                 keep_b |= !(d2[t].y > lim2.y) ? (1u << t) : 0u;
