@@ -182,6 +182,7 @@ class InterHandEncoder(nn.Module):
         bufs = [torch.zeros(B, Kp, device=dev) for _ in range(2)]
         conv_igemm(main_feat, P["feat"], B, 1, 1, ldx=1024, out=bufs[0], ldy=Kp, act=1)
         bufs[1][:, :1024].copy_(bufs[0][:, :1024])
+        self.feat = bufs[1][:, :1024]            # networks.py:68 -- the 1024-d image feature the MLP stages consume as `img_feat`
         mp = self.mean_params.to(dev)
         bufs[0][:, 1024:1024 + nparam].copy_(mp if mp.shape[0] == B else mp[:1].expand(B, -1))
         cur = 0

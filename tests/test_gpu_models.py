@@ -172,3 +172,41 @@ def test_run_optimize_device_and_host_eval_agree():
     m_host = run_optimize.main(base + ["--host_eval"])
     for k in ("mpjpe_3d", "inter_mpjpe_3d", "collision_ave", "collision_max"):
         assert abs(m_dev[k] - m_host[k]) <= 2e-6 * abs(m_host[k]) + 1e-9, (k, m_dev[k], m_host[k])
+
+
+def test_baseline_feeds_refinement_on_device_and_through_the_prediction_file(tmp_path):
+    """Baseline predictions -> IHMR-OPT inputs without leaving the device; the same through the
+    reference's prediction-file schema (data_utils.py:42-70) gives bit-identical refinement results."""
+    from helpers import seeded_state_dict
+    from ihmr_amd import pipeline, two_hand
+    from ihmr_amd.baseline_model import InterHandModel
+    from ihmr_amd.optimize_model import OptimizeModel
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    B = 4
+    base = InterHandModel(_opt(B))
+    base.encoder.load_state_dict(seeded_state_dict(base.encoder, 5, last_scale=0.01))
+    base.eval()
+    fwd = lambda p, s, t: two_hand.forward_from_packed(base.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
+    data = synthetic_opt_batch(B, fwd, seed=3, with_image=True)
+    base.set_input(data)
+    base.test()
+    preds = pipeline.predictions_from_baseline(base)
+    assert preds["img_feat"].shape == (B, 1024) and preds["joints_2d"].shape == (B, 42, 2)
+    anno = {k: data[k] for k in ("joints_2d", "joints_3d", "mano_pose", "mano_betas", "mano_params_weight", "hand_trans", "hand_type_array", "index")}
+    names = [f"synthetic/{i:08d}.jpg" for i in range(B)]
+    f = str(tmp_path / "pred.pkl")
+    pipeline.save_pred_file(f, names, preds)
+    back = pipeline.load_pred_file(f, names, device="cuda")
+    for k in pipeline.PRED_KEYS:
+        assert torch.equal(back[k], preds[k]), k
+    o = _opt(B); o.strategy, o.opt_epoch, o.save_mid_freq, o.optimizer = "opt_default", 3, 2, "adam"
+    outs = []
+    for p in (preds, back):
+        m = OptimizeModel(o)
+        m.set_input(pipeline.refinement_batch(p, anno)); m.init_optimize(); m.optimize()
+        torch.cuda.synchronize()
+        outs.append(m.get_pred_result())
+    for k in ("pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_joints_3d", "collision_loss_origin_scale"):
+        assert np.isfinite(outs[0][k]).all() and np.array_equal(outs[0][k], outs[1][k]), k
+    mb = pipeline.refinement_batch(preds, anno, for_mlp=True)
+    assert mb["init_hand_trans"].shape == (B, 3) and mb["img_feat"].shape == (B, 1024)
