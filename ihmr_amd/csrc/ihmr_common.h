@@ -29,6 +29,7 @@
 // the shader clock at named points, read back through ihmr_debug_read
 #ifdef IHMR_TIMING
 __device__ long long g_dbg[256];
+__device__ long long g_blk[2][1024];   // per-workgroup start / end stamps of the kernel under study (wall clock)
 #define TSTAMP(slot) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_dbg[slot] = clock64(); } while (0)
 #else
 #define TSTAMP(slot) do { } while (0)

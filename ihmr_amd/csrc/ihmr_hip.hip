@@ -510,6 +510,15 @@ extern "C" int ihmr_flush_kernel_timer(void) {
 extern "C" int ihmr_debug_read(long long* out256) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_dbg), 256 * sizeof(long long)));
+    if (getenv("IHMR_DEBUG_BLK")) {
+        static long long blk[2][1024];
+        HIP_TRY(hipMemcpyFromSymbol(blk, HIP_SYMBOL(g_blk), sizeof(blk)));
+        long long t0 = blk[0][0];
+        for (int i = 0; i < 128; ++i) t0 = std::min(t0, blk[0][i]);
+        printf("blk start/end (x10 ns since first start):");
+        for (int i = 0; i < 128; ++i) printf(" %lld-%lld", blk[0][i] - t0, blk[1][i] - t0);
+        printf("\n");
+    }
     return 0;
 }
 #endif

@@ -197,6 +197,9 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     const float* other = vl.hand(b, 1 - hnd);
     const int32_t* faces = hnd == 0 ? faces_r : faces_l;  // SoA [3][NFP]
     TSTAMP(20);
+#ifdef IHMR_TIMING
+    if (tid == 0 && blockIdx.x < 1024) g_blk[0][blockIdx.x] = wall_clock64();
+#endif
     // ---- bounding box (min / max are exact, any order)
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     float oq[3] = {0.f, 0.f, 0.f};
@@ -385,6 +388,9 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         if (tid == 0) atomicAdd(&ws.stats[2], (unsigned long long)blk_inside);            // inside voxels
     }
     TSTAMP(26);
+#ifdef IHMR_TIMING
+    if (tid == 0 && blockIdx.x < 1024) g_blk[1][blockIdx.x] = wall_clock64();
+#endif
 }
 
 // squared distance point -> triangle, closest point by Voronoi region.  Same values, operation for

@@ -11,8 +11,13 @@ from __future__ import annotations
 
 import argparse
 import json
+import os
 import time
 import types
+
+# several model instances run side by side on their own HIP streams (--streams): give them separate hardware queues
+# (read by the HIP runtime when it initialises, i.e. at the first device call below)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch

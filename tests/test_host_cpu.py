@@ -1,0 +1,67 @@
+"""Host-side logic that needs no GPU: prediction-file schema, refinement-batch construction, strategy plumbing."""
+import numpy as np
+import torch
+
+
+def _fake_preds(B, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    return dict(pred_cam_params=r(B, 3), pred_shape_params=r(B, 20), pred_pose_params=r(B, 96), pred_hand_trans=r(B, 3),
+                joints_2d=r(B, 42, 2), joints_3d=r(B, 42, 3), img_feat=r(B, 1024))
+
+
+def test_prediction_file_roundtrip_uses_reference_schema(tmp_path):
+    """data_utils.py:42-70 reads {img_path: {pred_cam_params, pred_shape_params, pred_pose_params, pred_hand_trans,
+    joints_2d, joints_3d, img_feat}}: the writer produces exactly that, and the reader returns the same bits in the
+    order of the requested image paths."""
+    from ihmr_amd import pipeline, ry_utils
+    B = 5
+    preds = _fake_preds(B)
+    names = [f"cam4/img_{i:04d}.jpg" for i in range(B)]
+    f = str(tmp_path / "pred.pkl")
+    pipeline.save_pred_file(f, names, preds)
+    raw = ry_utils.load_pkl(f)
+    assert sorted(raw) == sorted(names)
+    assert sorted(raw[names[0]]) == sorted(pipeline.PRED_KEYS)
+    assert raw[names[2]]["pred_pose_params"].shape == (96,) and raw[names[2]]["img_feat"].dtype == np.float32
+    back = pipeline.load_pred_file(f, names[::-1])
+    for k in pipeline.PRED_KEYS:
+        assert torch.equal(back[k], preds[k].flip(0)), k
+
+
+def test_refinement_batch_follows_opt_dataset():
+    """opt_dataset.py:134-151: unit scores appended to the predicted joints, init_hand_trans_j = joint 21 - joint 0 with
+    weight 1, init_hand_trans (B,1,4) with weight 1 for OPT and (B,3) for the MLP dataset (mlp_dataset.py:179)."""
+    from ihmr_amd import pipeline
+    B = 3
+    preds = _fake_preds(B, 1)
+    anno = dict(joints_2d=torch.zeros(B, 42, 3), joints_3d=torch.zeros(B, 42, 4), mano_pose=torch.zeros(B, 96), mano_betas=torch.zeros(B, 20),
+                mano_params_weight=torch.ones(B, 2), hand_trans=torch.zeros(B, 1, 4), hand_type_array=torch.ones(B, 2), index=torch.arange(B))
+    b = pipeline.refinement_batch(preds, anno)
+    assert b["init_joints_2d"].shape == (B, 42, 3) and torch.all(b["init_joints_2d"][:, :, 2] == 1)
+    assert b["init_joints_3d"].shape == (B, 42, 4) and torch.all(b["init_joints_3d"][:, :, 3] == 1)
+    assert torch.equal(b["init_joints_3d"][:, :, :3], preds["joints_3d"])
+    assert b["init_hand_trans"].shape == (B, 1, 4) and torch.equal(b["init_hand_trans"][:, 0, :3], preds["pred_hand_trans"])
+    assert torch.all(b["init_hand_trans"][:, 0, 3] == 1)
+    assert torch.equal(b["init_hand_trans_j"][:, 0, :3], preds["joints_3d"][:, 21] - preds["joints_3d"][:, 0])
+    assert torch.equal(b["init_pose_params"], preds["pred_pose_params"]) and torch.equal(b["index"], anno["index"])
+    m = pipeline.refinement_batch(preds, anno, for_mlp=True)
+    assert m["init_hand_trans"].shape == (B, 3) and torch.equal(m["img_feat"], preds["img_feat"])
+
+
+def test_packed_parameter_columns_match_reference_order():
+    """mlp_model.py:426-439 / baseline_model.py:262-270: final_params = [cam 3 | R orient 3, R pose 45, L orient 3,
+    L pose 45 | R shape 10, L shape 10 | trans 3]; the column table of the MLP model and the per-stage update sizes
+    (strategies/mlp_default.py) must tile those 122 columns."""
+    from ihmr_amd.mlp_model import COLS, PARAM_DIMS
+    from ihmr_amd.strategies import make_mlp_strategy
+    cover = np.zeros(122, int)
+    for n, sl in COLS.items():
+        assert sl.stop - sl.start == PARAM_DIMS[n], n
+        cover[sl] += 1
+    assert np.all(cover == 1)
+    assert COLS["pred_cam_params"] == slice(0, 3) and COLS["pred_hand_trans"] == slice(119, 122)
+    assert COLS["pred_right_orient"].start < COLS["pred_right_pose_params"].start < COLS["pred_left_orient"].start
+    assert COLS["pred_right_shape_params"].start < COLS["pred_left_shape_params"].start
+    dims = [sum(PARAM_DIMS[p] for p in st["update_params"]) for st in make_mlp_strategy()]
+    assert dims == [3, 3, 3, 90, 20, 3]
