@@ -245,7 +245,8 @@ def load_mano_pkl(path: str) -> Dict[str, np.ndarray]:
     :func:`synthetic_mano`, following what smplx 0.1.28 ``MANO.__init__`` extracts (``f``,
     ``v_template``, ``shapedirs``, ``posedirs`` reshaped to (135, V*3), ``J_regressor``,
     ``kintree_table[0]`` with parents[0] = -1, ``weights``, ``hands_mean``).
-    Untested against the real files (absent here); numpy-only, no chumpy needed."""
+    The real files are licence-gated and absent here; the layout is exercised by tests/test_host_cpu.py with a file
+    written in that layout (chumpy-pickled arrays, scipy-sparse J_regressor, uint32 faces).  numpy-only, no chumpy needed."""
     with open(path, "rb") as f:
         data = _TolerantUnpickler(io.BytesIO(f.read()), encoding="latin1").load()
     v_template = _to_array(data["v_template"]).astype(np.float64)

@@ -65,3 +65,42 @@ def test_packed_parameter_columns_match_reference_order():
     assert COLS["pred_right_shape_params"].start < COLS["pred_left_shape_params"].start
     dims = [sum(PARAM_DIMS[p] for p in st["update_params"]) for st in make_mlp_strategy()]
     assert dims == [3, 3, 3, 90, 20, 3]
+
+
+def test_load_mano_pkl_reads_the_original_file_layout(tmp_path):
+    """A file in the layout of the licence-gated ``MANO_RIGHT.pkl`` (chumpy objects for v_template / shapedirs /
+    posedirs / J_regressor-as-scipy-sparse / uint32 faces / kintree_table with 2^32-1 as the root's parent), written
+    from the synthetic asset with a throw-away ``chumpy`` module that is gone again at load time: the loader must
+    return exactly the arrays it was written from, without chumpy installed (smplx 0.1.28 ``MANO.__init__`` fields)."""
+    import pickle
+    import sys
+    import types
+
+    import scipy.sparse as sp
+
+    from ihmr_amd.assets import load_mano_pkl, synthetic_mano
+    ref = synthetic_mano(True)
+    mod_ch, mod_pkg = types.ModuleType("chumpy.ch"), types.ModuleType("chumpy")
+
+    class Ch:                                     # chumpy.ch.Ch pickles its value under `x`
+        def __init__(self, x): self.x = np.asarray(x, dtype=np.float64)
+    Ch.__module__, Ch.__qualname__ = "chumpy.ch", "Ch"
+    mod_ch.Ch = Ch
+    sys.modules["chumpy"], sys.modules["chumpy.ch"] = mod_pkg, mod_ch
+    try:
+        kin = np.stack([ref["parents"].astype(np.int64), np.arange(16)]).astype(np.uint32)   # parents[0] = -1 -> 4294967295
+        data = dict(v_template=Ch(ref["v_template"]), shapedirs=Ch(ref["shapedirs"]),
+                    posedirs=Ch(ref["posedirs"].T.reshape(778, 3, 135)), J_regressor=sp.csc_matrix(ref["J_regressor"].astype(np.float64)),
+                    weights=Ch(ref["lbs_weights"]), kintree_table=kin, f=ref["faces"].astype(np.uint32),
+                    hands_mean=ref["hands_mean"].astype(np.float64), hands_components=np.eye(45), bs_style="lbs", bs_type="lrotmin")
+        f = tmp_path / "MANO_RIGHT.pkl"
+        with open(f, "wb") as fh:
+            pickle.dump(data, fh, protocol=2)
+    finally:
+        del sys.modules["chumpy"], sys.modules["chumpy.ch"]
+    got = load_mano_pkl(str(f))
+    assert int(got["parents"][0]) == -1 and np.array_equal(got["parents"][1:], ref["parents"][1:])
+    assert got["faces"].dtype == np.int64 and np.array_equal(got["faces"], ref["faces"])
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "hands_mean"):
+        assert got[k].dtype == np.float32 and got[k].shape == ref[k].shape, k
+        np.testing.assert_array_equal(got[k], ref[k].astype(np.float32), err_msg=k)
