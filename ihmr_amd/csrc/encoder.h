@@ -32,8 +32,14 @@ struct ConvArgs {
     int act;                // 0 none, 1 relu, 2 sigmoid
     float* partial;         // split-K: [ksplit][M][Cout] raw partial sums (bias / residual / activation applied by conv_splitk_reduce_kernel)
     int ksplit;             // gridDim.z; 1 = no split
+    int exp_mask;           // timing experiments (IHMR_CONV_EXPERIMENT builds only)
 };
 
+#ifdef IHMR_CONV_EXPERIMENT
+#define CONV_EXP(bit) ((a.exp_mask >> (bit)) & 1)
+#else
+#define CONV_EXP(bit) 0
+#endif
 template <int BM, int BN>
 __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(ConvArgs a) {
     constexpr int WN_WAVES = BN / 32;                      // waves along n; each wave owns a 64 x 32 sub-tile
@@ -132,16 +138,17 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(
     for (int kc = kc0; kc < kc1; ++kc) {
         const int cur = (kc - kc0) & 1;
         const int nk = kc1;
-        if (kc + 1 < nk) load_tile(kc + 1);   // in flight during the MFMAs below
+        if (kc + 1 < nk && !CONV_EXP(0)) load_tile(kc + 1);   // in flight during the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < CONV_BK; kk += 2) {
-            const float a0 = As[cur][kk + kl][wm * 64 + l31], a1 = As[cur][kk + kl][wm * 64 + 32 + l31];
-            const float bf = Bs[cur][kk + kl][wn * 32 + l31];
+            float a0, a1, bf;
+            if (CONV_EXP(1)) { a0 = (float)kk; a1 = (float)(kk + 1); bf = (float)lane; }
+            else { a0 = As[cur][kk + kl][wm * 64 + l31]; a1 = As[cur][kk + kl][wm * 64 + 32 + l31]; bf = Bs[cur][kk + kl][wn * 32 + l31]; }
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf, acc[1], 0, 0, 0);
         }
-        if (kc + 1 < nk) store_tile(cur ^ 1);  // the other buffer: its readers finished before the previous barrier
-        __syncthreads();
+        if (kc + 1 < nk && !CONV_EXP(2)) store_tile(cur ^ 1);  // the other buffer: its readers finished before the previous barrier
+        if (!CONV_EXP(3)) __syncthreads();
     }
 
     // ---- epilogue: bias (+ residual) (+ activation); C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)

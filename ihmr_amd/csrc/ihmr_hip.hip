@@ -416,7 +416,10 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
                                int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int ldx, int ldw,
                                int ldy, int ldr, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !y || N <= 0 || Cout <= 0) return -1;
-    ConvArgs a{x, w, bias, residual, y, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, ldx, ldw, ldy, ldr, act, (float*)workspace, 1};
+    ConvArgs a{x, w, bias, residual, y, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, ldx, ldw, ldy, ldr, act, (float*)workspace, 1, 0};
+#ifdef IHMR_CONV_EXPERIMENT
+    if (const char* e = getenv("IHMR_CONV_EXP")) a.exp_mask = atoi(e);
+#endif
     const int M = N * Ho * Wo, nk = (kh * kw * Cin + CONV_BK - 1) / CONV_BK;
     hipStream_t st = (hipStream_t)stream;
     // Tile and K split, from per-layer measurements on MI355X (scripts/prof_encoder.py with IHMR_CONV_FORCE):
