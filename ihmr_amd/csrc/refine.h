@@ -81,12 +81,30 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
                                               LossShared& sh, int b, int j) {
     const bool act = j < 42;
     const int Bn = io.norm_batch > 0 ? io.norm_batch : B;   // the batch the reference's means run over
-    const float* cam = io.cam + b * 3;
-    const float cs = cam[0], ctx = cam[1], cty = cam[2];
-    float r[3] = {0.f, 0.f, 0.f};
+    // ---- every global input of this sample first, in one batch (the stores below may alias them as far as the
+    //      compiler knows, so left in place each load would wait for its own round trip)
+    const int jj = act ? j : 0;
+    const float cs = io.cam[b * 3], ctx = io.cam[b * 3 + 1], cty = io.cam[b * 3 + 2];
+    float r[3], t2[3], tg2[3], tg3[4], ti3[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r[k] = wk.joints_raw[(b * 42 + jj) * 3 + k];
+        t2[k] = io.init_joints_2d[(b * 42 + jj) * 3 + k];
+        tg2[k] = io.gt_joints_2d[(b * 42 + jj) * 3 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { tg3[k] = io.gt_joints_3d[(b * 42 + jj) * 4 + k]; ti3[k] = io.init_joints_3d[(b * 42 + jj) * 4 + k]; }
+    float tp4[4] = {0.f, 0.f, 0.f, 0.f}, tgt4[4] = {0.f, 0.f, 0.f, 0.f}, tr3[3] = {0.f, 0.f, 0.f};
+    if (j == 5) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { tp4[k] = io.init_hand_trans_j[b * 4 + k]; tgt4[k] = io.gt_hand_trans[b * 4 + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tr3[k] = io.trans[b * 3 + k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (act) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { r[k] = wk.joints_raw[(b * 42 + j) * 3 + k]; sh.raw[j][k] = r[k]; }
+        for (int k = 0; k < 3; ++k) sh.raw[j][k] = r[k];
     }
     LOSS_SYNC();
 
@@ -96,21 +114,26 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
         const float px = (r[0] + ctx) * cs, py = (r[1] + cty) * cs;
         io.joints_2d[(b * 42 + j) * 2] = px;
         io.joints_2d[(b * 42 + j) * 2 + 1] = py;
-        const float* t = io.init_joints_2d + (b * 42 + j) * 3;
-        const float* tg = io.gt_joints_2d + (b * 42 + j) * 3;
-        const float dx = t[0] - px, dy = t[1] - py;
-        l2d_p = (fabsf(dx) + fabsf(dy)) * t[2];
-        l2d_gt = (fabsf(tg[0] - px) + fabsf(tg[1] - py)) * tg[2];
+        const float dx = t2[0] - px, dy = t2[1] - py;
+        l2d_p = (fabsf(dx) + fabsf(dy)) * t2[2];
+        l2d_gt = (fabsf(tg2[0] - px) + fabsf(tg2[1] - py)) * tg2[2];
         const float s2 = w.joints_2d / (float)(Bn * 42 * 2);
         // d|t - p|/dp = -sign(t - p); dp/dX = cam scale
         const float sx = dx > 0.f ? -1.f : (dx < 0.f ? 1.f : 0.f), sy = dy > 0.f ? -1.f : (dy < 0.f ? 1.f : 0.f);
-        g_raw[0] = s2 * sx * t[2] * cs;
-        g_raw[1] = s2 * sy * t[2] * cs;
+        g_raw[0] = s2 * sx * t2[2] * cs;
+        g_raw[1] = s2 * sy * t2[2] * cs;
     }
 
-    // ---- 3D: two successive in-place root alignments (GT weights first, then init weights)
-    const int root1 = align_root(io.gt_joints_3d[(b * 42) * 4 + 3]);
-    const int root2 = align_root(io.init_joints_3d[(b * 42) * 4 + 3]);
+    // ---- 3D: two successive in-place root alignments (GT weights first, then init weights); lane 0 holds joint 0,
+    //      whose weight picks the root; the root joint's target row comes from its lane (uniform index)
+    const int root1 = align_root(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(tg3[3]), 0)));
+    const int root2 = align_root(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ti3[3]), 0)));
+    float tg0[3], ti0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        tg0[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tg3[k]), root1 >= 0 ? root1 : 0));
+        ti0[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ti3[k]), root2 >= 0 ? root2 : 0));
+    }
     float a1[3], a2[3], l3d_gt = 0.f, l3d_p = 0.f;
     if (act) {
 #pragma unroll
@@ -118,20 +141,16 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
     }
     LOSS_SYNC();
     if (act) {
-        const float* tg = io.gt_joints_3d + (b * 42 + j) * 4;
-        const float* tg0 = io.gt_joints_3d + (b * 42 + (root1 >= 0 ? root1 : 0)) * 4;
-        const float* ti = io.init_joints_3d + (b * 42 + j) * 4;
-        const float* ti0 = io.init_joints_3d + (b * 42 + (root2 >= 0 ? root2 : 0)) * 4;
         const float s3 = w.joints_3d / (float)(Bn * 42 * 3);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             a2[k] = root2 >= 0 ? a1[k] - sh.p1[root2][k] : a1[k];
             sh.p2[j][k] = a2[k];
-            const float gg = (root1 >= 0 ? tg[k] - tg0[k] : tg[k]) - a1[k];
-            l3d_gt += gg * gg * tg[3];
-            const float gi = (root2 >= 0 ? ti[k] - ti0[k] : ti[k]) - a2[k];
-            l3d_p += gi * gi * ti[3];
-            sh.g2[j][k] = -2.0f * s3 * gi * ti[3];
+            const float gg = (root1 >= 0 ? tg3[k] - tg0[k] : tg3[k]) - a1[k];
+            l3d_gt += gg * gg * tg3[3];
+            const float gi = (root2 >= 0 ? ti3[k] - ti0[k] : ti3[k]) - a2[k];
+            l3d_p += gi * gi * ti3[3];
+            sh.g2[j][k] = -2.0f * s3 * gi * ti3[3];
             io.joints_3d[(b * 42 + j) * 3 + k] = a2[k];
         }
     }
@@ -223,18 +242,15 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
     }
     // ---- translation loss (loss_utils.py:114-118) and the collision gradient scale
     if (j == 5) {
-        const float* tp = io.init_hand_trans_j + b * 4;
-        const float* tg = io.gt_hand_trans + b * 4;
-        const float* tr = io.trans + b * 3;
         float lp = 0.f, lg = 0.f;
         const float st = w.trans / (float)(Bn * 3);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float d = tp[k] - tr[k];
-            lp += d * d * tp[3];
-            wk.g_trans_direct[b * 3 + k] = -2.0f * st * d * tp[3];
-            const float dg = tg[k] - tr[k];
-            lg += dg * dg * tg[3];
+            const float d = tp4[k] - tr3[k];
+            lp += d * d * tp4[3];
+            wk.g_trans_direct[b * 3 + k] = -2.0f * st * d * tp4[3];
+            const float dg = tgt4[k] - tr3[k];
+            lg += dg * dg * tgt4[3];
         }
         io.loss_batch[6 * B + b] = lp / 3.f;
         io.loss_batch[7 * B + b] = lg / 3.f;
