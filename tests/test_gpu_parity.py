@@ -111,19 +111,28 @@ def _two_hand_verts(mano_arrays, B, seed):
     return torch.stack([rv, lv], dim=1).contiguous(), batch
 
 
-@pytest.mark.parametrize("squash", [None, 1e-3, 1e-6], ids=["hands", "thin", "sliver"])
+@pytest.mark.parametrize("squash", [None, 0.3, 1e-3, 1e-6, "ball"], ids=["hands", "flat", "thin", "sliver", "ball"])
 def test_sdf_dense_grid_bit_exact(mano_arrays, squash):
     """The product kernels evaluated on EVERY voxel reproduce the oracle's dense 32^3 grid bit for bit
     (same operation order, contraction off) -- inside/outside decisions and distances alike.  The squashed
     variants flatten the meshes along y, so the yz determinants of the ray test shrink by 1e3 / 1e6: the
-    near-degenerate regime in which the kernel's loop-free hit mask must fall back to per-voxel evaluation."""
+    near-degenerate regime in which the kernel's loop-free hit mask must fall back to per-voxel evaluation (no voxel
+    centre lies inside those two: the expected grid is all zeros, i.e. the test is that no ray produces a false crossing;
+    "flat" = 0.3 keeps an interior).  "ball"
+    projects every vertex onto a sphere about the hand's centre: voxels near the centre are (nearly) equidistant from
+    all 1538 triangles, so the bounding-sphere cull keeps more triangles than the per-wave survivor list holds and the
+    distance kernel takes its overflow path."""
     import ctypes as C
     from ihmr_amd import hip
     from oracle import sdf_ref
     right, left = mano_arrays
     B = 2
     hv, _ = _two_hand_verts(mano_arrays, B, 77)
-    if squash is not None:
+    if squash == "ball":
+        c = hv.mean(dim=2, keepdim=True)
+        d = hv - c
+        hv = (c + 0.08 * d / d.norm(dim=3, keepdim=True).clamp_min(1e-9)).contiguous()
+    elif squash is not None:
         hv = (hv * torch.tensor([1.0, squash, 1.0])).contiguous()
     centre, scale = sdf_ref.hand_boxes(hv)
     vn = (hv - centre) / scale
