@@ -144,7 +144,8 @@ def main():
         """n full passes over one batch each (set_input -> init_optimize -> optimize -> get_pred_result), up to S x G in flight."""
         res = None
         left = n
-        while left > 0:
+        pending = []                               # export handles of the previous round
+        while left > 0 or pending:
             jobs = []                              # (model, stream, input)
             n_round = min(left, S * G)
             for i in range(S):
@@ -162,12 +163,16 @@ def main():
                 for mdl, st, _ in jobs:
                     with torch.cuda.stream(st):
                         mdl.run_stage(stage)
+            handles = []
             for mdl, st, _ in jobs:
                 with torch.cuda.stream(st):
                     mdl.forward_losses(mdl.default_loss_weights)
-            for mdl, st, _ in jobs:
-                with torch.cuda.stream(st):
-                    res = mdl.get_pred_result()   # device -> host copies, as the reference's loop does
+                    # device -> host export of every batch, as the reference's loop does; queued behind the refinement
+                    # on its stream and collected one round later, so the host never leaves the GPU without work
+                    handles.append(mdl.get_pred_result_async())
+            for h in pending:
+                res = h.wait()
+            pending = handles
         return res
 
     # one untimed pass per instance: captures its stage graphs (a capture inside the timed region would cost ~100 ms),
@@ -176,6 +181,7 @@ def main():
         for mdl, inp in ((fused[i], batch_g), (singles[i], batch)):
             with torch.cuda.stream(streams[i]):
                 mdl.set_input(inp); mdl.init_optimize(); mdl.optimize()
+                mdl.get_pred_result_async().wait(); mdl.get_pred_result_async().wait()   # both pinned export buffer sets
     torch.cuda.synchronize()
 
     def barrier():

@@ -64,6 +64,20 @@ def _weights(w) -> hip.OptWeights:
                           w["collision_loss_weight"], w["finger_reg_loss_weight"])
 
 
+class _PendingResult:
+    """Handle of :meth:`OptimizeModel.get_pred_result_async`."""
+
+    def __init__(self, pinned, event, batch_size):
+        self._pinned, self._event, self._n = pinned, event, batch_size
+
+    def wait(self):
+        self._event.synchronize()
+        out = OrderedDict((k, v.numpy()) for k, v in self._pinned.items())
+        out["do_flip"] = np.zeros(self._n).astype(np.int32)
+        out["pred_hand_type"] = np.ones(self._n).astype(np.int32)
+        return out
+
+
 class OptimizeModel:
     name = "OptimizeModel"
 
@@ -250,17 +264,40 @@ class OptimizeModel:
     @property
     def joints_3d_loss_p_batch(self): return self.buf["loss_batch"][1]
 
+    def _export_sources(self):
+        return OrderedDict(
+            pred_cam_params=self.pred_cam_params, pred_hand_trans=self.pred_hand_trans,
+            pred_shape_params=self.pred_shape_params, pred_pose_params=self.pred_pose_params,
+            pred_right_hand_verts=self.pred_right_hand_verts, pred_left_hand_verts=self.pred_left_hand_verts,
+            mano_params_weight=self.mano_params_weight, pred_joints_3d=self.pred_joints_3d,
+            gt_joints_3d=self.buf["gt_joints_3d"], collision_loss=self.collision_loss_batch,
+            collision_loss_origin_scale=self.collision_loss_origin_scale)
+
     # optimize_model.py:418-435
     def get_pred_result(self):
         n = lambda t: t.detach().cpu().numpy()
-        return OrderedDict(
-            pred_cam_params=n(self.pred_cam_params), pred_hand_trans=n(self.pred_hand_trans),
-            pred_shape_params=n(self.pred_shape_params), pred_pose_params=n(self.pred_pose_params),
-            pred_right_hand_verts=n(self.pred_right_hand_verts), pred_left_hand_verts=n(self.pred_left_hand_verts),
-            mano_params_weight=n(self.mano_params_weight), pred_joints_3d=n(self.pred_joints_3d),
-            gt_joints_3d=n(self.buf["gt_joints_3d"]), collision_loss=n(self.collision_loss_batch),
-            collision_loss_origin_scale=n(self.collision_loss_origin_scale),
-            do_flip=np.zeros(self.batch_size).astype(np.int32), pred_hand_type=np.ones(self.batch_size).astype(np.int32))
+        out = OrderedDict((k, n(v)) for k, v in self._export_sources().items())
+        out["do_flip"] = np.zeros(self.batch_size).astype(np.int32)
+        out["pred_hand_type"] = np.ones(self.batch_size).astype(np.int32)
+        return out
+
+    def get_pred_result_async(self):
+        """``get_pred_result()`` without stalling the host: the device-to-host copies go, on the current stream and behind
+        the refinement that produced the values, into pinned host buffers (two alternating sets per instance); the
+        returned handle's ``wait()`` blocks until they have landed and hands out the same OrderedDict.  The arrays
+        are views of the pinned buffers: valid until the next-but-one export of this instance."""
+        if not hasattr(self, "_pinned"):
+            self._pinned, self._pin_slot = [None, None], 0
+        self._pin_slot ^= 1
+        src = self._export_sources()
+        if self._pinned[self._pin_slot] is None:
+            self._pinned[self._pin_slot] = OrderedDict((k, torch.empty(v.shape, dtype=v.dtype, pin_memory=True)) for k, v in src.items())
+        dst = self._pinned[self._pin_slot]
+        for k, v in src.items():
+            dst[k].copy_(v, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return _PendingResult(dst, ev, self.batch_size)
 
     # optimize_model.py:437-455 (means of the per-sample values)
     def get_current_errors(self):

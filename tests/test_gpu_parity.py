@@ -331,3 +331,18 @@ def test_opt_replay_is_deterministic(mano_arrays):
     for k in ("pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "collision_loss_origin_scale"):
         for o in outs[1:]:
             assert np.array_equal(outs[0][k], o[k]), k
+
+
+def test_async_export_equals_blocking_export(mano_arrays):
+    """get_pred_result_async().wait() hands out exactly what get_pred_result() does (same keys, dtypes, bits)."""
+    from ihmr_amd.optimize_model import OptimizeModel
+    B = 4
+    _, batch = _two_hand_verts(mano_arrays, B, 31)
+    model = OptimizeModel(_make_opt(B, epoch=2, save_mid_freq=1))
+    model.set_input(batch); model.init_optimize(); model.optimize()
+    h = model.get_pred_result_async()
+    ref = model.get_pred_result()
+    got = h.wait()
+    assert list(got) == list(ref)
+    for k in ref:
+        assert got[k].dtype == ref[k].dtype and got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k]), k
