@@ -346,3 +346,19 @@ def test_async_export_equals_blocking_export(mano_arrays):
     assert list(got) == list(ref)
     for k in ref:
         assert got[k].dtype == ref[k].dtype and got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k]), k
+
+
+@pytest.mark.parametrize("B", [1, 9, 33])
+def test_opt_odd_batch_sizes_match_oracle(mano_arrays, B):
+    """Batch sizes that are no multiple of the 8-hand skinning groups, of the 32-hand MFMA tiles of the pose-gradient
+    GEMM (2B = 2, 18, 66 hands) or of the XCD count: two iterations of every stage against the oracle."""
+    orc, model, batch = _oracle_and_model(mano_arrays, B, 1, 1, seed=100 + B)
+    orc.set_input(batch); orc.init_optimize(); orc.optimize()
+    model.set_input(batch); model.init_optimize(); model.optimize()
+    torch.cuda.synchronize()
+    r, g = orc.get_pred_result(), model.get_pred_result()
+    assert np.array_equal(np.stack(orc.selected), torch.stack(model.selected_history).cpu().numpy())
+    _report(f"B={B} pose", g["pred_pose_params"], r["pred_pose_params"], atol=1e-4)
+    _report(f"B={B} shape", g["pred_shape_params"], r["pred_shape_params"], atol=1e-4)
+    _report(f"B={B} verts [m]", g["pred_right_hand_verts"], r["pred_right_hand_verts"], atol=1e-4)
+    _report(f"B={B} penetration depth [m]", g["collision_loss_origin_scale"], r["collision_loss_origin_scale"], atol=1e-4)
