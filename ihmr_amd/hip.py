@@ -53,7 +53,7 @@ class OptWeights(C.Structure):
 
 
 class KernelTimer(C.Structure):
-    _fields_ = [("ms_sdf_eval", C.c_double), ("n_sdf_eval", C.c_long), ("algo_flops_sdf_eval", C.c_double)]
+    _fields_ = [("ms_sdf_eval", C.c_double), ("n_sdf_eval", C.c_long), ("algo_flops_sdf_eval", C.c_double), ("ms_event_pair", C.c_double)]
 
 
 def sources():

@@ -191,7 +191,10 @@ int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_joints_3d, co
 
 /* per-kernel timing hook for bench.py: when non-NULL, the library records hipEvents around the
  * dominant kernel on `stream` and accumulates (count, ms) here; host pointer, read after sync */
-typedef struct ihmr_kernel_timer { double ms_sdf_eval; long n_sdf_eval; double algo_flops_sdf_eval; } ihmr_kernel_timer;
+/* While a timer is set, every call launches the (idempotent) kernel 8 times back to back between ONE pair of events;
+ * n_sdf_eval counts launches.  ms_event_pair: an EMPTY event pair recorded right before each timed group, i.e. what
+ * the two event records cost by themselves; (ms_sdf_eval - ms_event_pair) / n_sdf_eval is the launch duration. */
+typedef struct ihmr_kernel_timer { double ms_sdf_eval; long n_sdf_eval; double algo_flops_sdf_eval; double ms_event_pair; } ihmr_kernel_timer;
 int ihmr_set_kernel_timer(ihmr_kernel_timer* t);
 int ihmr_flush_kernel_timer(void);
 
