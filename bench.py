@@ -215,7 +215,7 @@ def main():
     ms_per_step = 1000.0 * elapsed / args.steps
     value = world * B * args.steps / elapsed
 
-    # dominant kernel (sdf_eval_kernel): algorithmic work per launch from the kernel's own counters,
+    # dominant kernel (sdf_dist_kernel): algorithmic work per launch from the kernel's own counters,
     # gathered in an untimed replay of the same workload (see DESIGN.md "Measurement")
     roofline = None
     if rank == 0:

@@ -238,7 +238,7 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
 
 // seam-B callers hand over (F,3) int32 AoS faces on the device; the SoA copy lives in the workspace tail
 __global__ void faces_to_soa_kernel(const int32_t* __restrict__ aos, int32_t* __restrict__ soa, int* zero8) {
-    if (zero8 && blockIdx.x == 0 && threadIdx.x < SDF_NXCD) zero8[threadIdx.x] = 0;  // per-XCD inside-voxel counters
+    if (zero8 && blockIdx.x == 0 && threadIdx.x < SDF_NXCD) zero8[threadIdx.x] = 0;  // inside-voxel counter (8 slots, slot 0 in use)
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= NFP) return;
     const int s = f < NF ? f : 0;
@@ -399,7 +399,7 @@ extern "C" int ihmr_graph_destroy(ihmr_graph* g) {
 
 // diagnostics (synchronises): one forward + losses with the SDF work counters switched on.
 // out[0] = (voxel, triangle) ray tests, out[1] = exact point-triangle distances, out[2] = inside voxels,
-// out[3] = needed voxels -- totals of ONE sdf_eval_kernel launch.
+// out[3] = needed voxels -- totals of ONE sdf_prep_kernel + sdf_dist_kernel launch pair.
 extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                                   const ihmr_opt_weights* w, unsigned long long* out4, void* stream) {
     if (!m || !io || !w || !out4 || B <= 0) return -1;

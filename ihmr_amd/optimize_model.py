@@ -188,7 +188,7 @@ class OptimizeModel:
                   "ihmr_opt_forward_losses")
 
     def collect_sdf_stats(self, loss_weights=None):
-        """Work counters of one ``sdf_eval_kernel`` launch at the current parameters (diagnostics)."""
+        """Work counters of one ``sdf_prep_kernel`` + ``sdf_dist_kernel`` launch pair at the current parameters (diagnostics)."""
         w = _weights(loss_weights or self.default_loss_weights)
         mr, ml = self._mano_handles()
         out = (C.c_ulonglong * 4)()

@@ -156,7 +156,7 @@ int ihmr_graph_destroy(ihmr_graph* g);
 
 /* diagnostics (synchronises): forward + losses once with the SDF work counters on; out4 (host) =
  * {(voxel,triangle) ray tests, exact point-triangle distances, inside voxels, needed voxels} of one
- * sdf_eval_kernel launch -- the algorithmic work bench.py prices the roofline with. */
+ * sdf_prep_kernel + sdf_dist_kernel launch pair -- the algorithmic work bench.py prices the roofline with. */
 /* Scatter the reference's packed prediction vector `final_params` (B,122) = [cam 3 | right orient 3 | right pose 45 |
  * left orient 3 | left pose 45 | right shape 10 | left shape 10 | trans 3] (baseline_model.py:262-270,
  * mlp_model.py:426-439) into io->cam / orient / pose / shape / trans. */
