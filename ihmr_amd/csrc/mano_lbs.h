@@ -434,24 +434,43 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
         for (int q = 0; q < 4; ++q) wreg[r][q] = w4[q];
     }
     if (tid < NJ) { bw.par[tid] = m.parents[tid]; bw.dep[tid] = m.depth[tid]; }
-    // ---- TWO_HAND: d L / d shift = sum over the LEFT hand's vertex and joint gradients of this sample
+    // every other global input of the workgroup in the same batch: the left hand's output gradients (for d L / d shift),
+    // this hand's output gradients, v_posed and skeleton record, the joint gradients
+    constexpr int NR = (NV3 + LBS_THREADS - 1) / LBS_THREADS, SR = (SK_STRIDE + LBS_THREADS - 1) / LBS_THREADS;
+    float rg[NR], rv[NR], rs[SR], gl0[VR][3], gjl[3] = {0.f, 0.f, 0.f}, gjo = 0.f;
     if (TWO_HAND) {
         const float* gl = d_verts + ((size_t)(B + b) * NV) * 3;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        float gl0[VR][3];
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
             const int v = tid + r * LBS_THREADS;
 #pragma unroll
             for (int k = 0; k < 3; ++k) gl0[r][k] = v < NV ? gl[3 * v + k] : 0.f;
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < VR; ++r) { s0 += gl0[r][0]; s1 += gl0[r][1]; s2 += gl0[r][2]; }
         if (tid < 21) {
             const float* gj = d_joints + ((size_t)b * 42 + 21 + tid) * 3;
-            s0 += gj[0]; s1 += gj[1]; s2 += gj[2];
+            gjl[0] = gj[0]; gjl[1] = gj[1]; gjl[2] = gj[2];
         }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int i = min(tid + r * LBS_THREADS, NV3 - 1);
+        rg[r] = d_verts[(size_t)h * NV3 + i];
+        rv[r] = wk.v_posed[(size_t)h * NV3 + i];
+    }
+#pragma unroll
+    for (int r = 0; r < SR; ++r) rs[r] = wk.skel[(size_t)h * SK_STRIDE + min(tid + r * LBS_THREADS, SK_STRIDE - 1)];
+    if (tid < 21 * 3) {
+        const int j = tid / 3, k = tid % 3;
+        if (TWO_HAND) gjo = d_joints[((size_t)b * 42 + (left ? 21 : 0) + j) * 3 + k];
+        else gjo = j < NJ ? d_joints[((size_t)h * NJ + j) * 3 + k] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- TWO_HAND: d L / d shift = sum over the LEFT hand's vertex and joint gradients of this sample
+    if (TWO_HAND) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < VR; ++r) { s0 += gl0[r][0]; s1 += gl0[r][1]; s2 += gl0[r][2]; }
+        s0 += gjl[0]; s1 += gjl[1]; s2 += gjl[2];
         // fixed-order block sum: DPP inside each wave, then the 4 wave totals in index order
         s0 = wave_reduce_sum_dpp(s0); s1 = wave_reduce_sum_dpp(s1); s2 = wave_reduce_sum_dpp(s2);
         if (tid % WAVE == 0) { bw.wsum[tid / WAVE][0] = s0; bw.wsum[tid / WAVE][1] = s1; bw.wsum[tid / WAVE][2] = s2; }
@@ -467,44 +486,23 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
     }
 
     TSTAMP(11);
-    // ---- skeleton record of this iteration's forward, output gradients into the raw hand frame (all loads issued
-    //      before the first LDS store)
-    {
-        constexpr int NR = (NV3 + LBS_THREADS - 1) / LBS_THREADS, SR = (SK_STRIDE + LBS_THREADS - 1) / LBS_THREADS;
-        float rg[NR], rv[NR], rs[SR];
+    // ---- skeleton record of this iteration's forward, output gradients into the raw hand frame
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int i = min(tid + r * LBS_THREADS, NV3 - 1);
-            rg[r] = d_verts[(size_t)h * NV3 + i];
-            rv[r] = wk.v_posed[(size_t)h * NV3 + i];
+    for (int r = 0; r < NR; ++r) {
+        const int i = tid + r * LBS_THREADS;
+        if (i < NV3) {
+            bw.g[i] = (left && (i % 3) == 0) ? -rg[r] : rg[r];
+            bw.vp[i] = rv[r];
         }
+    }
 #pragma unroll
-        for (int r = 0; r < SR; ++r) rs[r] = wk.skel[(size_t)h * SK_STRIDE + min(tid + r * LBS_THREADS, SK_STRIDE - 1)];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int i = tid + r * LBS_THREADS;
-            if (i < NV3) {
-                bw.g[i] = (left && (i % 3) == 0) ? -rg[r] : rg[r];
-                bw.vp[i] = rv[r];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < SR; ++r) {
-            const int i = tid + r * LBS_THREADS;
-            if (i < SK_STRIDE) bw.sk[i] = rs[r];
-        }
+    for (int r = 0; r < SR; ++r) {
+        const int i = tid + r * LBS_THREADS;
+        if (i < SK_STRIDE) bw.sk[i] = rs[r];
     }
     if (tid < 21 * 3) {
         const int j = tid / 3, k = tid % 3;
-        float gv;
-        if (TWO_HAND) {
-            gv = d_joints[((size_t)b * 42 + (left ? 21 : 0) + j) * 3 + k];
-            if (left && k == 0) gv = -gv;
-        } else {
-            gv = j < NJ ? d_joints[((size_t)h * NJ + j) * 3 + k] : 0.f;
-        }
-        bw.gj[j][k] = gv;
+        bw.gj[j][k] = (TWO_HAND && left && k == 0) ? -gjo : gjo;
     }
     __syncthreads();
     if (TWO_HAND && tid < IHMR_NUM_TIPS * 3) {  // fingertip joints are vertices
