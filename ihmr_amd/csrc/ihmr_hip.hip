@@ -154,11 +154,11 @@ static void lbs_forward_launch(const ihmr_mano* m, bool two_hand, const float* o
     const dim3 skin_grid(8, 4 * ((N + 63) / 64));
     if (two_hand) {
         hipLaunchKernelGGL(lbs_skel_kernel<true>, dim3(N), dim3(192), 0, st, *m, orient, pose, betas, trans, B, wk.skel, joints);
-        hipLaunchKernelGGL(lbs_skin_kernel<true>, skin_grid, dim3(SKIN_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
+        hipLaunchKernelGGL(lbs_skin_kernel<true>, skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
                            joints, wk.v_posed);
     } else {
         hipLaunchKernelGGL(lbs_skel_kernel<false>, dim3(N), dim3(192), 0, st, *m, orient, pose, betas, trans, B, wk.skel, joints);
-        hipLaunchKernelGGL(lbs_skin_kernel<false>, skin_grid, dim3(SKIN_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
+        hipLaunchKernelGGL(lbs_skin_kernel<false>, skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
                            joints, wk.v_posed);
     }
 }
@@ -284,7 +284,7 @@ extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
                        const ihmr_opt_weights& w, const AdamStep& prev, hipStream_t st) {
     hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B).inside_count);
-    hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3(8, 4 * ((2 * B + 63) / 64)), dim3(SKIN_THREADS), 0, st, *m, (const float*)wk.lbs.skel,
+    hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m, (const float*)wk.lbs.skel,
                        2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
     VertLayout vl{io->verts, (long)NV3, (long)B * NV3};

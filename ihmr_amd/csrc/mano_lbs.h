@@ -24,8 +24,6 @@
 #define LBS_THREADS 256
 #define LBS_HG 8          // hands per skin / bwd2 workgroup
 #define LBS_TILE_V 195    // vertices per skin workgroup (4 x 195 = 780 >= 778)
-#define SKIN_THREADS 512   // skin workgroup: two halves of 256 lanes share the 135 pose features, then the 4 hand pairs
-#define SKIN_ESPLIT 72     // pose features [0,72) -> half 0 (8 batches of 9), [72,135) -> half 1 (7 batches)
 #define LBS_KG 25         // bwd2: K groups (split-K partial sums, reduced in fixed order by bwd3)
 #define LBS_KC 3          // bwd2: 32-column chunks per K group: 25 x 3 x 32 = 2400 >= 2334 basis columns
 #define LBS_SEG 13         // CSR entries per dA segment
@@ -231,23 +229,21 @@ __device__ __forceinline__ int lbs_group_hand(int x, int s, int i) { return x + 
 // ------------------------------------------------------------------------------------- skin
 // grid = (8, 4 vertex tiles x ceil(N/64) groups), block = 256 (195 active lanes = vertices).
 template <bool TWO_HAND>
-__global__ __launch_bounds__(SKIN_THREADS) void lbs_skin_kernel(ihmr_mano m, const float* __restrict__ skel, int N, int B,
+__global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, const float* __restrict__ skel, int N, int B,
                                                                float* __restrict__ verts, float* __restrict__ joints,
                                                                float* __restrict__ v_posed_ws) {
     __shared__ float4 pfT[136][2];        // [e][hands 0-3 | 4-7]
     __shared__ float A_s[LBS_HG / 2][192][2];   // skinning matrices, the two hands of a pair interleaved
     __shared__ float beta_s[10][LBS_HG];  // [l][hand]
     __shared__ float shift_s[LBS_HG][4];
-    __shared__ float xch[2][12][256];     // partial pose blends handed to the other half: [writer][pair-of-other x coord x hand][lane]
     const int tid = threadIdx.x, gx = blockIdx.x, tile = blockIdx.y % 4, gs = blockIdx.y / 4;
-    const int half = tid >> 8, lt = tid & 255;   // half 0 / 1, lane within the half = vertex of the tile
     TSTAMP(0);
-    for (int idx = tid; idx < LBS_HG * 136; idx += SKIN_THREADS) {
+    for (int idx = tid; idx < LBS_HG * 136; idx += LBS_THREADS) {
         const int hh = idx / 136, e = idx % 136, hid = lbs_group_hand(gx, gs, hh);
         const float v = (hid < N && e < NPF) ? skel[(size_t)hid * SK_STRIDE + SK_PF + e] : 0.f;
         reinterpret_cast<float*>(&pfT[e][0])[hh] = v;
     }
-    for (int idx = tid; idx < LBS_HG * 192; idx += SKIN_THREADS) {
+    for (int idx = tid; idx < LBS_HG * 192; idx += LBS_THREADS) {
         const int hh = idx / 192, e = idx % 192, hid = lbs_group_hand(gx, gs, hh);
         A_s[hh / 2][e][hh % 2] = hid < N ? skel[(size_t)hid * SK_STRIDE + SK_A + e] : 0.f;
     }
@@ -261,13 +257,13 @@ __global__ __launch_bounds__(SKIN_THREADS) void lbs_skin_kernel(ihmr_mano m, con
     }
     __syncthreads();
     TSTAMP(1);
-    const bool active = lt < LBS_TILE_V && tile * LBS_TILE_V + lt < NV;   // inactive lanes still reach the barrier below
-    const int v = active ? tile * LBS_TILE_V + lt : 0;
+    const int v = tile * LBS_TILE_V + tid;
+    if (tid >= LBS_TILE_V || v >= NV) return;
 
     // shape blend: v_shaped = v_template + shapedirs . beta   (8 hands at once, as 4 hand PAIRS: packed fp32 FMAs
     // do two hands per instruction and give the same IEEE results as scalar ones)
     lbs_v2f vq[LBS_HG / 2][3];
-    if (half == 0) {
+    {
         const float4 t = m.vt4[v];
         float4 sd[10];
 #pragma unroll
@@ -284,9 +280,6 @@ __global__ __launch_bounds__(SKIN_THREADS) void lbs_skin_kernel(ihmr_mano m, con
                 vq[q][2] = __builtin_elementwise_fma(lbs_v2f{sd[l].z, sd[l].z}, bl, vq[q][2]);
             }
         }
-    } else {
-#pragma unroll
-        for (int q = 0; q < LBS_HG / 2; ++q) { vq[q][0] = lbs_v2f{0.f, 0.f}; vq[q][1] = lbs_v2f{0.f, 0.f}; vq[q][2] = lbs_v2f{0.f, 0.f}; }
     }
     TSTAMP(2);
     // pose blend: v_posed = v_shaped + pose_feature . posedirs.  The basis rows are fetched 9 at a time into two
@@ -318,46 +311,21 @@ __global__ __launch_bounds__(SKIN_THREADS) void lbs_skin_kernel(ihmr_mano m, con
                 }
             }
         };
-        // this half's share of the 135 pose features, in batches of 9, the next batch in flight while one is consumed
-        static_assert(SKIN_ESPLIT % 9 == 0 && (NPF - SKIN_ESPLIT) % 9 == 0, "both shares are whole batches");
-        const int e_begin = half == 0 ? 0 : SKIN_ESPLIT, e_end = half == 0 ? SKIN_ESPLIT : NPF;
-        fetch(pa, e_begin);
+        static_assert(NPF % 9 == 0 && (NPF / 9) % 2 == 1, "15 batches of 9: 7 double steps + 1");
+        fetch(pa, 0);
 #pragma unroll 1
-        for (int e0 = e_begin; e0 < e_end; e0 += 18) {
-            const bool has_b = e0 + 9 < e_end, has_a2 = e0 + 18 < e_end;
-            if (has_b) fetch(pb, e0 + 9);
+        for (int e0 = 0; e0 + 9 < NPF; e0 += 18) {
+            fetch(pb, e0 + 9);
             __builtin_amdgcn_sched_barrier(0);
             consume(pa, e0);
             __builtin_amdgcn_sched_barrier(0);
-            if (has_a2) fetch(pa, e0 + 18);
+            fetch(pa, e0 + 18);
             __builtin_amdgcn_sched_barrier(0);
-            if (has_b) consume(pb, e0 + 9);
+            consume(pb, e0 + 9);
             __builtin_amdgcn_sched_barrier(0);
         }
+        consume(pa, NPF - 9);
     }
-    // hand the partial blends of the pairs the OTHER half finishes over through LDS, take in those for our own pairs
-    // (half 0 finishes pairs 0,1 = hands 0-3; half 1 pairs 2,3 = hands 4-7)
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const lbs_v2f val = half == 0 ? vq[2 + qq][c] : vq[qq][c];
-            xch[half][(qq * 3 + c) * 2 + 0][lt] = val.x;
-            xch[half][(qq * 3 + c) * 2 + 1][lt] = val.y;
-        }
-    }
-    __syncthreads();
-    lbs_v2f vo[2][3];      // the two pairs this half finishes
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const lbs_v2f mine = half == 0 ? vq[qq][c] : vq[2 + qq][c];
-            const lbs_v2f other = {xch[1 - half][(qq * 3 + c) * 2 + 0][lt], xch[1 - half][(qq * 3 + c) * 2 + 1][lt]};
-            // half 0 holds template + shape + first features, half 1 the remaining features: same order in both halves
-            vo[qq][c] = half == 0 ? mine + other : other + mine;
-        }
-    if (!active) return;
     TSTAMP(3);
     float w[NJ];
     {
@@ -374,8 +342,7 @@ __global__ __launch_bounds__(SKIN_THREADS) void lbs_skin_kernel(ihmr_mano m, con
     // skinning, one hand pair at a time: T = sum_j w_j A_j over all 16 joints without branches (a zero weight adds an
     // exact zero), the pair's matrices read from LDS as broadcast 16-byte rows, packed FMAs
 #pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-        const int q = 2 * half + qq;        // this half finishes hand pairs 2*half, 2*half + 1
+    for (int q = 0; q < LBS_HG / 2; ++q) {
         lbs_v2f T[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = lbs_v2f{0.f, 0.f};
@@ -392,14 +359,14 @@ __global__ __launch_bounds__(SKIN_THREADS) void lbs_skin_kernel(ihmr_mano m, con
         }
         lbs_v2f o2[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) o2[r] = T[4 * r + 0] * vo[qq][0] + T[4 * r + 1] * vo[qq][1] + T[4 * r + 2] * vo[qq][2] + T[4 * r + 3];
+        for (int r = 0; r < 3; ++r) o2[r] = T[4 * r + 0] * vq[q][0] + T[4 * r + 1] * vq[q][1] + T[4 * r + 2] * vq[q][2] + T[4 * r + 3];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int hh = 2 * q + i, h = lbs_group_hand(gx, gs, hh);
             if (h >= N) continue;
             float out[3] = {i ? o2[0].y : o2[0].x, i ? o2[1].y : o2[1].x, i ? o2[2].y : o2[2].x};
             float* ws = v_posed_ws + ((size_t)h * NV + v) * 3;
-            ws[0] = i ? vo[qq][0].y : vo[qq][0].x; ws[1] = i ? vo[qq][1].y : vo[qq][1].x; ws[2] = i ? vo[qq][2].y : vo[qq][2].x;
+            ws[0] = i ? vq[q][0].y : vq[q][0].x; ws[1] = i ? vq[q][1].y : vq[q][1].x; ws[2] = i ? vq[q][2].y : vq[q][2].x;
             const bool left = TWO_HAND && h >= B;
             if (left) {  // optimize_model.py:210-211, 222-228
                 out[0] = -out[0] + shift_s[hh][0];

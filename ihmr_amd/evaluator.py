@@ -121,7 +121,9 @@ class Evaluator:
         sums = np.array([f64(e), len(e), f64(pa), len(pa), f64(ca), f64(cm), len(inter)], dtype=np.float64)
         if self._device_parts:
             import torch
-            dsum = torch.stack([p.sum(dim=0) for p in self._device_parts]).sum(dim=0).cpu().numpy()
+            # one reduction over all samples in the order they were added: the float64 sum does not depend on how
+            # the samples were grouped into batches / launch sequences
+            dsum = torch.cat(self._device_parts, dim=0).sum(dim=0).cpu().numpy()
             sums = sums + dsum
         return sums
 
