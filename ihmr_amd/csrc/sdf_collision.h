@@ -24,7 +24,7 @@
 #define SDF_EVAL_CHUNKS 8          // workgroups per hand in the parity kernel
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
 #ifndef SDF_DIST_BLOCKS
-#define SDF_DIST_BLOCKS 1024          // 4 workgroups (30 KB LDS, <= 128 VGPRs) per CU: a typical launch's work items are all resident at once
+#define SDF_DIST_BLOCKS 2048          // >= the work items of two fused 64-sample batches (~1800): one item per workgroup, no second table staging; 4 workgroups (30 KB LDS, <= 128 VGPRs) per CU
 #endif
 #define SDF_SURV_CAP 512             // LDS slots per wave for the triangles surviving the sphere cull (typically ~40)
 #define SDF_ITEM 16                // inside voxels per work item of the distance kernel (one hand per item); power of two
