@@ -257,8 +257,8 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
     }
 }
 
-// Collision sampling + joint / translation / finger losses of sample b in one launch.  grid = B, block = 1024:
-// waves 0-14 sample the two distance grids at the other hand's vertices (value, gradient -> g_verts), wave 15
+// Collision sampling + joint / translation / finger losses of sample b in one launch.  grid = B, block = 512:
+// waves 0-6 sample the two distance grids at the other hand's vertices (value, gradient -> g_verts), wave 7
 // evaluates the joint losses and their gradient (-> g_joints); the two halves share nothing but the launch.
 #define OPT_SAMPLE_WORKERS (SDF_SAMPLE_THREADS - WAVE)
 __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void opt_sample_loss_kernel(ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,

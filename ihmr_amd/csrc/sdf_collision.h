@@ -568,7 +568,7 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
 // Writes per_vert / origin_scale (B,1556), dval (B,1556,3) = d per_vert / d vertex, loss (B)
 // (x mask[b] = [hand_type_array sum > 1.5] when hand_type != nullptr, loss_utils.py:186-188).
 // If gverts != nullptr: fused-path gradient gverts[(1-hnd), b, v, :] = gs * dval  (layout (2,B,778,3)).
-#define SDF_SAMPLE_THREADS 1024
+#define SDF_SAMPLE_THREADS 512
 __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const SdfWorkspace& ws, float robustifier,
                                                  float* __restrict__ loss, float* __restrict__ per_vert,
                                                  float* __restrict__ origin, float* __restrict__ dval,
@@ -650,7 +650,7 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
     }
 }
 
-// seam B: grid = B, block = 1024
+// seam B: grid = B, block = SDF_SAMPLE_THREADS (512)
 __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void sdf_sample_kernel(VertLayout vl, SdfWorkspace ws, float robustifier,
                                                                  float* __restrict__ loss, float* __restrict__ per_vert,
                                                                  float* __restrict__ origin, float* __restrict__ dval, int B) {
