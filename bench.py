@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--epoch", type=int, default=49, help="opt_default epoch per stage (49 -> 200 iterations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fuse", type=int, default=2,
+    ap.add_argument("--fuse", type=int, default=4,
                     help="batches of --batch samples carried by ONE launch sequence (opt.fuse_batches; per-sample arithmetic "
                          "identical to separate batches); batches in flight = streams x fuse")
     ap.add_argument("--streams", type=int, default=4,
@@ -129,32 +129,45 @@ def main():
         o.fuse_batches = fuse
         return OptimizeModel(o)
 
-    fused = [make_model(G) for _ in range(S)]
     streams = [torch.cuda.Stream() for _ in range(S)]
-    model = fused[0] if G == 1 else make_model(1)   # single-batch instance: remainder runs, roofline timing, work counters
-    # remainder of fewer than G batches: single-batch instances, one per stream (slot 0 doubles as `model`)
-    singles = fused if G == 1 else [model] + [make_model(1) for _ in range(S - 1)]
+    model = make_model(1)                        # single-batch instance: roofline timing, work counters, size-1 jobs of stream 0
+    pool = {(0, 1): model}                       # (stream, batches per launch sequence) -> instance, built on demand
     fwd = lambda p, s, t: two_hand.forward_from_packed(model.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
     batch_cpu = synthetic_opt_batch(B, fwd, seed=1234 + rank, first_index=rank * B)
     batch = {k: v.cuda() for k, v in batch_cpu.items()}   # resident in HBM before timing
-    batch_g = batch if G == 1 else {k: torch.cat([v] * G, dim=0) for k, v in batch.items()}
+    inputs = {1: batch}
+    for g in range(2, G + 1):
+        inputs[g] = {k: torch.cat([v] * g, dim=0) for k, v in batch.items()}
     torch.cuda.synchronize()
 
+    def plan(n):
+        """n batches -> per stream a list of job sizes (batches fused into one launch sequence, <= G): the streams get
+        equal shares (+-1), a share is cut into the fewest jobs of the most equal sizes.  Any n keeps all S streams busy
+        to the end (n = 20, S = 4, G = 3: every stream runs a 3 and a 2)."""
+        out = []
+        for i in range(S):
+            c = n // S + (1 if i < n % S else 0)
+            k = -(-c // G) if c else 0
+            out.append([c // k + (1 if j < c % k else 0) for j in range(k)] if k else [])
+        return out
+
+    def instance(i, g):
+        if (i, g) not in pool:
+            pool[(i, g)] = make_model(g)
+            with torch.cuda.stream(streams[i]):      # untimed first pass: captures the stage graphs, allocates the pinned buffers
+                m = pool[(i, g)]
+                m.set_input(inputs[g]); m.init_optimize(); m.optimize()
+                m.get_pred_result_async().wait(); m.get_pred_result_async().wait()
+        return pool[(i, g)]
+
     def run_steps(n):
-        """n full passes over one batch each (set_input -> init_optimize -> optimize -> get_pred_result), up to S x G in flight."""
+        """n full passes over one batch each (set_input -> init_optimize -> optimize -> get_pred_result), S streams x up to
+        G fused batches in flight."""
         res = None
-        left = n
+        sizes = plan(n)
         pending = []                               # export handles of the previous round
-        while left > 0 or pending:
-            jobs = []                              # (model, stream, input)
-            n_round = min(left, S * G)
-            for i in range(S):
-                # spread a partial round over all streams (G <= 2: a stream carries 2 batches fused, 1 alone, or none)
-                share = (n_round // S + (1 if i < n_round % S else 0)) if G <= 2 else min(G, left)
-                if share >= G and left >= G:
-                    jobs.append((fused[i], streams[i], batch_g)); left -= G
-                elif share >= 1 and left > 0:
-                    jobs.append((singles[i], streams[i], batch)); left -= 1
+        for r in range(max((len(q) for q in sizes), default=0) + 1):
+            jobs = [(instance(i, q[r]), streams[i], inputs[q[r]]) for i, q in enumerate(sizes) if r < len(q)]
             for mdl, st, inp in jobs:
                 with torch.cuda.stream(st):
                     mdl.set_input(inp)
@@ -175,13 +188,14 @@ def main():
             pending = handles
         return res
 
-    # one untimed pass per instance: captures its stage graphs (a capture inside the timed region would cost ~100 ms),
-    # whatever --warmup / --steps the caller chose
-    for i in range(S):
-        for mdl, inp in ((fused[i], batch_g), (singles[i], batch)):
-            with torch.cuda.stream(streams[i]):
-                mdl.set_input(inp); mdl.init_optimize(); mdl.optimize()
-                mdl.get_pred_result_async().wait(); mdl.get_pred_result_async().wait()   # both pinned export buffer sets
+    with torch.cuda.stream(streams[0]):              # the pre-built single-batch instance gets its untimed first pass too
+        model.set_input(batch); model.init_optimize(); model.optimize()
+        model.get_pred_result_async().wait(); model.get_pred_result_async().wait()
+    # every instance the warm-up and the timed run will use is built (graphs captured, pinned buffers allocated) now
+    for n in (max(args.warmup, 0), args.steps):
+        for i, q in enumerate(plan(n)):
+            for g in q:
+                instance(i, g)
     torch.cuda.synchronize()
 
     def barrier():
@@ -264,7 +278,7 @@ def main():
             config=dict(workload=f"IHMR-OPT opt_default epoch={args.epoch} ({n_iters} refine iterations + final forward), "
                                  f"save_mid_freq={freq}, batch {B}/GPU, synthetic MANO-shaped asset seed 0",
                         global_batch=world * B, refine_iters=n_iters, batches_in_flight_per_gpu=S * G, launch_streams=S,
-                        batches_per_launch_sequence=G,
+                        max_batches_per_launch_sequence=G,
                         parallelism=f"dp{world} (independent samples, no collective)"),
             roofline=roofline, cpu_baseline=cpu,
             parity=dict(mean_penetration_depth_m=float(np.mean(res["collision_loss_origin_scale"]))),
