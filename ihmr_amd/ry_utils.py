@@ -29,3 +29,18 @@ def save_mesh_to_obj(path, verts, faces):
             f.write(f"v {v[0]:.6f} {v[1]:.6f} {v[2]:.6f}\n")
         for t in faces + 1:
             f.write(f"f {t[0]} {t[1]} {t[2]}\n")
+
+
+def save_pred_obj(res_dir, pred_result, mano_models, iter_id, data_id, opt_iter, sample=0):
+    """The reference's ``utils/opt_utils.py:45-54``: the two predicted hands of one sample as ONE mesh -- right-hand
+    vertices first, left-hand face indices shifted by the 778 right-hand vertices (``concat(faces_r, faces_l + 778)``,
+    integer work, bit-exact) -- written to ``iter_XXXX_stage_XX_opt_iter_XXXX.obj``.  Returns the path."""
+    right_verts = np.asarray(pred_result["pred_right_hand_verts"][sample])
+    left_verts = np.asarray(pred_result["pred_left_hand_verts"][sample])
+    right_faces = np.asarray(mano_models["right"].faces).astype(np.int64)
+    left_faces = np.asarray(mano_models["left"].faces).astype(np.int64)
+    verts = np.concatenate([right_verts, left_verts], axis=0)
+    faces = np.concatenate([right_faces, left_faces + right_verts.shape[0]], axis=0)
+    path = os.path.join(res_dir, f"iter_{iter_id:04d}_stage_{data_id:02d}_opt_iter_{opt_iter:04d}.obj")
+    save_mesh_to_obj(path, verts, faces)
+    return path

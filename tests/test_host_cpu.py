@@ -104,3 +104,30 @@ def test_load_mano_pkl_reads_the_original_file_layout(tmp_path):
     for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "hands_mean"):
         assert got[k].dtype == np.float32 and got[k].shape == ref[k].shape, k
         np.testing.assert_array_equal(got[k], ref[k].astype(np.float32), err_msg=k)
+
+
+def test_two_hand_obj_export_face_indexing(tmp_path, mano_arrays):
+    """utils/opt_utils.py:45-54 + ry_utils.save_mesh_to_obj: right vertices first, left faces shifted by 778, 1-based OBJ
+    indices -- integer work, reproduced exactly when the file is read back."""
+    import types
+
+    from ihmr_amd import ry_utils
+    right, left = mano_arrays
+    rng = np.random.RandomState(0)
+    pred = dict(pred_right_hand_verts=rng.randn(2, 778, 3).astype(np.float32), pred_left_hand_verts=rng.randn(2, 778, 3).astype(np.float32))
+    models = dict(right=types.SimpleNamespace(faces=right["faces"]), left=types.SimpleNamespace(faces=left["faces"]))
+    path = ry_utils.save_pred_obj(str(tmp_path), pred, models, iter_id=3, data_id=1, opt_iter=40, sample=1)
+    assert path.endswith("iter_0003_stage_01_opt_iter_0040.obj")
+    v, f = [], []
+    for line in open(path):
+        t = line.split()
+        if t[0] == "v":
+            v.append([float(x) for x in t[1:]])
+        elif t[0] == "f":
+            f.append([int(x) for x in t[1:]])
+    v, f = np.array(v), np.array(f)
+    assert v.shape == (1556, 3) and f.shape == (3076, 3)
+    assert np.array_equal(f - 1, np.concatenate([right["faces"], left["faces"] + 778], 0))     # bit-exact face index
+    assert f.min() == 1 and f.max() == 1556
+    np.testing.assert_allclose(v[:778], pred["pred_right_hand_verts"][1], atol=5e-7)
+    np.testing.assert_allclose(v[778:], pred["pred_left_hand_verts"][1], atol=5e-7)
