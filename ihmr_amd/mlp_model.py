@@ -174,9 +174,9 @@ class MLPModel:
         gt = self.joints_3d.clone()
         w0 = gt[:, 0, 3]
         root = torch.where(w0 > 0.5, 0, torch.where(w0 < 1e-7, 21, -1))
-        for b in range(gt.shape[0]):
-            if int(root[b]) >= 0:
-                gt[b, :, :3] = gt[b, :, :3] - gt[b, int(root[b]):int(root[b]) + 1, :3]
+        has = (root >= 0)
+        ref = gt[torch.arange(gt.shape[0], device=gt.device), root.clamp(min=0), :3]          # (B,3) root joint of every sample
+        gt[:, :, :3] = gt[:, :, :3] - ref[:, None, :] * has[:, None, None].to(gt.dtype)         # rows without a root: minus an exact zero
         return OrderedDict(
             pred_cam_params=n(self.pred_cam_params), pred_pose_params=n(self.pred_pose_params), pred_shape_params=n(self.pred_shape_params),
             pred_hand_trans=n(self.pred_hand_trans), gt_right_hand_verts=n(self.gt_right_hand_verts), gt_left_hand_verts=n(self.gt_left_hand_verts),
