@@ -447,6 +447,8 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
     if (M <= 64) {
         pick = wide_ok ? 1 : 3;
         ksplit = (int)std::max<long>(1, std::min<long>(std::min<long>(8, cap), nk / 8));
+    } else if (blocks(pick) < 64) {      // a handful of workgroups (Linear layers at batch 128): deep split as above
+        ksplit = (int)std::max<long>(1, std::min<long>(std::min<long>(8, cap), nk / 8));
     } else if (blocks(pick) < 384 && nk >= 64 && cap >= 2) {
         ksplit = 2;
     }
