@@ -400,7 +400,6 @@ struct LbsBwdShared {
     float dJ[NJ][3];
     float gsum[3];        // TWO_HAND: sum of the left-hand output gradients (= d L / d shift)
     float gj[21][3];      // joint gradients (raw hand frame)
-    float red[LBS_THREADS];
     int par[NJ], dep[NJ];         // kinematic tree (parents, depth), staged once: the chain loops read them many times
     int nchild[NJ], child[NJ][NJ];  // children of every joint in index order (built in-kernel from par)
     float wsum[LBS_THREADS / WAVE][4];

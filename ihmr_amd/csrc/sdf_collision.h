@@ -441,12 +441,12 @@ __device__ __forceinline__ float sdf_point_tri_dist2(const float* a, const float
 }
 
 // ------------------------------------------------------------------------------------- distance
-// grid = SDF_DIST_BLOCKS, block = 256 (4 waves).  The inside voxels of the whole batch sit in one list (balanced
-// work matters more here than L2 affinity: the per-sample counts vary by 3x).  A work item = 32 consecutive list entries = inside
-// voxels of ONE hand: the workgroup stages that hand's 1538 bounding spheres in LDS (25 KB), then each wave
-// takes 8 voxels.  Per voxel: wave-level min-reduction over the mesh (lanes across triangles) -- sphere pass
-// for the upper bound, cull, scan-compacted survivors, exact closest-point distance on dense lanes, DPP min.
-// Keeping the table in LDS instead of registers leaves ~70 VGPRs, i.e. 5 workgroups per CU to hide latency.
+// grid = SDF_DIST_BLOCKS, block = 256 (4 waves), 4 workgroups per CU (<= 128 VGPRs, 36 KB LDS).  The inside voxels of
+// the whole batch sit in one list (balanced work matters more here than L2 affinity: the per-sample counts vary
+// by 3x).  A work item = SDF_ITEM (16) consecutive list entries = inside voxels of ONE hand: the workgroup stages
+// that hand's 1538 bounding spheres in LDS (32 KB), then each wave takes 4 voxels, two at a time through the
+// sphere passes (lanes across triangles, packed fp32 on the voxel pair): upper bound = nearest centroid, cull,
+// scan-compacted survivors, exact closest-point distance on dense lanes, DPP min.
 typedef float sdf_v2f __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace ws, int collect_stats) {
     __shared__ float4 sph_s[NFP];
