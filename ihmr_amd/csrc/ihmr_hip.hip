@@ -117,6 +117,13 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
     m->nnz = (int)wv.size();
     m->nseg = (int)seg_q.size() - 1;
     if (m->nseg > LBS_SEG_CAP) { ihmr_mano_destroy(m); return -1; }
+    // lbs_bwd1 keeps the per-segment partial sums in dynamic LDS (48 B per segment on top of ~36 KB static): dense
+    // weight matrices (up to ~960 segments) go past the default 64 KB per workgroup, so raise the cap to what is needed
+    {
+        const int dyn = m->nseg * 12 * (int)sizeof(float);
+        (void)hipFuncSetAttribute((const void*)lbs_bwd1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+        (void)hipFuncSetAttribute((const void*)lbs_bwd1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    }
     if (rc) return rc;
     *out = m;
     return 0;

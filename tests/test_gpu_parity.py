@@ -387,3 +387,31 @@ def test_opt_200_iterations_match_oracle(mano_arrays):
     mp_ref, mp_got = float(r["collision_loss_origin_scale"].mean()), float(g["collision_loss_origin_scale"].mean())
     print(f"[parity] 200 iterations: mean penetration depth ref={mp_ref:.6e} got={mp_got:.6e}")
     assert abs(mp_ref - mp_got) < 1e-4
+
+
+def test_lbs_backward_with_dense_skinning_weights(mano_arrays):
+    """A weight matrix without zeros (every vertex bound to all 16 bones): ~960 dA segments, i.e. 46 KB of dynamic LDS
+    on top of the static 36 KB of lbs_bwd1 -- beyond the default per-workgroup limit, the library has to raise it.
+    Gradients against autograd through the oracle."""
+    from ihmr_amd import mano
+    from oracle.mano_ref import ManoRef
+    right = dict(mano_arrays[0])
+    rng = np.random.RandomState(5)
+    w = np.abs(rng.rand(778, 16)).astype(np.float32) * 0.02 + right["lbs_weights"]
+    right["lbs_weights"] = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    N = 3
+    g = torch.Generator().manual_seed(9)
+    o, p, b = (torch.randn(N, 3, generator=g) * 0.3), (torch.randn(N, 45, generator=g) * 0.2), torch.randn(N, 10, generator=g) * 0.5
+    wv, wj = torch.randn(N, 778, 3, generator=g), torch.randn(N, 16, 3, generator=g)
+
+    def run(mod, dev):
+        oo, pp, bb = (t.clone().to(dev).requires_grad_(True) for t in (o, p, b))
+        out = mod(global_orient=oo, hand_pose=pp, betas=bb)
+        ((out.vertices * wv.to(dev)).sum() + (out.joints * wj.to(dev)).sum()).backward()
+        return out.vertices.detach().cpu(), [t.grad.cpu() for t in (oo, pp, bb)]
+
+    v_ref, g_ref = run(ManoRef(right), "cpu")
+    v_got, g_got = run(mano.MANO(right).to(_dev()), _dev())
+    _report("dense-weights verts", v_got, v_ref, atol=2e-6)
+    for name, a, r in zip(("orient", "pose", "betas"), g_got, g_ref):
+        _report(f"dense-weights d{name}", a, r, atol=3e-5 * float(r.abs().max()))
