@@ -147,21 +147,28 @@ __device__ __forceinline__ float sdf_ray_t(int i, float ax, float e1x, float e1y
 // every needed voxel gives -- without the per-voxel loop.  In real arithmetic t_i = x* - px_i: it falls by exactly
 // 1/16 per voxel (up to the rounding of det and 1/det, delta below), so one evaluation at the lowest needed
 // voxel places the crossing index ic = lo + 16 t_lo.  Voxels a whole index away from ic have |t| >= 1/16, far
-// above the rounding error E of the float expression (bounded term by term below), so their sign is known;
+// above the rounding error E of the float expression (bounded per triangle by sdf_ray_tri_safe), so their sign is known;
 // the (at most two) voxels next to the crossing are evaluated with the exact expression.  Whenever the bound
 // does not hold (near-degenerate triangles: huge 1/det) every needed voxel is evaluated.
-__device__ __forceinline__ unsigned sdf_ray_hits(unsigned need, float ax, float e1x, float e1y, float e1z, float e2x, float e2y,
-                                                 float e2z, float inv, float sy, float sz, float qx) {
+// Per-triangle part of the error bound of sdf_ray_hits: true iff, for EVERY column and voxel of the grid, the float
+// expression of t differs from the real one by well under a voxel step.  |float t - real t| <= E = 16 u S |1/det| with
+// S the sum of the magnitudes of the terms (|s| <= 2 anywhere in the [-1,1]^3 grid), and the real slope of t
+// along x is -(1 + delta)/16 with |delta| <= 4 u (|e1z e2y| + |e1y e2z|) |1/det| + 4 u  (rounding of det and 1/det).
+__device__ __forceinline__ bool sdf_ray_tri_safe(float e1x, float e1y, float e1z, float e2x, float e2y, float e2z, float inv) {
     const float U = 5.9604645e-8f;   // 2^-24
-    const int lo = __ffs((int)need) - 1, hi = 31 - __clz((int)need);
+    const float ainv = fabsf(inv), smax = 2.0f;
+    const float qx_max = smax * (fabsf(e1z) + fabsf(e1y));
+    const float S = fabsf(e2x) * qx_max + fabsf(e2y) * smax * (fabsf(e1x) + fabsf(e1z)) + fabsf(e2z) * smax * (fabsf(e1y) + fabsf(e1x));
+    const float E = 16.0f * U * S * ainv;
+    const float delta = 4.0f * U * (fabsf(e1z * e2y) + fabsf(e1y * e2z)) * ainv + 4.0f * U;
+    return E + 2.0f * delta < (1.0f / 64.0f);
+}
+
+__device__ __forceinline__ unsigned sdf_ray_hits(unsigned need, bool tri_safe, float ax, float e1x, float e1y, float e1z, float e2x,
+                                                 float e2y, float e2z, float inv, float sy, float sz, float qx) {
+    const int lo = __ffs((int)need) - 1;
     const float t_lo = sdf_ray_t(lo, ax, e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx);
-    const float ainv = fabsf(inv);
-    const float smax = fmaxf(fabsf((float)(2 * lo + 1) / (float)SDF_G - 1.0f - ax), fabsf((float)(2 * hi + 1) / (float)SDF_G - 1.0f - ax));
-    const float S = fabsf(e2x * qx) + fabsf(e2y) * (fabsf(sz * e1x) + smax * fabsf(e1z)) +
-                    fabsf(e2z) * (smax * fabsf(e1y) + fabsf(sy * e1x));
-    const float E = 16.0f * U * S * ainv;                                                    // |float t - real t|
-    const float delta = 4.0f * U * (fabsf(e1z * e2y) + fabsf(e1y * e2z)) * ainv + 4.0f * U;  // |det_real / det_float - 1|
-    if (!(E + 2.0f * delta < (1.0f / 64.0f))) {
+    if (!tri_safe) {
         unsigned hits = 0, rem = need;
         while (rem) {
             const int i = __ffs((int)rem) - 1;
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
 #endif
         if (!ok) continue;                                   // degenerate in yz: the +x ray never counts it
         const float inv = 1.0f / det;
+        const bool tri_safe = sdf_ray_tri_safe(e1x, e1y, e1z, e2x, e2y, e2z, inv);
         int j0, j1, k0, k1;
         tri_col_range(a[1], bb[1], c[1], a[2], bb[2], c[2], j0, j1, k0, k1);
 #ifdef IHMR_TIMING
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             const float vv = qx * inv;
             st_tests += 1;
             if (!((uu >= 0.0f) && (uu <= 1.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f))) continue;
-            const unsigned hits = sdf_ray_hits(need, a[0], e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx);
+            const unsigned hits = sdf_ray_hits(need, tri_safe, a[0], e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx);
             st_tests += __popc(need);
             if (hits) atomicXor(&parity[col], hits);
         }
