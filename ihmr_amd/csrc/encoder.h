@@ -73,6 +73,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(
 
     float4 areg[A_F4], breg[B_F4];
     int tap_h = 0, tap_w = 0, tap_c = 0;                   // filter tap / channel offset of the NEXT tile to load (fast path)
+    int gc[A_F4], gfw[A_F4], gfh[A_F4];                    // generic path: (channel, tap column, tap row) of each loader's element 0
+    const int gstep_c = CONV_BK % a.Cin, gstep_t = CONV_BK / a.Cin;
     auto load_tile = [&](int kc) {
         const int k0 = kc * CONV_BK;
 #pragma unroll
@@ -83,17 +85,25 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(
                 areg[i] = ok ? *reinterpret_cast<const float4*>(a.x + ((size_t)(an[i] * a.H + hi) * a.W + wi) * a.ldx + tap_c + ak4[i])
                              : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
+                // generic gather (Cin not a multiple of 16, i.e. the 7x7 stem with Cin = 3): element e of the float4 is
+                // k = k0 + ak4 + e; its (channel, tap column, tap row) is carried incrementally, no div / mod in the loop
                 float v[4];
+                int c = gc[i], fw = gfw[i], fh = gfh[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int k = k0 + ak4[i] + e;
                     v[e] = 0.f;
-                    if (am_ok[i] && k < K) {
-                        const int c = k % a.Cin, tap = k / a.Cin, fh = tap / a.kw, fw = tap % a.kw;
+                    if (am_ok[i] && fh < a.kh) {                 // fh >= kh: past the last tap (zero-padded K)
                         const int hi = aho[i] * a.stride + fh - a.pad, wi = awo[i] * a.stride + fw - a.pad;
                         if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) v[e] = a.x[((size_t)(an[i] * a.H + hi) * a.W + wi) * a.ldx + c];
                     }
+                    if (++c == a.Cin) { c = 0; if (++fw == a.kw) { fw = 0; ++fh; } }
                 }
+                // advance this loader's element 0 by one K tile (16 elements)
+                gc[i] += gstep_c;
+                int tapinc = gstep_t;
+                if (gc[i] >= a.Cin) { gc[i] -= a.Cin; ++tapinc; }
+                gfw[i] += tapinc;
+                while (gfw[i] >= a.kw) { gfw[i] -= a.kw; ++gfh[i]; }
                 areg[i] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
@@ -129,6 +139,13 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(
     const int nk_all = Kpad / CONV_BK, nk_per = (nk_all + a.ksplit - 1) / a.ksplit;
     const int kc0 = blockIdx.z * nk_per, kc1 = min(nk_all, kc0 + nk_per);
     if (fast) { const int k0 = kc0 * CONV_BK, tap = k0 / a.Cin; tap_c = k0 % a.Cin; tap_h = tap / a.kw; tap_w = tap % a.kw; }
+    else {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int k = kc0 * CONV_BK + ak4[i], tap = k / a.Cin;
+            gc[i] = k % a.Cin; gfw[i] = tap % a.kw; gfh[i] = tap / a.kw;
+        }
+    }
     const int kl = lane >> 5, l31 = lane & 31;
     if (kc0 < kc1) {
         load_tile(kc0);
