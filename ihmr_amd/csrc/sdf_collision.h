@@ -19,7 +19,7 @@
 #include "ihmr_common.h"
 
 #define SDF_THREADS 256
-#define SDF_PREP_THREADS 1024
+#define SDF_PREP_THREADS 512
 #define SDF_NCOL (SDF_G * SDF_G)   // 1024 columns (k,j)
 #define SDF_EVAL_CHUNKS 8          // workgroups per hand in the parity kernel
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
@@ -86,18 +86,15 @@ struct VertLayout {
 // grid_sample un-normalisation, align_corners = False: ((x + 1) * G - 1) / 2
 __device__ __forceinline__ float sdf_unnorm(float x) { return ((x + 1.0f) * (float)SDF_G - 1.0f) / 2.0f; }
 
-// exclusive prefix sum of data[0..1023] (LDS) by 1024 threads (one element each); returns the total.
-__device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >= 16 ints, LDS */) {
+// exclusive prefix sum of data[0..1023] (LDS) by SDF_PREP_THREADS = 512 threads, thread t owning the adjacent
+// elements 2t and 2t+1; returns the total.
+__device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >= 8 ints, LDS */) {
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
     __syncthreads();
-    const int mine = data[tid];
-    int inc = mine;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const int t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
-    if (lane == WAVE - 1) scratch[wave] = inc;
+    const int m0 = data[2 * tid], m1 = data[2 * tid + 1];
+    int wtot;
+    const int inc = wave_incl_scan(m0 + m1, wtot);
+    if (lane == WAVE - 1) scratch[wave] = wtot;
     __syncthreads();
     int base = 0, total = 0;
 #pragma unroll
@@ -107,7 +104,8 @@ __device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >
         total += x;
     }
     __syncthreads();
-    data[tid] = base + inc - mine;
+    data[2 * tid] = base + inc - (m0 + m1);
+    data[2 * tid + 1] = base + inc - m1;
     __syncthreads();
     return total;
 }
@@ -207,23 +205,28 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
 #ifdef IHMR_TIMING
     if (tid == 0 && blockIdx.x < 1024) g_blk[0][blockIdx.x] = wall_clock64();
 #endif
-    // ---- bounding box (min / max are exact, any order)
+    // ---- bounding box (min / max are exact, any order); a thread owns vertices tid and tid + 512
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    float oq[3] = {0.f, 0.f, 0.f};
-    if (tid < NV) {
+    float oq[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float x = own[3 * tid + k];
-            oq[k] = other[3 * tid + k];
-            vn[3 * tid + k] = x;
-            mn[k] = x;
-            mx[k] = x;
+    for (int rep = 0; rep < 2; ++rep) {
+        const int v = tid + rep * SDF_PREP_THREADS;
+        if (v < NV) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float x = own[3 * v + k];
+                oq[rep][k] = other[3 * v + k];
+                vn[3 * v + k] = x;
+                mn[k] = fminf(mn[k], x);
+                mx[k] = fmaxf(mx[k], x);
+            }
         }
     }
-    // face indices of this lane's (up to two) triangles: issued early, consumed after the box is known
-    int fidx[2][3];
+    // face indices of this lane's (up to four) triangles: issued early, consumed after the box is known
+    constexpr int TRI_IT = (NFP + SDF_PREP_THREADS - 1) / SDF_PREP_THREADS;
+    int fidx[TRI_IT][3];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < TRI_IT; ++it) {
         const int f = min(tid + it * SDF_PREP_THREADS, NFP - 1);
         fidx[it][0] = faces[f]; fidx[it][1] = faces[NFP + f]; fidx[it][2] = faces[2 * NFP + f];
     }
@@ -232,8 +235,11 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         const float a = wave_reduce_min(mn[k]), c = wave_reduce_max(mx[k]);
         if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = c; }
     }
-    needed[tid] = DENSE ? 0xffffffffu : 0u;
-    parity[tid] = 0u;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        needed[tid + rep * SDF_PREP_THREADS] = DENSE ? 0xffffffffu : 0u;
+        parity[tid + rep * SDF_PREP_THREADS] = 0u;
+    }
     __syncthreads();
     if (tid == 0) {
         float lo[3], hi[3];
@@ -252,12 +258,15 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     if (tid < 4) ws.box[H * 4 + tid] = box[tid];
     TSTAMP(21);
     // ---- normalise own vertices into [-1,1]^3; which voxels will the other hand's vertices read?
-    if (tid < NV) {
-        vn[3 * tid] = (vn[3 * tid] - cx) / sc;
-        vn[3 * tid + 1] = (vn[3 * tid + 1] - cy) / sc;
-        vn[3 * tid + 2] = (vn[3 * tid + 2] - cz) / sc;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int v = tid + rep * SDF_PREP_THREADS;
+        if (v >= NV) break;
+        vn[3 * v] = (vn[3 * v] - cx) / sc;
+        vn[3 * v + 1] = (vn[3 * v + 1] - cy) / sc;
+        vn[3 * v + 2] = (vn[3 * v + 2] - cz) / sc;
         if (!DENSE) {
-            const float qx = (oq[0] - cx) / sc, qy = (oq[1] - cy) / sc, qz = (oq[2] - cz) / sc;
+            const float qx = (oq[rep][0] - cx) / sc, qy = (oq[rep][1] - cy) / sc, qz = (oq[rep][2] - cz) / sc;
             const float ix = sdf_unnorm(qx), iy = sdf_unnorm(qy), iz = sdf_unnorm(qz);
             const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
             // completely outside the grid (or non-finite): contributes nothing
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     float4* abc = ws.abc + (size_t)H * NFP * 3;
     unsigned long long st_tests = 0;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < TRI_IT; ++it) {
         const int f = tid + it * SDF_PREP_THREADS;
         if (f >= NFP) break;
         const int fa = fidx[it][0], fb = fidx[it][1], fc = fidx[it][2];
@@ -352,19 +361,24 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
 #endif
     __syncthreads();
     TSTAMP(27);
-    // ---- publish: thread = column; phi = 0 for the outside voxels, inside voxels into the batch-wide list
+    // ---- publish: a thread owns the adjacent columns 2 tid and 2 tid + 1; phi = 0 for the outside voxels, inside voxels
+    //      into the batch-wide list
     float* phi = ws.phi + (size_t)H * SDF_NVOX;
-    const unsigned need = needed[tid];
-    const unsigned inside = parity[tid] & need;
-    {
-        unsigned rem = need & ~inside;
+    unsigned need2[2], inside2[2];
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int col = 2 * tid + rep;
+        need2[rep] = needed[col];
+        inside2[rep] = parity[col] & need2[rep];
+        unsigned rem = need2[rep] & ~inside2[rep];
         while (rem) {
             const int i = __ffs((int)rem) - 1;
             rem &= rem - 1;
-            phi[tid * SDF_G + i] = 0.0f;
+            phi[col * SDF_G + i] = 0.0f;
         }
+        cur[col] = __popc(inside2[rep]);
     }
-    cur[tid] = __popc(inside);
+    const unsigned need = need2[0];   // (work counters below)
     const int blk_total = block_excl_scan_1024(cur, scratch);
     const int xcd = 0;   // one batch-wide list: balanced work items matter more here than L2 affinity
     // the hand's inside voxels occupy a 16-aligned run of the list (tail padded with an invalid marker),
@@ -374,14 +388,16 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     __syncthreads();
     TSTAMP(28);
     if (tid < blk_padded - blk_total) ws.inside_list[(size_t)xcd * ws.xcd_cap + blk_base + blk_total + tid] = 0xffffffffu;
-    {
-        unsigned* glist = ws.inside_list + (size_t)xcd * ws.xcd_cap + blk_base + cur[tid];
-        unsigned rem = inside;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int col = 2 * tid + rep;
+        unsigned* glist = ws.inside_list + (size_t)xcd * ws.xcd_cap + blk_base + cur[col];
+        unsigned rem = inside2[rep];
         int o = 0;
         while (rem) {
             const int i = __ffs((int)rem) - 1;
             rem &= rem - 1;
-            glist[o++] = ((unsigned)H << 16) | (unsigned)(tid * SDF_G + i);
+            glist[o++] = ((unsigned)H << 16) | (unsigned)(col * SDF_G + i);
         }
     }
     TSTAMP(29);
@@ -389,7 +405,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         unsigned long long c = st_tests;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        unsigned long long nv = (unsigned long long)__popc(need);
+        unsigned long long nv = (unsigned long long)(__popc(need) + __popc(need2[1]));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nv += __shfl_xor(nv, o);
         if (lane == 0) { atomicAdd(&ws.stats[0], c); atomicAdd(&ws.stats[3], nv); }   // ray tests, needed voxels
