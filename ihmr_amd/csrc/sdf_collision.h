@@ -20,6 +20,8 @@
 
 #define SDF_THREADS 256
 #define SDF_PREP_THREADS 512
+#define SDF_PREP_CPT (SDF_NCOL / SDF_PREP_THREADS)                         // adjacent grid columns owned by a thread
+#define SDF_PREP_VPT ((NV + SDF_PREP_THREADS - 1) / SDF_PREP_THREADS)   // vertices owned by a thread
 #define SDF_NCOL (SDF_G * SDF_G)   // 1024 columns (k,j)
 #define SDF_EVAL_CHUNKS 8          // workgroups per hand in the parity kernel
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
@@ -86,14 +88,16 @@ struct VertLayout {
 // grid_sample un-normalisation, align_corners = False: ((x + 1) * G - 1) / 2
 __device__ __forceinline__ float sdf_unnorm(float x) { return ((x + 1.0f) * (float)SDF_G - 1.0f) / 2.0f; }
 
-// exclusive prefix sum of data[0..1023] (LDS) by SDF_PREP_THREADS = 512 threads, thread t owning the adjacent
-// elements 2t and 2t+1; returns the total.
-__device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >= 8 ints, LDS */) {
+// exclusive prefix sum of data[0..1023] (LDS) by SDF_PREP_THREADS threads, thread t owning the SDF_PREP_CPT adjacent
+// elements from SDF_PREP_CPT * t; returns the total.
+__device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >= SDF_PREP_THREADS / 64 ints, LDS */) {
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
     __syncthreads();
-    const int m0 = data[2 * tid], m1 = data[2 * tid + 1];
+    int m[SDF_PREP_CPT], mine = 0;
+#pragma unroll
+    for (int c = 0; c < SDF_PREP_CPT; ++c) { m[c] = data[SDF_PREP_CPT * tid + c]; mine += m[c]; }
     int wtot;
-    const int inc = wave_incl_scan(m0 + m1, wtot);
+    const int inc = wave_incl_scan(mine, wtot);
     if (lane == WAVE - 1) scratch[wave] = wtot;
     __syncthreads();
     int base = 0, total = 0;
@@ -104,8 +108,9 @@ __device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >
         total += x;
     }
     __syncthreads();
-    data[2 * tid] = base + inc - (m0 + m1);
-    data[2 * tid + 1] = base + inc - m1;
+    int run = base + inc - mine;
+#pragma unroll
+    for (int c = 0; c < SDF_PREP_CPT; ++c) { data[SDF_PREP_CPT * tid + c] = run; run += m[c]; }
     __syncthreads();
     return total;
 }
@@ -123,7 +128,7 @@ __device__ __forceinline__ void tri_col_range(float y0, float y1, float y2, floa
 
 // ------------------------------------------------------------------------------------- prep + parity
 // grid = 2B (block id = hand id H = hnd*B + b, so both hands of sample b sit on XCD b % 8 when B % 8 == 0),
-// block = 1024.  Everything up to the inside/outside decision of a hand happens here, out of LDS:
+// block = SDF_PREP_THREADS (512).  Everything up to the inside/outside decision of a hand happens here, out of LDS:
 //   box -> normalised vertices -> needed-voxel mask (one 32-bit word per (k,j) column)
 //   -> lane = triangle: sphere + abc records to HBM for the distance kernel; for every needed column whose
 //      centre lies in the triangle's yz bounding box the (u,v) ray test, and for a hit the t > 0 test of the
@@ -205,11 +210,12 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
 #ifdef IHMR_TIMING
     if (tid == 0 && blockIdx.x < 1024) g_blk[0][blockIdx.x] = wall_clock64();
 #endif
-    // ---- bounding box (min / max are exact, any order); a thread owns vertices tid and tid + 512
+    // ---- bounding box (min / max are exact, any order); a thread owns vertices tid, tid + SDF_PREP_THREADS, ...
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    float oq[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    float oq[SDF_PREP_VPT][3];
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < SDF_PREP_VPT; ++rep) {
+        oq[rep][0] = oq[rep][1] = oq[rep][2] = 0.f;
         const int v = tid + rep * SDF_PREP_THREADS;
         if (v < NV) {
 #pragma unroll
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = c; }
     }
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < SDF_PREP_CPT; ++rep) {
         needed[tid + rep * SDF_PREP_THREADS] = DENSE ? 0xffffffffu : 0u;
         parity[tid + rep * SDF_PREP_THREADS] = 0u;
     }
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     TSTAMP(21);
     // ---- normalise own vertices into [-1,1]^3; which voxels will the other hand's vertices read?
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < SDF_PREP_VPT; ++rep) {
         const int v = tid + rep * SDF_PREP_THREADS;
         if (v >= NV) break;
         vn[3 * v] = (vn[3 * v] - cx) / sc;
@@ -361,13 +367,13 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
 #endif
     __syncthreads();
     TSTAMP(27);
-    // ---- publish: a thread owns the adjacent columns 2 tid and 2 tid + 1; phi = 0 for the outside voxels, inside voxels
+    // ---- publish: a thread owns SDF_PREP_CPT adjacent columns; phi = 0 for the outside voxels, inside voxels
     //      into the batch-wide list
     float* phi = ws.phi + (size_t)H * SDF_NVOX;
-    unsigned need2[2], inside2[2];
+    unsigned need2[SDF_PREP_CPT], inside2[SDF_PREP_CPT];
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int col = 2 * tid + rep;
+    for (int rep = 0; rep < SDF_PREP_CPT; ++rep) {
+        const int col = SDF_PREP_CPT * tid + rep;
         need2[rep] = needed[col];
         inside2[rep] = parity[col] & need2[rep];
         unsigned rem = need2[rep] & ~inside2[rep];
@@ -378,7 +384,6 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         }
         cur[col] = __popc(inside2[rep]);
     }
-    const unsigned need = need2[0];   // (work counters below)
     const int blk_total = block_excl_scan_1024(cur, scratch);
     const int xcd = 0;   // one batch-wide list: balanced work items matter more here than L2 affinity
     // the hand's inside voxels occupy a 16-aligned run of the list (tail padded with an invalid marker),
@@ -389,8 +394,8 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     TSTAMP(28);
     if (tid < blk_padded - blk_total) ws.inside_list[(size_t)xcd * ws.xcd_cap + blk_base + blk_total + tid] = 0xffffffffu;
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int col = 2 * tid + rep;
+    for (int rep = 0; rep < SDF_PREP_CPT; ++rep) {
+        const int col = SDF_PREP_CPT * tid + rep;
         unsigned* glist = ws.inside_list + (size_t)xcd * ws.xcd_cap + blk_base + cur[col];
         unsigned rem = inside2[rep];
         int o = 0;
@@ -405,7 +410,9 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         unsigned long long c = st_tests;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        unsigned long long nv = (unsigned long long)(__popc(need) + __popc(need2[1]));
+        unsigned long long nv = 0;
+#pragma unroll
+        for (int rep = 0; rep < SDF_PREP_CPT; ++rep) nv += (unsigned long long)__popc(need2[rep]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nv += __shfl_xor(nv, o);
         if (lane == 0) { atomicAdd(&ws.stats[0], c); atomicAdd(&ws.stats[3], nv); }   // ray tests, needed voxels
