@@ -112,7 +112,7 @@ typedef struct ihmr_opt_io {
     float* snap_params;  /* (S_max, B, 90) active parameters, right hand first */
     float* snap_loss;    /* (S_max, 2, B): joints_3d_loss_p_batch, collision_loss_batch */
     int32_t* selected;   /* (B) argmin index of the last stage */
-    /* Adam state, zeroed by ihmr_opt_stage_begin */
+    /* Adam state, zeroed by the first kernel of every stage */
     float* adam_m;       /* (B,90) */
     float* adam_v;       /* (B,90) */
     void* workspace;     /* ihmr_opt_workspace_bytes(B) */
@@ -154,14 +154,14 @@ int ihmr_opt_forward_graph_create(const ihmr_mano* m, const ihmr_mano* m_left, c
 int ihmr_graph_launch(ihmr_graph* g, void* stream);
 int ihmr_graph_destroy(ihmr_graph* g);
 
-/* diagnostics (synchronises): forward + losses once with the SDF work counters on; out4 (host) =
- * {(voxel,triangle) ray tests, exact point-triangle distances, inside voxels, needed voxels} of one
- * sdf_prep_kernel + sdf_dist_kernel launch pair -- the algorithmic work bench.py prices the roofline with. */
 /* Scatter the reference's packed prediction vector `final_params` (B,122) = [cam 3 | right orient 3 | right pose 45 |
  * left orient 3 | left pose 45 | right shape 10 | left shape 10 | trans 3] (baseline_model.py:262-270,
  * mlp_model.py:426-439) into io->cam / orient / pose / shape / trans. */
 int ihmr_opt_set_params(const ihmr_opt_io* io, const float* final_params, int B, void* stream);
 
+/* diagnostics (synchronises): forward + losses once with the SDF work counters on; out4 (host) =
+ * {(voxel,triangle) ray tests, exact point-triangle distances, inside voxels, needed voxels} of one
+ * sdf_prep_kernel + sdf_dist_kernel launch pair -- the algorithmic work bench.py prices the roofline with. */
 int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                        const ihmr_opt_weights* w, unsigned long long* out4, void* stream);
 
@@ -190,8 +190,8 @@ int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_joints_3d, co
                       const float* sample_scale, const unsigned char* interacting, int B, double* out6, void* stream);
 
 /* per-kernel timing hook for bench.py: when non-NULL, the library records hipEvents around the
- * dominant kernel on `stream` and accumulates (count, ms) here; host pointer, read after sync */
-/* While a timer is set, every call launches the (idempotent) kernel 8 times back to back between ONE pair of events;
+ * dominant kernel (sdf_dist_kernel) on `stream` and accumulates (count, ms) here; host pointer, read after sync.
+ * While a timer is set, every call launches the (idempotent) kernel 8 times back to back between ONE pair of events;
  * n_sdf_eval counts launches.  ms_event_pair: an EMPTY event pair recorded right before each timed group, i.e. what
  * the two event records cost by themselves; (ms_sdf_eval - ms_event_pair) / n_sdf_eval is the launch duration. */
 typedef struct ihmr_kernel_timer { double ms_sdf_eval; long n_sdf_eval; double algo_flops_sdf_eval; double ms_event_pair; } ihmr_kernel_timer;
