@@ -11,6 +11,7 @@
 #include "ihmr_common.h"
 #include "mano_lbs.h"
 #include "sdf_collision.h"
+#include "preprocess.h"
 #include "refine.h"
 #include "encoder.h"
 #include "evaluate.h"
@@ -505,6 +506,16 @@ extern "C" int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_jo
     if (!pred_joints_3d || !gt_joints_3d || !coll_origin_scale || !out6 || B <= 0) return -1;
     hipLaunchKernelGGL(eval_metrics_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pred_joints_3d, gt_joints_3d, coll_origin_scale,
                        sample_scale, interacting, B, out6);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ image preprocessing
+extern "C" int ihmr_preprocess_images(const uint8_t* pixels, const int64_t* offsets, const int32_t* sizes, const uint8_t* do_flip,
+                                      int B, int final_size, float* img_out, uint8_t* img_u8, const float* joints_in,
+                                      float* joints_out, void* stream) {
+    if (!pixels || !offsets || !sizes || !img_out || B <= 0 || final_size <= 0 || (joints_in && !joints_out)) return -1;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((final_size * final_size + PRE_THREADS - 1) / PRE_THREADS, B), dim3(PRE_THREADS), 0,
+                       (hipStream_t)stream, pixels, offsets, sizes, do_flip, final_size, img_out, img_u8, joints_in, joints_out);
     return (int)hipGetLastError();
 }
 

@@ -189,6 +189,22 @@ int ihmr_avgpool_relu(const float* x, float* y, int N, int HW, int C, int ldy, v
 int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_joints_3d, const float* coll_origin_scale,
                       const float* sample_scale, const unsigned char* interacting, int B, double* out6, void* stream);
 
+/* ------------------------------------------------------------------ image preprocessing */
+/* What the reference's DataLoader workers do per image on the CPU before the encoder sees it, for a whole batch:
+ * `DataProcessor.padding_and_resize` (data/data_preprocess.py:45-60: longer side -> final_size with `cv2.resize`
+ * [INTER_LINEAR on uint8 BGR], zero padding bottom / right), the test-time flip of left-only samples
+ * (`random_flip(do_flip=True)`, data_preprocess.py:63-72, baseline_dataset.py:71-74: image mirrored, the two hands'
+ * 2-D joints swapped and x -> final_size - x), `normalize_joints_2d` (data_preprocess.py:162-169) and
+ * `ToTensor` + `Normalize(0.5, 0.5)` (baseline_dataset.py:41-44,202).
+ * pixels: the B raw images back to back, each (H,W,3) uint8 as `cv2.imread` returns it (BGR, row-major);
+ * offsets (B) int64: byte offset of image b in `pixels`;  sizes (B,2) int32: H, W;  do_flip (B) bytes or NULL.
+ * img_out (B,3,final_size,final_size) float32 in [-1,1];  img_u8 optional (B,final_size,final_size,3) = the padded
+ * uint8 image itself;  joints_in / joints_out optional (B,42,3) [x, y in source pixels, weight] -> [x, y in [-1,1], weight].
+ * Every image must keep at least one pixel per side after the resize (the host wrapper checks, as cv2 would raise). */
+int ihmr_preprocess_images(const uint8_t* pixels, const int64_t* offsets, const int32_t* sizes, const uint8_t* do_flip,
+                           int B, int final_size, float* img_out, uint8_t* img_u8, const float* joints_in,
+                           float* joints_out, void* stream);
+
 /* per-kernel timing hook for bench.py: when non-NULL, the library records hipEvents around the
  * dominant kernel (sdf_dist_kernel) on `stream` and accumulates (count, ms) here; host pointer, read after sync.
  * While a timer is set, every call launches the (idempotent) kernel 8 times back to back between ONE pair of events;

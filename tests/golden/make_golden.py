@@ -9,7 +9,8 @@ its two third-party seams (``smplx`` MANO layer, ``sdf`` collision module: absen
 8(c)); there this build's CPU restatements (``oracle/mano_ref.py``, ``oracle/sdf_ref.py``) are
 injected, so the fixtures pin everything AROUND those seams: loss terms and their gradients,
 Rodrigues / projection, snapshot filter + select, the full ``OptimizeModel.optimize()`` trajectory
-logic, the ResNet-50 encoder + IEF head, the MLP refinement head, and the evaluator metrics.
+logic, the ResNet-50 encoder + IEF head, the MLP refinement head, the evaluator metrics, and the image
+preprocessing around ``cv2.resize`` (third seam of that kind: ``oracle/preprocess_ref.py``).
 """
 import os
 import os.path as osp
@@ -293,11 +294,47 @@ def gen_mlp_test(ns):
     np.savez_compressed(osp.join(HERE, "mlp_test.npz"), **t2n(out))
     print("mlp_test.npz", {k: np.asarray(v).shape for k, v in res.items() if k.startswith("pred_")})
 
+def gen_preprocess(ns):
+    """The reference's own ``DataProcessor.padding_and_resize`` / ``random_flip(do_flip=True)`` /
+    ``normalize_joints_2d`` (data/data_preprocess.py:45-72,162-169) run on seeded images, with ``cv2.resize``
+    (absent) replaced by ``oracle/preprocess_ref.resize_linear_u8``; ToTensor + Normalize are torch's own float32
+    ops (``div(255)``, ``sub_(0.5).div_(0.5)``, what torchvision 0.7 does).  Pins the size arithmetic, the padding,
+    the joint scaling / flip / normalisation and the float conversion -- not the resize itself."""
+    import importlib
+    import types
+    from oracle import preprocess_ref as P
+    dp = importlib.import_module("data.data_preprocess")
+    sys.modules["cv2"].resize = lambda img, dsize: P.resize_linear_u8(img, dsize[0], dsize[1])
+    dp.cv2 = sys.modules["cv2"]
+    rng = np.random.RandomState(7)
+    out = {}
+    cases = [(37, 53, 32, 0), (53, 37, 32, 1), (64, 64, 32, 0), (32, 32, 32, 1), (32, 20, 32, 0), (17, 100, 32, 1),
+             (90, 64, 48, 0), (48, 96, 48, 1), (5, 3, 48, 0)]
+    for i, (h, w, S, flip) in enumerate(cases):
+        proc = types.SimpleNamespace(opt=types.SimpleNamespace(inputSize=S))
+        img = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        joints = np.concatenate([rng.uniform(0, [w, h], size=(42, 2)), rng.randint(0, 2, size=(42, 1))], 1).astype(np.float32)
+        new_img, j = dp.DataProcessor.padding_and_resize(proc, img.copy(), joints.copy())
+        if flip:
+            dummy3 = np.zeros((42, 4), np.float32)
+            mano = (np.zeros(96, np.float32), np.zeros(20, np.float32), np.ones(2, np.float32))
+            gu = importlib.import_module("utils.geometry_utils")
+            res = dp.DataProcessor.random_flip(proc, new_img, np.array([0, 1], np.float32), j, dummy3, mano, do_flip=True)
+            new_img, j = res[0], res[2]
+        j = dp.DataProcessor.normalize_joints_2d(proc, j)
+        t = torch.from_numpy(np.ascontiguousarray(new_img.transpose(2, 0, 1))).float().div(255)
+        t = t.sub_(0.5).div_(0.5)
+        out[f"img{i}"] = img; out[f"joints{i}"] = joints; out[f"size{i}"] = np.array([S, flip], np.int32)
+        out[f"u8_{i}"] = np.ascontiguousarray(new_img); out[f"f32_{i}"] = t.numpy(); out[f"jout{i}"] = j.astype(np.float32)
+    out["n"] = np.array(len(cases))
+    np.savez_compressed(osp.join(HERE, "preprocess.npz"), **out)
+    print("preprocess.npz", len(cases), "cases")
+
 
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ns = import_reference()
-    which = sys.argv[1:] or ["losses", "select", "opt_traj", "encoder", "mlp_head", "metrics", "mlp_test"]
+    which = sys.argv[1:] or ["losses", "select", "opt_traj", "encoder", "mlp_head", "metrics", "mlp_test", "preprocess"]
     for w in which:
         globals()[f"gen_{w}"](ns)
