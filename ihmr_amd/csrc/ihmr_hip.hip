@@ -15,6 +15,7 @@
 #include "refine.h"
 #include "encoder.h"
 #include "evaluate.h"
+#include "train.h"
 
 static ihmr_kernel_timer* g_timer = nullptr;
 #define IHMR_TIMED_REPEAT 8
@@ -506,6 +507,53 @@ extern "C" int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_jo
     if (!pred_joints_3d || !gt_joints_3d || !coll_origin_scale || !out6 || B <= 0) return -1;
     hipLaunchKernelGGL(eval_metrics_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pred_joints_3d, gt_joints_3d, coll_origin_scale,
                        sample_scale, interacting, B, out6);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ IHMR-MLP training step
+extern "C" int ihmr_mlp_train_grad(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                                   const ihmr_opt_weights* w, const ihmr_train_weights* tw, const float* gt_pose,
+                                   const float* gt_shape, const float* params_weight, const float* init_shape,
+                                   const float* trans_weight_mean, float* grad122, float* terms5, void* stream) {
+    if (!m || !io || !w || !tw || !gt_pose || !gt_shape || !params_weight || !init_shape || !trans_weight_mean || !grad122 || !terms5 ||
+        B <= 0)
+        return -1;
+    hipStream_t st = (hipStream_t)stream;
+    OptWork wk = opt_carve(io->workspace, B);
+    int rc = opt_forward(m, m_left, io, wk, B, *w, AdamStep{-1, 0.f, 0.f, 1.f, -1, 0}, st);
+    if (rc) return rc;
+    lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, 15, wk.lbs, st);
+    hipLaunchKernelGGL(mlp_train_grad_kernel, dim3(B), dim3(128), 0, st, *io, wk, B, *tw, gt_pose, gt_shape, params_weight, init_shape,
+                       trans_weight_mean, grad122, terms5);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_transpose(const float* x, float* y, int rows, int cols, int ldx, int ldy, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || ldx < cols || ldy < rows) return -1;
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, y, rows, cols, ldx,
+                       ldy);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_relu_backward(float* dx, const float* y, int rows, int cols, int ld_dx, int ld_y, void* stream) {
+    if (!dx || !y || rows <= 0 || cols <= 0) return -1;
+    hipLaunchKernelGGL(relu_backward_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, y, rows, cols, ld_dx,
+                       ld_y);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_colsum(const float* x, float* out, int rows, int cols, int ldx, void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0) return -1;
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, rows, cols, ldx);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float grad_scale,
+                              float lr, float beta1, float beta2, float eps, int step, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n == 0 || step <= 0) return -1;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, n, grad_scale, beta1, beta2, eps, (float)((double)lr / bc1), (float)sqrt(bc2));
     return (int)hipGetLastError();
 }
 

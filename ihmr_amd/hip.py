@@ -30,7 +30,8 @@ EXPORTED_SYMBOLS = [
     "ihmr_sdf_workspace_bytes", "ihmr_sdf_collision", "ihmr_sdf_dense_grid", "ihmr_opt_workspace_bytes",
     "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_opt_sdf_stats", "ihmr_opt_stage_graph_create",
     "ihmr_opt_forward_graph_create", "ihmr_graph_launch", "ihmr_graph_destroy", "ihmr_opt_set_params", "ihmr_eval_metrics", "ihmr_conv_igemm", "ihmr_maxpool3x3s2",
-    "ihmr_avgpool_relu", "ihmr_preprocess_images", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
+    "ihmr_avgpool_relu", "ihmr_preprocess_images", "ihmr_mlp_train_grad", "ihmr_transpose", "ihmr_relu_backward", "ihmr_colsum",
+    "ihmr_adam_step", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
 ]
 
 
@@ -50,6 +51,10 @@ class OptIO(C.Structure):
 
 class OptWeights(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("joints_2d", "joints_3d", "trans", "shape_reg", "collision", "finger_reg")]
+
+
+class TrainWeights(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("joints_2d", "mano_pose", "mano_shape", "hand_trans", "shape_reg", "shape_residual")]
 
 
 class KernelTimer(C.Structure):
@@ -107,6 +112,11 @@ def lib():
         L.ihmr_conv_igemm.argtypes = [vp, vp, vp, vp, vp] + [i] * 16 + [vp, C.c_size_t, vp]
         L.ihmr_maxpool3x3s2.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.ihmr_avgpool_relu.argtypes = [vp, vp, i, i, i, i, vp]
+        L.ihmr_mlp_train_grad.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(TrainWeights)] + [vp] * 8
+        L.ihmr_transpose.argtypes = [vp, vp, i, i, i, i, vp]
+        L.ihmr_relu_backward.argtypes = [vp, vp, i, i, i, i, vp]
+        L.ihmr_colsum.argtypes = [vp, vp, i, i, i, vp]
+        L.ihmr_adam_step.argtypes = [vp, vp, vp, vp, C.c_size_t, f, f, f, f, f, i, vp]
         L.ihmr_preprocess_images.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp]
         L.ihmr_opt_sdf_stats.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), vp, vp]
         L.ihmr_set_kernel_timer.argtypes = [C.POINTER(KernelTimer)]

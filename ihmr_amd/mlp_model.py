@@ -7,7 +7,8 @@
 joint / collision terms (ONE captured launch of the fused kernels that also serve IHMR-OPT,
 ``ihmr_opt_forward_losses``), keep the update per sample only if every filter loss got strictly better-or-equal
 as ``select_better_params`` prescribes (``:592-637``), store to the per-dataset-index "prev" tables
-(``:337-356``).  No backward pass.  Training, ``sync`` (pickle gather) and visualisation are out of scope.
+(``:337-356``).  The training step (``forward / compute_loss / optimize_parameters``, ``src/train_mlp.py:93-99``) is in
+:mod:`ihmr_amd.mlp_train`; ``sync`` (pickle gather) and visualisation are out of scope.
 """
 from __future__ import annotations
 
@@ -22,6 +23,7 @@ import torch
 
 from . import hip, two_hand
 from .networks import InterHandSubNetwork
+from .mlp_train import MLPTrainMixin
 from .optimize_model import OptimizeModel
 
 PARAM_DIMS = OrderedDict(pred_hand_trans=3, pred_left_orient=3, pred_right_orient=3, pred_left_pose_params=45,
@@ -33,7 +35,7 @@ COLS = OrderedDict(pred_cam_params=slice(0, 3), pred_right_orient=slice(3, 6), p
 LOSS_SLOT = dict(joints_2d_loss_p=0, joints_3d_loss_p=1, collision_loss=2)      # rows of ihmr_opt_io.loss_batch
 
 
-class MLPModel:
+class MLPModel(MLPTrainMixin):
     name = "InterHandModel"  # sic, mlp_model.py:26-27
 
     def __init__(self, opt):
@@ -50,6 +52,7 @@ class MLPModel:
         self.default_loss_weights = dict(joints_2d_loss=10.0, joints_3d_loss=10.0, collision_loss=1.0)
         self._w = dict(joints_2d_loss=10.0, joints_3d_loss=10.0, trans_loss_weight=0.0, shape_reg_loss_weight=0.0,
                        collision_loss_weight=1.0, finger_reg_loss_weight=0.0)
+        self._init_train()
 
     # mlp_model.py:297-334
     def set_update_info(self, strategy, num_data):
@@ -69,6 +72,8 @@ class MLPModel:
     def add_new_network(self, stage_id):
         dim = sum(PARAM_DIMS[p] for p in self.strategy[stage_id]["update_params"])
         self.sub_network_list.append(InterHandSubNetwork(self.opt, self.opt.total_params_dim + 1024, dim).to(self.device))
+        if self.isTrain:                                   # mlp_model.py:402-405: a fresh Adam(lr) for the new sub-network
+            self._make_trainer(stage_id)
 
     def load(self, epoch, stage_id):
         path = osp.join(self.save_dir, f"{epoch}_net_mlp_stage_{stage_id:02d}.pth")
@@ -129,6 +134,8 @@ class MLPModel:
     def test(self):
         # mlp_model.py:204-216: [cam | pose 96 | shape 20 | trans] in the reference's order
         final = torch.cat([self.init_cam, self.init_pose_params, self.init_shape_params, self.init_hand_trans], dim=1).contiguous()
+        for tr in self.trainers.values():             # weights trained in this process: refresh the modules' copies
+            tr.sync_to_module()
         loss = self._forward_mano_and_losses(final)
         self._save_prev(final, loss)
         self.kept_history = []

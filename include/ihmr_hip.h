@@ -189,6 +189,40 @@ int ihmr_avgpool_relu(const float* x, float* y, int N, int HW, int C, int ldy, v
 int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_joints_3d, const float* coll_origin_scale,
                       const float* sample_scale, const unsigned char* interacting, int B, double* out6, void* stream);
 
+/* ------------------------------------------------------------------ IHMR-MLP training step */
+/* Gradient of the training objective `MLPModel.compute_loss(stage['loss_weights'])` (models/mlp_model.py:514-583)
+ * w.r.t. the packed prediction vector final_params (B,122) [cam 3 | R orient 3 | R pose 45 | L orient 3 | L pose 45 |
+ * R shape 10 | L shape 10 | trans 3]: what `self.loss.backward()` (:586-589) delivers to the sub-network's output.
+ * The state must have been set with ihmr_opt_set_params; `io->init_joints_2d / init_joints_3d` must point at the
+ * ANNOTATED joints (the training terms compare with the annotation, :518-531) and io->gt_hand_trans at hand_trans (B,4).
+ * One launch sequence: fused two-hand forward + 2-D / 3-D joint and collision terms, LBS backward for all parameter
+ * groups, then the direct terms (_mano_pose_loss with the reference's own batch_rodrigues, _mano_shape_loss,
+ * _hand_trans_loss, _shape_reg_loss, _shape_residual_loss; models/loss_utils.py:46-78,114-135) and the gather.
+ * `w`: joints_2d / joints_3d / collision weights of the stage (trans, shape_reg, finger_reg must be 0 here);
+ * gt_pose (B,96), gt_shape (B,20), params_weight (B,2) = mano_params_weight, init_shape (B,20),
+ * trans_weight_mean (1) = mean of hand_trans[:, 0, 3] over the batch (the reference multiplies a (B,3) difference by a
+ * (B,1,1) weight, which broadcasts to (B,B,3): the term is mean(w) * mean(d^2), mlp_model.py:557-558).
+ * Outputs: grad122 (B,122);  terms5 (B,5) per-sample shares of [mano_pose, mano_shape, hand_trans, shape_reg,
+ * shape_residual] (weighted; summed over the batch they are the reference's scalars); the joint / collision terms are
+ * in io->loss_batch rows 0, 1, 2 as in ihmr_opt_forward_losses. */
+typedef struct ihmr_train_weights { float joints_2d, mano_pose, mano_shape, hand_trans, shape_reg, shape_residual; } ihmr_train_weights;
+int ihmr_mlp_train_grad(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                        const ihmr_opt_weights* w, const ihmr_train_weights* tw, const float* gt_pose, const float* gt_shape,
+                        const float* params_weight, const float* init_shape, const float* trans_weight_mean,
+                        float* grad122, float* terms5, void* stream);
+/* Dense helpers for the backward pass of `InterHandSubNetwork` (models/networks.py:83-105; Linear-ReLU x3 + Linear):
+ * the GEMMs themselves (dX = dY . W, dW = X^T . dY) run through ihmr_conv_igemm.
+ *   ihmr_transpose:     y[c][r] = x[r][c]                       (rows x cols, row strides ldx / ldy)
+ *   ihmr_relu_backward: dx[r][c] = y[r][c] > 0 ? dx[r][c] : 0  (nn.ReLU backward from the layer OUTPUT y)
+ *   ihmr_colsum:        out[c] = sum_r x[r][c], rows in order   (bias gradient)
+ *   ihmr_adam_step:     torch.optim.Adam(lr, betas, eps) step number `step` (1-based) on a flat buffer, gradient
+ *                       multiplied by grad_scale first (1 / world size after a SUM all-reduce) */
+int ihmr_transpose(const float* x, float* y, int rows, int cols, int ldx, int ldy, void* stream);
+int ihmr_relu_backward(float* dx, const float* y, int rows, int cols, int ld_dx, int ld_y, void* stream);
+int ihmr_colsum(const float* x, float* out, int rows, int cols, int ldx, void* stream);
+int ihmr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float grad_scale,
+                   float lr, float beta1, float beta2, float eps, int step, void* stream);
+
 /* ------------------------------------------------------------------ image preprocessing */
 /* What the reference's DataLoader workers do per image on the CPU before the encoder sees it, for a whole batch:
  * `DataProcessor.padding_and_resize` (data/data_preprocess.py:45-60: longer side -> final_size with `cv2.resize`

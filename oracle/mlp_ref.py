@@ -83,6 +83,62 @@ class MLPRef:
         _, cb, self.collision_loss_origin_scale = L.collision_loss(self.sdf, self.pred_right_hand_verts, self.pred_left_hand_verts, self.hand_type_array)
         self.collision_loss_batch = cb * w["collision_loss"]
 
+    # mlp_model.py:514-583 with a stage's loss weights: the TRAINING objective (every term vs the annotation)
+    def compute_train_loss(self, w):
+        t = {}
+        l, _ = L.joints_2d_loss(self.joints_2d[:, :, :2], self.pred_joints_2d, self.joints_2d[:, :, 2:3])
+        t["joints_2d_loss"] = l * w["joints_2d_loss"]
+        l, _ = L.joints_3d_loss_(self.joints_3d[:, :, :3], self.pred_joints_3d, self.joints_3d[:, :, 3:4])
+        t["joints_3d_loss"] = l * w["joints_3d_loss"]
+        g, mw = self.gt_pose_params, self.mano_params_weight
+        t["mano_pose_loss"] = (L.mano_pose_loss(g[:, 3:48], self.pred_right_pose_params, mw[:, 0:1])
+                               + L.mano_pose_loss(g[:, 51:], self.pred_left_pose_params, mw[:, 1:2])) * w["mano_pose_loss"]
+        gs = self.gt_shape_params
+        t["mano_shape_loss"] = (L.mano_shape_loss(gs[:, :10], self.pred_right_shape_params, mw[:, 0:1])
+                                + L.mano_shape_loss(gs[:, 10:], self.pred_left_shape_params, mw[:, 1:2])) * w["mano_shape_loss"]
+        # (B,3) difference times a (B,1,1) weight: the reference broadcasts to (B,B,3) -- mean(w) * mean(d^2) (mlp_model.py:557-558)
+        t["hand_trans_loss"] = L.hand_trans_loss(self.hand_trans[:, 0, :3], self.pred_hand_trans, self.hand_trans[:, :, 3:4]) * w["hand_trans_loss"]
+        t["shape_reg_loss"] = L.shape_reg_loss(torch.cat([self.pred_right_shape_params, self.pred_left_shape_params], 1)) * w["shape_reg_loss"]
+        t["shape_residual_loss"] = (L.shape_residual_loss(self.pred_right_shape_params, self.init_shape_params[:, :10])
+                                    + L.shape_residual_loss(self.pred_left_shape_params, self.init_shape_params[:, 10:])) * w["shape_residual_loss"]
+        c, _, _ = L.collision_loss(self.sdf, self.pred_right_hand_verts, self.pred_left_hand_verts, self.hand_type_array)
+        t["collision_loss"] = c * w["collision_loss"]
+        t["loss"] = sum(t.values())
+        return t
+
+    # train_mlp.py:93-99 for one batch: retrive_prev_prediction -> forward -> compute_loss(stage weights) -> backward
+    def train_forward_backward(self, sid):
+        stage = self.strategy[sid]
+        for n in PARAM_DIMS:
+            setattr(self, n, self.prev_params[n][self.data_idxs].clone())
+        self._gather()
+        net = self.nets[sid]
+        for prm in net.parameters():
+            prm.grad = None
+        res = net(torch.cat([self.img_feat, self.final_params], dim=1))
+        o = 0
+        for n in stage["update_params"]:
+            setattr(self, n, getattr(self, n) + res[:, o:o + PARAM_DIMS[n]])
+            o += PARAM_DIMS[n]
+        self._gather()
+        self._forward_mano()
+        terms = self.compute_train_loss(stage["loss_weights"])
+        terms["loss"].backward()
+        return {k: float(v.detach()) for k, v in terms.items()}
+
+    def init_prev_from_backbone(self):
+        """train_mlp.py:60-66: the backbone prediction fills the "prev" tables."""
+        with torch.no_grad():
+            p, s = self.init_pose_params.clone(), self.init_shape_params.clone()
+            self.pred_cam_params, self.pred_hand_trans = self.init_cam.clone(), self.init_hand_trans.clone()
+            self.pred_right_orient, self.pred_left_orient = p[:, :3], p[:, 48:51]
+            self.pred_right_pose_params, self.pred_left_pose_params = p[:, 3:48], p[:, 51:]
+            self.pred_right_shape_params, self.pred_left_shape_params = s[:, :10], s[:, 10:]
+            self._gather()
+            self._forward_mano()
+            self._compute_loss()
+            self._save_prev()
+
     def _save_prev(self):
         for n in PARAM_DIMS:
             self.prev_params[n][self.data_idxs] = getattr(self, n).clone()

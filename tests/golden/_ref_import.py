@@ -15,6 +15,7 @@ import types
 import torch
 
 REF_SRC = "/root/reference/src"
+sys.dont_write_bytecode = True   # never write __pycache__ next to the (read-only) reference sources
 
 
 def reference_available() -> bool:

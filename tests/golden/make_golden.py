@@ -330,11 +330,66 @@ def gen_preprocess(ns):
     np.savez_compressed(osp.join(HERE, "preprocess.npz"), **out)
     print("preprocess.npz", len(cases), "cases")
 
+def gen_mlp_train(ns):
+    """One training step of the reference's MLPModel per stage of ``mlp_default`` (train_mlp.py:93-99:
+    ``set_input -> retrive_prev_prediction -> forward -> compute_loss(stage weights) -> optimize_parameters``) on a
+    synthetic batch, with a seeded sub-network: loss terms, the gradient of every sub-network parameter and the
+    weights after the Adam step."""
+    import importlib
+    import sys as _sys
+    from helpers import seeded_state_dict
+    _sys.modules["ry_utils"].load_pkl = lambda p: {"mean_pose": np.zeros(48), "mean_betas": np.zeros(10)}
+    mlp_model = importlib.import_module("models.mlp_model")
+    B = 4
+    opt = make_opt(B, strategy="mlp_default", is_train=True)
+    opt.total_epoch = 1
+    opt.pretrain_weights_dir = None
+    model = mlp_model.MLPModel(opt)
+    batch = make_mlp_batch(B, 778)
+    batch["joints_3d"][1, 0, 3] = 0.0                    # a sample whose GT lacks the right wrist (root = joint 21)
+    batch["mano_params_weight"][2, 1] = 0.0              # a sample without left-hand MANO annotation
+    batch["hand_trans"][3, 0, 3] = 0.0                   # a sample without translation annotation
+    batch["hand_type_array"][0] = torch.tensor([1.0, 0.0])   # a single-hand sample (collision masked)
+    import copy
+    strategy = copy.deepcopy(ns.strategies.strategies["mlp_default"])
+    strategy[4]["loss_weights"]["shape_residual_loss"] = 1.0     # zero everywhere in mlp_default: exercise the term once
+    model.set_update_info(strategy, 10)
+    with torch.no_grad():                                 # train_mlp.py:60-66: backbone prediction -> "prev" tables
+        model.set_input({k: v.clone() for k, v in batch.items()})
+        model.forward(forward_backbone=True)
+        model.compute_loss()
+        model.save_pred_to_prev()
+    out = {f"in_{k}": v for k, v in batch.items()}
+    names = ["joints_2d_loss", "joints_3d_loss", "mano_pose_loss", "mano_shape_loss", "hand_trans_loss", "shape_reg_loss",
+             "shape_residual_loss", "collision_loss", "loss"]
+    for sid in range(len(strategy)):
+        model.add_new_network(sid)
+        net = model.sub_network_list[sid]
+        net.load_state_dict(seeded_state_dict(net, 950 + sid, last_scale=0.05))
+        net.train()
+        model.set_input({k: v.clone() for k, v in batch.items()})
+        model.retrive_prev_prediction()
+        model.forward()
+        model.compute_loss(strategy[sid]["loss_weights"])
+        out[f"s{sid}_losses"] = np.array([float(getattr(model, n)) for n in names], np.float64)
+        model.optimize_parameters()
+        for k, prm in net.named_parameters():
+            g, w = prm.grad.detach().clone(), prm.detach().clone()
+            out[f"s{sid}_gradnorm_{k}"] = np.array(float(g.double().norm()))
+            if g.numel() > 20000:          # the three big matrices: a regular sample of rows / columns (fixture size)
+                g, w = g[::8, ::8], w[::8, ::8]
+            out[f"s{sid}_grad_{k}"] = g
+            out[f"s{sid}_new_{k}"] = w
+        out[f"s{sid}_residual_cols"] = np.array(sum(model._MLPModel__get_param_dim(n) for n in strategy[sid]["update_params"]))
+    out["loss_names"] = np.array(names)
+    np.savez_compressed(osp.join(HERE, "mlp_train.npz"), **t2n(out))
+    print("mlp_train.npz", {k: np.round(v, 6).tolist() for k, v in out.items() if k.endswith("_losses")})
+
 
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ns = import_reference()
-    which = sys.argv[1:] or ["losses", "select", "opt_traj", "encoder", "mlp_head", "metrics", "mlp_test", "preprocess"]
+    which = sys.argv[1:] or ["losses", "select", "opt_traj", "encoder", "mlp_head", "metrics", "mlp_test", "preprocess", "mlp_train"]
     for w in which:
         globals()[f"gen_{w}"](ns)

@@ -73,6 +73,28 @@ def test_two_rank_metric_reduction_matches_single_process(tmp_path):
     assert m["mpjpe_3d"] > 0 and m["collision_max"] >= m["collision_ave"]
 
 
+def _grad_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ihmr_amd import dist as D
+    D.init_dist("gloo")
+    g = torch.from_numpy(np.random.RandomState(100 + rank).normal(size=4099).astype(np.float32))   # this rank's flat gradient
+    scale = D.all_reduce_gradients(g)
+    if rank == 0:
+        np.save(out, (g * scale).numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce_is_the_mean(tmp_path):
+    """the training step's data-parallel exchange (ihmr_amd.dist.all_reduce_gradients): sum over ranks x 1/world = mean"""
+    out = str(tmp_path / "grad.npy")
+    mp.spawn(_grad_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ref = sum(np.random.RandomState(100 + r).normal(size=4099).astype(np.float32) for r in range(2)) * np.float32(0.5)
+    assert np.allclose(np.load(out), ref, rtol=0, atol=1e-7)
+    from ihmr_amd.dist import all_reduce_gradients
+    assert all_reduce_gradients(torch.ones(3)) == 1.0                     # single process: identity
+
+
 def test_shard_indices_cover_and_pad():
     sys.path.insert(0, ROOT)
     from ihmr_amd.dist import shard_indices

@@ -380,3 +380,38 @@ def test_mlp_test_path_matches_reference(mano_arrays):
     close(m.joints_3d_loss_p_batch, g["out_joints_3d_loss_p_batch"], 1e-6, what="j3d_p batch")
     close(m.joints_2d_loss_p_batch, g["out_joints_2d_loss_p_batch"], 1e-6, what="j2d_p batch")
     print("kept per stage:", [k.tolist() for k in m.kept_history])
+
+
+def test_mlp_train_step_matches_reference(mano_arrays):
+    """oracle MLPRef.train_forward_backward() == one training step of the reference's MLPModel per stage (mlp_train.npz):
+    every loss term, the gradient of every sub-network parameter, and the weights after torch.optim.Adam's step."""
+    from helpers import seeded_state_dict
+    from ihmr_amd.strategies import make_mlp_strategy
+    from oracle.mlp_ref import MLPRef
+    g = gold("mlp_train.npz")
+    batch = {k[3:]: T(v) for k, v in g.items() if k.startswith("in_")}
+    B = batch["init_cam"].shape[0]
+    right, left = mano_arrays
+    torch.set_num_threads(8)
+    strategy = make_mlp_strategy()
+    strategy[4]["loss_weights"]["shape_residual_loss"] = 1.0      # as the fixture was generated
+    m = MLPRef(right, left, B, strategy, num_data=10)
+    m.set_input(batch)
+    m.init_prev_from_backbone()
+    names = [str(n) for n in g["loss_names"]]
+    for sid, net in enumerate(m.nets):
+        net.load_state_dict(seeded_state_dict(net, 950 + sid, last_scale=0.05))
+        m.set_input(batch)
+        terms = m.train_forward_backward(sid)
+        close([terms[n] for n in names], g[f"s{sid}_losses"], 1e-6, 1e-5, what=f"stage {sid} losses")
+        opt = torch.optim.Adam(net.parameters(), lr=strategy[sid]["lr"])
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        opt.step()
+        for k, p in net.named_parameters():
+            gr, new = grads[k], p.detach()
+            scale = float(g[f"s{sid}_gradnorm_{k}"]) / np.sqrt(gr.numel())       # rms gradient entry
+            assert abs(float(gr.double().norm()) - float(g[f"s{sid}_gradnorm_{k}"])) <= 1e-4 * float(g[f"s{sid}_gradnorm_{k}"]) + 1e-12
+            if gr.numel() > 20000:
+                gr, new = gr[::8, ::8], new[::8, ::8]
+            close(gr, g[f"s{sid}_grad_{k}"], 2e-4 * scale + 1e-10, 1e-4, what=f"stage {sid} grad {k}")
+            close(new, g[f"s{sid}_new_{k}"], 2e-6, what=f"stage {sid} weights after the step {k}")
