@@ -514,9 +514,10 @@ extern "C" int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_jo
 extern "C" int ihmr_mlp_train_grad(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                                    const ihmr_opt_weights* w, const ihmr_train_weights* tw, const float* gt_pose,
                                    const float* gt_shape, const float* params_weight, const float* init_shape,
-                                   const float* trans_weight_mean, float* grad122, float* terms5, void* stream) {
-    if (!m || !io || !w || !tw || !gt_pose || !gt_shape || !params_weight || !init_shape || !trans_weight_mean || !grad122 || !terms5 ||
-        B <= 0)
+                                   const float* trans_weight_mean, float* grad122, float* terms5, const int32_t* out_cols,
+                                   int n_out, float* d_out, int ld_out, void* stream) {
+    if (!m || !io || !w || !tw || !gt_pose || !gt_shape || !params_weight || !init_shape || !grad122 || !terms5 || B <= 0 ||
+        (d_out && (!out_cols || n_out <= 0 || ld_out < n_out)))
         return -1;
     hipStream_t st = (hipStream_t)stream;
     OptWork wk = opt_carve(io->workspace, B);
@@ -524,7 +525,7 @@ extern "C" int ihmr_mlp_train_grad(const ihmr_mano* m, const ihmr_mano* m_left, 
     if (rc) return rc;
     lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, 15, wk.lbs, st);
     hipLaunchKernelGGL(mlp_train_grad_kernel, dim3(B), dim3(128), 0, st, *io, wk, B, *tw, gt_pose, gt_shape, params_weight, init_shape,
-                       trans_weight_mean, grad122, terms5);
+                       trans_weight_mean, grad122, terms5, out_cols, n_out, d_out, ld_out);
     return (int)hipGetLastError();
 }
 
@@ -544,7 +545,7 @@ extern "C" int ihmr_relu_backward(float* dx, const float* y, int rows, int cols,
 
 extern "C" int ihmr_colsum(const float* x, float* out, int rows, int cols, int ldx, void* stream) {
     if (!x || !out || rows <= 0 || cols <= 0) return -1;
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, rows, cols, ldx);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, out, rows, cols, ldx);
     return (int)hipGetLastError();
 }
 

@@ -49,8 +49,10 @@ __global__ __launch_bounds__(128) void mlp_train_grad_kernel(ihmr_opt_io io, Opt
                                                              const float* __restrict__ params_weight,
                                                              const float* __restrict__ init_shape,
                                                              const float* __restrict__ trans_weight_mean, float* __restrict__ grad,
-                                                             float* __restrict__ terms) {
+                                                             float* __restrict__ terms, const int32_t* __restrict__ out_cols, int n_out,
+                                                             float* __restrict__ d_out, int ld_out) {
     __shared__ float part[5][128];
+    __shared__ float gsh[128];
     const int b = blockIdx.x, e = threadIdx.x;
     const float Bn = (float)(io.norm_batch > 0 ? io.norm_batch : B);
     float g = 0.f, l_pose = 0.f, l_shape = 0.f, l_trans = 0.f, l_reg = 0.f, l_res = 0.f;
@@ -114,11 +116,21 @@ __global__ __launch_bounds__(128) void mlp_train_grad_kernel(ihmr_opt_io io, Opt
         // _hand_trans_loss with a (B,3) difference and a (B,1,1) weight: the reference's broadcast makes it
         // mean_i(w_i) * mean_{j,k}(d_jk^2) (mlp_model.py:557-558, loss_utils.py:114-118)
         const float df = io.gt_hand_trans[b * 4 + d] - io.trans[b * 3 + d];
-        const float st = tw.hand_trans * trans_weight_mean[0] / (Bn * 3.0f);
+        float wmean;
+        if (trans_weight_mean) {
+            wmean = trans_weight_mean[0];
+        } else {                                            // mean of the batch this sample belongs to, rows in order
+            const int nb = io.norm_batch > 0 ? io.norm_batch : B, b0 = (b / nb) * nb;
+            float sw = 0.f;
+            for (int q = 0; q < nb; ++q) sw += io.gt_hand_trans[(b0 + q) * 4 + 3];
+            wmean = sw / (float)nb;
+        }
+        const float st = tw.hand_trans * wmean / (Bn * 3.0f);
         g += -2.0f * st * df;
         l_trans = st * df * df;
     }
     if (e < 122) grad[(size_t)b * 122 + e] = g;
+    gsh[e] = g;
     part[0][e] = l_pose; part[1][e] = l_shape; part[2][e] = l_trans; part[3][e] = l_reg; part[4][e] = l_res;
     __syncthreads();
     if (e < 5) {
@@ -126,6 +138,9 @@ __global__ __launch_bounds__(128) void mlp_train_grad_kernel(ihmr_opt_io io, Opt
         for (int q = 0; q < 122; ++q) s += part[e][q];
         terms[(size_t)b * 5 + e] = s;
     }
+    // optional: the columns the current stage's sub-network produces, straight into the head's dY operand
+    if (d_out)
+        for (int c = e; c < n_out; c += 128) d_out[(size_t)b * ld_out + c] = gsh[out_cols[c]];
 }
 
 // ------------------------------------------------------------------------------------- dense helpers of the head
@@ -150,13 +165,17 @@ __global__ __launch_bounds__(256) void relu_backward_kernel(float* __restrict__ 
     if (!(y[(size_t)r * ld_y + c] > 0.f)) dx[(size_t)r * ld_dx + c] = 0.f;
 }
 
-// out[c] = sum_r x[r][c] in row order (bias gradient): one thread per column, coalesced over columns
+// out[c] = sum_r x[r][c] (bias gradient): a workgroup owns 64 columns, its 4 waves take rows w, w + 4, ... (coalesced over the
+// columns), the four partial sums are added in wave order
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int cols, int ldx) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x % 64, wave = threadIdx.x / 64, c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[(size_t)r * ldx + c];
-    out[c] = s;
+    if (c < cols)
+        for (int r = wave; r < rows; r += 4) s += x[(size_t)r * ldx + c];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < cols) out[c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 // torch.optim.Adam (no weight decay, no amsgrad) on a flat buffer; the same update expression as opt_adam_apply

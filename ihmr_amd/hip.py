@@ -112,7 +112,7 @@ def lib():
         L.ihmr_conv_igemm.argtypes = [vp, vp, vp, vp, vp] + [i] * 16 + [vp, C.c_size_t, vp]
         L.ihmr_maxpool3x3s2.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.ihmr_avgpool_relu.argtypes = [vp, vp, i, i, i, i, vp]
-        L.ihmr_mlp_train_grad.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(TrainWeights)] + [vp] * 8
+        L.ihmr_mlp_train_grad.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(TrainWeights)] + [vp] * 8 + [i, vp, i, vp]
         L.ihmr_transpose.argtypes = [vp, vp, i, i, i, i, vp]
         L.ihmr_relu_backward.argtypes = [vp, vp, i, i, i, i, vp]
         L.ihmr_colsum.argtypes = [vp, vp, i, i, i, vp]

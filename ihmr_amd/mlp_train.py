@@ -106,9 +106,14 @@ class HeadTrainer:
                                                hip.stream_ptr()), "ihmr_transpose")
 
     # ---- forward (keeps the activations), networks.py:103-105
-    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+    def forward(self, *inputs: torch.Tensor) -> torch.Tensor:
+        """``inputs``: the pieces of the input row (img_feat (B,1024), final_params (B,122)), written side by side."""
         B = self.B
-        self.x[0][:, :self.dims[0][0]].copy_(inputs)
+        o = 0
+        for t in inputs:
+            self.x[0][:, o:o + t.shape[1]].copy_(t)
+            o += t.shape[1]
+        assert o == self.dims[0][0]
         for l in range(4):
             i, o = self.dims[l]
             y = self.x[l + 1] if l < 3 else self.out
@@ -117,10 +122,12 @@ class HeadTrainer:
         return self.out
 
     # ---- backward from d loss / d output (B, k): fills self.grads
-    def backward(self, d_out: torch.Tensor):
+    def backward(self, d_out: torch.Tensor | None = None):
+        """d_out (B,k), or None when the caller has already written it into ``self.dy[3]`` (ihmr_mlp_train_grad does)."""
         B, L = self.B, hip.lib()
         st = hip.stream_ptr
-        self.dy[3][:B, :self.dims[3][1]].copy_(d_out)
+        if d_out is not None:
+            self.dy[3][:B, :self.dims[3][1]].copy_(d_out)
         for l in (3, 2, 1, 0):
             i, o = self.dims[l]
             kin = self.kpad[l] if l == 0 else i
@@ -174,7 +181,7 @@ class MLPTrainMixin:
         B, dev = self.batch_size, self.device
         self._grad122 = torch.zeros(B, 122, device=dev)
         self._terms5 = torch.zeros(B, 5, device=dev)
-        self._wmean = torch.zeros(1, device=dev)
+        self._out_cols = {}
 
     def _make_trainer(self, stage_id):
         tr = HeadTrainer(self.sub_network_list[stage_id], self.batch_size, self.strategy[stage_id]["lr"], self.device)
@@ -186,10 +193,9 @@ class MLPTrainMixin:
 
     # mlp_model.py:408-423
     def retrive_prev_prediction(self):
-        idx = self.data_idxs
-        assert bool(self.data_idxs_all[idx].all()), "retrive_prev_prediction: sample without a stored prediction"
-        self._prev_final = self.prev_final[idx].clone()
-        self.img_feat = self.img_feat_all[idx].clone()
+        idx = self.data_idxs          # (no check that the rows exist: it would stall the host on the device every step)
+        self._prev_final = self.prev_final[idx]
+        self.img_feat = self.img_feat_all[idx]
 
     # mlp_model.py:504-511 (+ 442-472)
     def forward(self, forward_backbone=False, stage_id=-1):
@@ -201,15 +207,14 @@ class MLPTrainMixin:
         if stage_id < 0:
             stage_id = len(self.sub_network_list) - 1
         prev = self._prev_final
-        inputs = torch.cat([self.img_feat, prev], dim=1)
         tr = self.trainers.get(stage_id) if torch.is_grad_enabled() else None
         if tr is not None:
-            res = tr.forward(inputs)
+            res = tr.forward(self.img_feat, prev)
         else:
             if stage_id in self.trainers:
                 self.trainers[stage_id].sync_to_module()
             with torch.no_grad():
-                res = self.sub_network_list[stage_id](inputs)
+                res = self.sub_network_list[stage_id](torch.cat([self.img_feat, prev], dim=1))
         new = prev.clone()
         o = 0
         for n in self.strategy[stage_id]["update_params"]:           # mlp_model.py:459-472
@@ -233,39 +238,50 @@ class MLPTrainMixin:
         io.init_joints_2d, io.init_joints_3d = io.gt_joints_2d, io.gt_joints_3d
         try:
             hip.check(hip.lib().ihmr_opt_set_params(C.byref(io), self.final_params.data_ptr(), B, hip.stream_ptr()), "ihmr_opt_set_params")
-            self._wmean.copy_(self.hand_trans[:, 0, 3].mean().reshape(1))
             ow = hip.OptWeights(w["joints_2d_loss"], w["joints_3d_loss"], 0.0, 0.0, w["collision_loss"], 0.0)
             tw = hip.TrainWeights(w["joints_2d_loss"], w["mano_pose_loss"], w["mano_shape_loss"], w["hand_trans_loss"], w["shape_reg_loss"],
                                   w["shape_residual_loss"])
             mr, ml = core._mano_handles()
+            sid = self._stage_id
+            if sid not in self._out_cols:               # columns of final_params the stage's sub-network produces, in its output order
+                from .mlp_model import COLS
+                cols = [c for n in self.strategy[sid]["update_params"] for c in range(COLS[n].start, COLS[n].stop)]
+                self._out_cols[sid] = torch.tensor(cols, dtype=torch.int32, device=self.device)
+            oc, tr = self._out_cols[sid], self.trainers[sid]
             hip.check(hip.lib().ihmr_mlp_train_grad(mr, ml, C.byref(io), B, C.byref(ow), C.byref(tw),
                                                     hip.ptr(self.gt_pose_params), hip.ptr(self.gt_shape_params), hip.ptr(self.mano_params_weight),
-                                                    hip.ptr(self.init_shape_params), hip.ptr(self._wmean), hip.ptr(self._grad122),
-                                                    hip.ptr(self._terms5), hip.stream_ptr()), "ihmr_mlp_train_grad")
+                                                    hip.ptr(self.init_shape_params), None, hip.ptr(self._grad122),
+                                                    hip.ptr(self._terms5), hip.ptr(oc), oc.numel(), hip.ptr(tr.dy[3]), tr.dy[3].shape[1],
+                                                    hip.stream_ptr()), "ihmr_mlp_train_grad")
         finally:
             io.init_joints_2d, io.init_joints_3d = keep
-        lb = core.buf["loss_batch"]
-        t5 = self._terms5.sum(dim=0)
-        self.joints_2d_loss, self.joints_3d_loss = lb[0].mean(), lb[1].mean()
-        self.collision_loss = lb[2].mean() * w["collision_loss"]
-        self.mano_pose_loss, self.mano_shape_loss, self.hand_trans_loss = t5[0], t5[1], t5[2]
-        self.shape_reg_loss, self.shape_residual_loss = t5[3], t5[4]
-        self.loss = (self.joints_2d_loss + self.joints_3d_loss + self.mano_pose_loss + self.mano_shape_loss + self.hand_trans_loss
-                     + self.shape_reg_loss + self.shape_residual_loss + self.collision_loss)
+        self._train_w = dict(w)
+
+    def _train_terms(self):
+        """The loss terms of the last training compute_loss as device scalars (evaluated on demand: a training step needs
+        only the gradient)."""
+        lb, t5, w = self._core.buf["loss_batch"], self._terms5.sum(dim=0), self._train_w
+        d = OrderedDict(joints_2d_loss=lb[0].mean(), joints_3d_loss=lb[1].mean(), mano_pose_loss=t5[0], mano_shape_loss=t5[1],
+                        hand_trans_loss=t5[2], shape_reg_loss=t5[3], shape_residual_loss=t5[4],
+                        collision_loss=lb[2].mean() * w["collision_loss"])
+        d["loss"] = sum(d.values())
+        return d
+
+    @property
+    def loss(self):
+        return self._train_terms()["loss"]
 
     # mlp_model.py:586-589
     def optimize_parameters(self):
-        from .mlp_model import COLS
-        sid = self._stage_id
-        tr = self.trainers[sid]
-        d_out = torch.cat([self._grad122[:, COLS[n]] for n in self.strategy[sid]["update_params"]], dim=1)
-        tr.backward(d_out)
+        tr = self.trainers[self._stage_id]
+        tr.backward()                              # dY was written by ihmr_mlp_train_grad
         tr.optimizer_step(self.world_size)
 
     # mlp_model.py:722-752
     def get_current_errors(self):
-        d = OrderedDict((n, float(getattr(self, n))) for n in TRAIN_LOSS_NAMES)
-        d["total_loss"] = float(self.loss)
+        t = self._train_terms()
+        d = OrderedDict((n, float(t[n])) for n in TRAIN_LOSS_NAMES)
+        d["total_loss"] = float(t["loss"])
         d["hand_type_loss"] = 0.0
         return d
 

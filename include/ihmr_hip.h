@@ -200,8 +200,12 @@ int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_joints_3d, co
  * _hand_trans_loss, _shape_reg_loss, _shape_residual_loss; models/loss_utils.py:46-78,114-135) and the gather.
  * `w`: joints_2d / joints_3d / collision weights of the stage (trans, shape_reg, finger_reg must be 0 here);
  * gt_pose (B,96), gt_shape (B,20), params_weight (B,2) = mano_params_weight, init_shape (B,20),
- * trans_weight_mean (1) = mean of hand_trans[:, 0, 3] over the batch (the reference multiplies a (B,3) difference by a
- * (B,1,1) weight, which broadcasts to (B,B,3): the term is mean(w) * mean(d^2), mlp_model.py:557-558).
+ * trans_weight_mean (1) = mean of hand_trans[:, 0, 3] over the batch, or NULL = computed from io->gt_hand_trans (the
+ * reference multiplies a (B,3) difference by a (B,1,1) weight, which broadcasts to (B,B,3): the term is
+ * mean(w) * mean(d^2), mlp_model.py:557-558).
+ * out_cols (n_out) int32 / d_out (B, ld_out), optional: the columns of final_params the stage's sub-network produces
+ * (`update_params` in order, mlp_model.py:459-472) are also written as d_out[b][c] = grad122[b][out_cols[c]] -- the
+ * dY operand of the head's backward pass.
  * Outputs: grad122 (B,122);  terms5 (B,5) per-sample shares of [mano_pose, mano_shape, hand_trans, shape_reg,
  * shape_residual] (weighted; summed over the batch they are the reference's scalars); the joint / collision terms are
  * in io->loss_batch rows 0, 1, 2 as in ihmr_opt_forward_losses. */
@@ -209,7 +213,7 @@ typedef struct ihmr_train_weights { float joints_2d, mano_pose, mano_shape, hand
 int ihmr_mlp_train_grad(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                         const ihmr_opt_weights* w, const ihmr_train_weights* tw, const float* gt_pose, const float* gt_shape,
                         const float* params_weight, const float* init_shape, const float* trans_weight_mean,
-                        float* grad122, float* terms5, void* stream);
+                        float* grad122, float* terms5, const int32_t* out_cols, int n_out, float* d_out, int ld_out, void* stream);
 /* Dense helpers for the backward pass of `InterHandSubNetwork` (models/networks.py:83-105; Linear-ReLU x3 + Linear):
  * the GEMMs themselves (dX = dY . W, dW = X^T . dY) run through ihmr_conv_igemm.
  *   ihmr_transpose:     y[c][r] = x[r][c]                       (rows x cols, row strides ldx / ldy)

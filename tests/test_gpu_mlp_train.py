@@ -136,6 +136,8 @@ def test_param_gradient_matches_oracle_autograd(mano_arrays):
     for n in ("joints_2d_loss", "joints_3d_loss", "mano_pose_loss", "mano_shape_loss", "hand_trans_loss", "shape_reg_loss",
               "shape_residual_loss", "collision_loss"):
         _close(f"term {n}", err[n], float(terms[n].detach()), 2e-6, 2e-5)
+    # the stage's columns, written straight into the head's dY operand
+    _close("dY of stage 0 = trans columns", model.trainers[0].dy[3][:B, :3].cpu(), ref[:, 119:122], 2e-4 * 40)
     for n, sl in COLS.items():
         scale = float(ref[:, sl].abs().max())
         _close(f"d loss / d {n}", got[:, sl], ref[:, sl], 2e-4 * scale + 1e-7)
@@ -161,7 +163,7 @@ def test_head_backward_matches_torch():
         y_ref = ref_net(x)
         y_ref.backward(dy)
         tr = HeadTrainer(net.cuda(), B, 1e-3, torch.device("cuda"))
-        y = tr.forward(x.cuda())
+        y = tr.forward(x.cuda()[:, :1024].contiguous(), x.cuda()[:, 1024:].contiguous())
         tr.backward(dy.cuda())
         torch.cuda.synchronize()
         _close(f"head forward B={B} k={k}", y.cpu(), y_ref.detach(), 1e-5, 1e-5)
