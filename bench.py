@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--epoch", type=int, default=49, help="opt_default epoch per stage (49 -> 200 iterations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-batch-roofline", action="store_true",
+                    help="skip the reference timing of the dominant kernel launched for one 64-sample batch (profiling runs: keeps "
+                         "the kernel summary to launches of one size)")
     ap.add_argument("--fuse", type=int, default=4,
                     help="batches of --batch samples carried by ONE launch sequence (opt.fuse_batches; per-sample arithmetic "
                          "identical to separate batches); batches in flight = streams x fuse")
@@ -210,16 +213,25 @@ def main():
     res = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    # dominant-kernel timing: HIP events on the launch stream, in a separate single-stream pass of the same
-    # workload (with several batches in flight the kernels share the GPU and a per-launch time is meaningless)
+    # dominant-kernel timing: HIP events on the launch stream, in a separate single-stream pass of the same workload (with
+    # several batches in flight the kernels share the GPU and a per-launch time is meaningless).  The launches of the timed
+    # region carry Gr = min(--fuse, --steps / --streams) batches each, so that is the launch this pass times; a second pass
+    # times the un-fused 64-sample launch for reference.
+    Gr = max(1, min(G, args.steps // S))
     timer = hip.KernelTimer(0.0, 0, 0.0, 0.0)
+    timer1 = hip.KernelTimer(0.0, 0, 0.0, 0.0)
+    rmodel = instance(0, Gr) if rank == 0 else model
     if rank == 0:
-        hip.lib().ihmr_set_kernel_timer(C.byref(timer))
-        model.use_graphs = False   # event records cannot sit inside a captured graph
-        model.set_input(batch); model.init_optimize(); model.optimize(0, 1)
-        torch.cuda.synchronize()
-        hip.lib().ihmr_flush_kernel_timer()
-        hip.lib().ihmr_set_kernel_timer(None)
+        for tm, mdl, inp in ((timer, rmodel, inputs[Gr]), (timer1, model, batch)):
+            hip.lib().ihmr_set_kernel_timer(C.byref(tm))
+            mdl.use_graphs = False   # event records cannot sit inside a captured graph
+            mdl.set_input(inp); mdl.init_optimize(); mdl.optimize(0, 1)
+            torch.cuda.synchronize()
+            hip.lib().ihmr_flush_kernel_timer()
+            hip.lib().ihmr_set_kernel_timer(None)
+            if Gr == 1 or args.no_single_batch_roofline:
+                timer1 = timer if Gr == 1 else timer1
+                break
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,11 +245,11 @@ def main():
     # gathered in an untimed replay of the same workload (see DESIGN.md "Measurement")
     roofline = None
     if rank == 0:
-        # counters at the end state and at the initial state of the refinement, averaged
-        st_end = model.collect_sdf_stats()
-        model.set_input(batch)
-        model.init_optimize()
-        st_ini = model.collect_sdf_stats()
+        # counters at the end state and at the initial state of the refinement, averaged (one launch = Gr batches)
+        st_end = rmodel.collect_sdf_stats()
+        rmodel.set_input(inputs[Gr])
+        rmodel.init_optimize()
+        st_ini = rmodel.collect_sdf_stats()
         stats = {k: 0.5 * (st_ini[k] + st_end[k]) for k in st_ini}
         # algorithmic flops of ONE sdf_dist_kernel launch (DESIGN.md "Measurement"): per inside voxel the
         # sphere pass over all 1538 triangles (8 flops: |p - centroid|^2) and the cull test (3 flops), plus
@@ -246,17 +258,24 @@ def main():
         # launch duration = event-bracketed time minus the cost of an (empty) event pair recorded right before it
         avg_raw_ms = timer.ms_sdf_eval / max(timer.n_sdf_eval, 1)
         avg_ms = (timer.ms_sdf_eval - timer.ms_event_pair) / max(timer.n_sdf_eval, 1)
-        traffic, traffic_src = pmc_traffic("sdf_dist_kernel") if (B == 64 and args.epoch == 49) else (None, None)
+        avg1_ms = (timer1.ms_sdf_eval - timer1.ms_event_pair) / max(timer1.n_sdf_eval, 1)
+        traffic, traffic_src = pmc_traffic("sdf_dist_kernel") if (B == 64 and args.epoch == 49 and Gr == 4) else (None, None)
         if avg_ms > 0:
             flops = stats["flops_per_launch"]
             ach = flops / (avg_ms * 1e-3) / 1e12
+            ach1 = (flops / Gr) / (avg1_ms * 1e-3) / 1e12 if avg1_ms > 0 else None
             roofline = dict(bound="mfma", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS,
                             traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
-                            kernel="sdf_dist_kernel", avg_launch_ms=avg_ms, avg_event_bracket_ms=avg_raw_ms, launches=int(timer.n_sdf_eval),
+                            kernel="sdf_dist_kernel", batches_per_launch=Gr, avg_launch_ms=avg_ms, avg_event_bracket_ms=avg_raw_ms,
+                            launches=int(timer.n_sdf_eval),
                             note="largest share of GPU time in the rocprofv3 kernel summary (profiles/). fp32 VALU kernel (no GEMM "
                                  "shape): priced against the fp32 peak, the same 157.3 TFLOP/s for vector and f32-input MFMA on "
-                                 "gfx950; timed with HIP events on the launch stream in a single-stream pass",
+                                 "gfx950; timed with HIP events on the launch stream in a single-stream pass, at the launch size of "
+                                 "the timed region (batches_per_launch batches of 64 per launch sequence)",
                             algorithmic_flops_per_launch=flops, work_per_launch=stats,
+                            # the same kernel launched for ONE 64-sample batch (launch ramp, table staging and the 3.4 work items
+                            # per CU weigh twice as much there)
+                            single_batch_launch=dict(avg_launch_ms=avg1_ms, achieved=ach1, frac=(ach1 / FP32_PEAK_TFLOPS) if ach1 else None),
                             # SURVEY.md 8(d) prices the SDF at ~100 flop per (voxel, triangle) pair of the brute-force
                             # search; for the voxels this launch evaluates that would be the figure below -- the kernel
                             # reaches the same bits with the culled search counted in `achieved`
