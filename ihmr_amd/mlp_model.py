@@ -124,7 +124,7 @@ class MLPModel(MLPTrainMixin):
 
     def _save_prev(self, final, loss):  # mlp_model.py:337-356
         idx = self.data_idxs
-        self.data_idxs_all[idx] = True
+        self.data_idxs_all.index_fill_(0, idx, True)      # (no host scalar: stays capturable in a graph)
         self.img_feat_all[idx] = self.img_feat
         self.prev_final[idx] = final
         self.prev_loss[idx] = loss
@@ -174,9 +174,7 @@ class MLPModel(MLPTrainMixin):
             self.mano_models["right"], g[:, :3], g[:, 48:51], g[:, 3:48], g[:, 51:], self.gt_shape_params[:, :10],
             self.gt_shape_params[:, 10:], self.hand_trans[:, :, :3])
 
-    # mlp_model.py:702-719
-    def get_pred_result(self):
-        n = lambda t: t.detach().cpu().numpy()
+    def _export_sources(self):
         # the reference root-aligns its GT joint buffer in place (no clone at mlp_model.py:530-531) and exports it
         gt = self.joints_3d.clone()
         w0 = gt[:, 0, 3]
@@ -185,9 +183,43 @@ class MLPModel(MLPTrainMixin):
         ref = gt[torch.arange(gt.shape[0], device=gt.device), root.clamp(min=0), :3]          # (B,3) root joint of every sample
         gt[:, :, :3] = gt[:, :, :3] - ref[:, None, :] * has[:, None, None].to(gt.dtype)         # rows without a root: minus an exact zero
         return OrderedDict(
-            pred_cam_params=n(self.pred_cam_params), pred_pose_params=n(self.pred_pose_params), pred_shape_params=n(self.pred_shape_params),
-            pred_hand_trans=n(self.pred_hand_trans), gt_right_hand_verts=n(self.gt_right_hand_verts), gt_left_hand_verts=n(self.gt_left_hand_verts),
-            pred_right_hand_verts=n(self.pred_right_hand_verts), pred_left_hand_verts=n(self.pred_left_hand_verts),
-            mano_params_weight=n(self.mano_params_weight), pred_joints_3d=n(self.pred_joints_3d), gt_joints_3d=n(gt),
-            do_flip=np.zeros(self.batch_size).astype(np.int32), collision_loss=n(self.collision_loss_batch),
-            collision_loss_origin_scale=n(self.collision_loss_origin_scale))
+            pred_cam_params=self.pred_cam_params, pred_pose_params=self.pred_pose_params, pred_shape_params=self.pred_shape_params,
+            pred_hand_trans=self.pred_hand_trans, gt_right_hand_verts=self.gt_right_hand_verts, gt_left_hand_verts=self.gt_left_hand_verts,
+            pred_right_hand_verts=self.pred_right_hand_verts, pred_left_hand_verts=self.pred_left_hand_verts,
+            mano_params_weight=self.mano_params_weight, pred_joints_3d=self.pred_joints_3d, gt_joints_3d=gt,
+            collision_loss=self.collision_loss_batch, collision_loss_origin_scale=self.collision_loss_origin_scale)
+
+    _KEY_ORDER = ("pred_cam_params", "pred_pose_params", "pred_shape_params", "pred_hand_trans", "gt_right_hand_verts", "gt_left_hand_verts",
+                  "pred_right_hand_verts", "pred_left_hand_verts", "mano_params_weight", "pred_joints_3d", "gt_joints_3d", "do_flip",
+                  "collision_loss", "collision_loss_origin_scale")
+
+    # mlp_model.py:702-719
+    def get_pred_result(self):
+        out = {k: v.detach().cpu().numpy() for k, v in self._export_sources().items()}
+        out["do_flip"] = np.zeros(self.batch_size).astype(np.int32)
+        return OrderedDict((k, out[k]) for k in self._KEY_ORDER)
+
+    def get_pred_result_async(self):
+        """``get_pred_result()`` without stalling the host (as :meth:`OptimizeModel.get_pred_result_async`): the copies are
+        queued behind ``test()`` on the current stream into pinned buffers (two alternating sets); ``wait()`` on the
+        returned handle blocks until they have landed.  The arrays are valid until the next-but-one export."""
+        if not hasattr(self, "_pinned"):
+            self._pinned, self._pin_slot = [None, None], 0
+        self._pin_slot ^= 1
+        src = OrderedDict((k, v.detach()) for k, v in self._export_sources().items())
+        if self._pinned[self._pin_slot] is None:
+            self._pinned[self._pin_slot] = OrderedDict((k, torch.empty(v.shape, dtype=v.dtype, pin_memory=True)) for k, v in src.items())
+        dst = self._pinned[self._pin_slot]
+        for k, v in src.items():
+            dst[k].copy_(v, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        model = self
+
+        class _Pending:
+            def wait(self_inner):
+                ev.synchronize()
+                out = {k: v.numpy() for k, v in dst.items()}
+                out["do_flip"] = np.zeros(model.batch_size).astype(np.int32)
+                return OrderedDict((k, out[k]) for k in model._KEY_ORDER)
+        return _Pending()

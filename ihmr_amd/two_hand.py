@@ -6,19 +6,27 @@ autograd semantics (drop-in tests, data synthesis).  The refinement loop itself 
 import torch
 
 TIP_IDS = (744, 320, 443, 554, 671)  # optimize_model.py:99
+_CONST = {}
+
+
+def _consts(device):
+    """Small device constants, built once per device (no host-to-device copy per call: the forward stays capturable)."""
+    if device not in _CONST:
+        _CONST[device] = (torch.tensor([1.0, -1.0, -1.0], device=device), torch.tensor([-1.0, 1.0, 1.0], device=device),
+                          torch.tensor(TIP_IDS, dtype=torch.long, device=device))
+    return _CONST[device]
 
 
 def two_hand_forward(mano_right, right_orient, left_orient, right_pose, left_pose, right_shape, left_shape, hand_trans):
     bs = right_orient.shape[0]
-    sgn = torch.tensor([1.0, -1.0, -1.0], device=right_orient.device)
+    sgn, flip, tips = _consts(right_orient.device)
     left_orient_f = left_orient * sgn
     left_pose_f = (left_pose.reshape(bs * 15, 3) * sgn).reshape(bs, 45)
     out = mano_right(global_orient=torch.cat([right_orient, left_orient_f], 0),
                      hand_pose=torch.cat([right_pose, left_pose_f], 0),
                      betas=torch.cat([right_shape, left_shape], 0))
     verts = out.vertices
-    joints = torch.cat([out.joints, verts[:, list(TIP_IDS), :]], dim=1)
-    flip = torch.tensor([-1.0, 1.0, 1.0], device=verts.device)
+    joints = torch.cat([out.joints, verts.index_select(1, tips)], dim=1)
     rv, rj = verts[:bs], joints[:bs]
     lv, lj = verts[bs:] * flip, joints[bs:] * flip
     shift = hand_trans.reshape(bs, 1, 3) + (rj[:, 0:1, :] - lj[:, 0:1, :])
