@@ -172,7 +172,7 @@ int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
  * ldw a multiple of 64 (128 to use the wide tile) and >= Cout;  bias [Cout];  residual optional [M][ldr];
  * y [M][ldy];  act: 0 none, 1 ReLU, 2 sigmoid.  A Linear layer is the case H = W = kh = kw = 1.
  * workspace (optional, device, workspace_bytes): scratch for split-K partial sums -- layers too small to fill the
- * GPU (7x7 maps, Linear layers) split their K loop over up to min(8, workspace_bytes / (M*Cout*4)) workgroups. */
+ * GPU (7x7 maps: 2; Linear layers: up to 32) split their K loop over up to min(32, workspace_bytes / (M*Cout*4)) workgroups. */
 int ihmr_conv_igemm(const float* x, const float* w, const float* bias, const float* residual, float* y, int N, int H, int W,
                     int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int ldx, int ldw, int ldy, int ldr,
                     int act, void* workspace, size_t workspace_bytes, void* stream);

@@ -28,6 +28,19 @@ def _close(name, got, ref, atol, rtol=0.0):
     assert np.all(err <= atol + rtol * np.abs(ref)), f"{name}: max err {err.max():.3e}"
 
 
+def _close_after_adam(name, got, ref, grad_ref, lr, atol):
+    """Weights after ONE Adam step: w - lr * g / (|g| + 1e-8).  Where the gradient entry is tiny the step is ill-conditioned
+    (the last bits of g, i.e. the summation order of the GEMM, decide between -lr and +lr): those entries may differ by up to
+    2 lr, everywhere else the tolerance is `atol` -- a wrong gradient sign or step size on a well-conditioned entry fails."""
+    got, ref, g = np.asarray(got, np.float64), np.asarray(ref, np.float64), np.abs(np.asarray(grad_ref, np.float64))
+    err = np.abs(got - ref)
+    well = g > 1e-5 * max(g.max(), 1e-30)
+    print(f"[parity] {name}: max|err|={err[well].max() if well.any() else 0.0:.3e} on {int(well.sum())} well-conditioned entries, "
+          f"{err[~well].max() if (~well).any() else 0.0:.3e} on the other {int((~well).sum())}")
+    assert np.all(err[well] <= atol), f"{name}: max err {err[well].max():.3e}"
+    assert np.all(err[~well] <= 2.1 * lr), f"{name}: max err {err[~well].max():.3e} on near-zero gradient entries"
+
+
 def _strategy():
     from ihmr_amd.strategies import make_mlp_strategy
     s = make_mlp_strategy()
@@ -85,7 +98,7 @@ def test_training_step_matches_reference_golden():
                 gr, w = gr[::8, ::8], w[::8, ::8]
             _close(f"stage {sid} grad {k}", gr, g[f"s{sid}_grad_{k}"], 1e-3 * scale + 1e-10, 1e-3)
             # one Adam step moves every weight by about lr: a wrong gradient SIGN shows as a 2 lr = 2e-4 error
-            _close(f"stage {sid} weights after the step {k}", w, g[f"s{sid}_new_{k}"], 2e-5)
+            _close_after_adam(f"stage {sid} weights after the step {k}", w, g[f"s{sid}_new_{k}"], g[f"s{sid}_grad_{k}"], strategy[sid]["lr"], 2e-5)
 
 
 def test_param_gradient_matches_oracle_autograd(mano_arrays):
@@ -169,14 +182,13 @@ def test_head_backward_matches_torch():
         _close(f"head forward B={B} k={k}", y.cpu(), y_ref.detach(), 1e-5, 1e-5)
         for (name, gr), p in zip(tr.named_gradients().items(), ref_net.parameters()):
             _close(f"head grad {name} B={B} k={k}", gr.cpu(), p.grad, 1e-5 * float(p.grad.abs().max()) + 1e-7, 1e-5)
-        # Adam's first step moves a weight by lr * g / (|g| + 1e-8): +-lr unless the gradient entry is ~1e-8, where the last
-        # bits of g matter (seen: 1e-5 on one entry of 131072) -- a wrong sign or a wrong step size shows as >= 1e-3
         opt = torch.optim.Adam(ref_net.parameters(), lr=1e-3)
+        ref_grads = [p.grad.clone() for p in ref_net.parameters()]
         opt.step()
         tr.optimizer_step()
         tr.sync_to_module()
-        for (n, p), q in zip(net.regressor.state_dict().items(), ref_net.state_dict().values()):
-            _close(f"head weights after Adam {n}", p.cpu(), q, 5e-5)
+        for (n, p), q, gr in zip(net.regressor.state_dict().items(), ref_net.state_dict().values(), ref_grads):
+            _close_after_adam(f"head weights after Adam {n}", p.cpu(), q, gr, 1e-3, 5e-5)
 
 
 def test_train_loop_runs_and_reduces_the_loss():
