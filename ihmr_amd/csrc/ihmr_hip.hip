@@ -16,6 +16,7 @@
 #include "encoder.h"
 #include "evaluate.h"
 #include "train.h"
+#include "train_conv.h"
 
 static ihmr_kernel_timer* g_timer = nullptr;
 #define IHMR_TIMED_REPEAT 8
@@ -558,6 +559,107 @@ extern "C" int ihmr_adam_step(float* params, const float* grads, float* exp_avg,
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, n, grad_scale, beta1, beta2, eps, (float)((double)lr / bc1), (float)sqrt(bc2));
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ encoder training kernels
+static int bn_chunks(long M, int* rows_per) {
+    long rp = std::max<long>(64, (M + 255) / 256);
+    *rows_per = (int)rp;
+    return (int)((M + rp - 1) / rp);
+}
+
+extern "C" size_t ihmr_bn_workspace_bytes(int C) { return (size_t)256 * 2 * C * sizeof(float) + (size_t)2 * C * sizeof(float); }
+
+extern "C" int ihmr_bn_train_forward(const float* z, long M, int C, const float* gamma, const float* beta, const float* residual,
+                                     int relu, float eps, float* y, float* mean, float* var, float* invstd, void* workspace,
+                                     void* stream) {
+    if (!z || !gamma || !beta || !y || !mean || !var || !invstd || !workspace || M <= 0 || C <= 0 || C % 4) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    int rows_per;
+    const int S = bn_chunks(M, &rows_per);
+    float* part = (float*)workspace;
+    const dim3 grid((C + 63) / 64, S);
+    hipLaunchKernelGGL(bn_partial_kernel<0>, grid, dim3(256), 0, st, z, (const float*)nullptr, (int)M, C, C, C, rows_per,
+                       (const float*)nullptr, (const float*)nullptr, part);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)part, S, 1, C, 1.0 / (double)M, mean,
+                       (float*)nullptr, 0.f);
+    hipLaunchKernelGGL(bn_partial_kernel<1>, grid, dim3(256), 0, st, z, (const float*)nullptr, (int)M, C, C, C, rows_per,
+                       (const float*)mean, (const float*)nullptr, part);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)part, S, 1, C, 1.0 / (double)M, var, invstd,
+                       eps);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, st, z, (const float*)mean,
+                       (const float*)invstd, gamma, beta, residual, y, M, C, relu);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_bn_train_backward(const float* z, const float* g, long M, int C, const float* mean, const float* invstd,
+                                      const float* gamma, float* dz, float* dgamma, float* dbeta, void* workspace, void* stream) {
+    if (!z || !g || !mean || !invstd || !gamma || !dz || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0 || C % 4) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    int rows_per;
+    const int S = bn_chunks(M, &rows_per);
+    float* part = (float*)workspace;
+    float* sums = part + (size_t)256 * 2 * C;            // [2][C]: sum g, sum g * xhat
+    hipLaunchKernelGGL(bn_partial_kernel<2>, dim3((C + 63) / 64, S), dim3(256), 0, st, z, g, (int)M, C, C, C, rows_per, mean, invstd, part);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, (const float*)part, S, 2, C, 1.0, sums,
+                       (float*)nullptr, 0.f);
+    hipLaunchKernelGGL(bn_backward_apply_kernel, dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, st, z, g, mean, invstd, gamma,
+                       (const float*)sums, dz, M, C);
+    HIP_TRY(hipMemcpyAsync(dbeta, sums, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dgamma, sums + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                               int kh, int kw, int stride, int pad, int ldx, int lddy, int ldw, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw || !workspace || N <= 0 || Cin % 4 || lddy % 4 || ldx % 4 || ldw < Cout) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const int M = N * Ho * Wo, K = kh * kw * Cin;
+    const bool wide_n = Cout > 64, wide_m = K > 64;
+    const int BMv = wide_m ? 128 : 64, BNv = wide_n ? 128 : 64;
+    const long tiles = (long)((K + BMv - 1) / BMv) * ((Cout + BNv - 1) / BNv);
+    const int nchunks = (M + CONV_BK - 1) / CONV_BK;
+    const long cap = (long)(workspace_bytes / ((size_t)K * Cout * sizeof(float)));
+    if (cap < 1) return -1;
+    long msplit = std::max<long>(1, std::min<long>(std::min<long>(cap, 256), std::min<long>((1024 + tiles - 1) / tiles, std::max(1, nchunks / 8))));
+    const int chunks_per = (int)((nchunks + msplit - 1) / msplit);
+    msplit = (nchunks + chunks_per - 1) / chunks_per;
+    WgradArgs a{x, dy, (float*)workspace, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, ldx, lddy, chunks_per};
+    const dim3 grid((K + BMv - 1) / BMv, (Cout + BNv - 1) / BNv, (unsigned)msplit);
+    if (wide_m && wide_n) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, dim3(512), 0, st, a);
+    else if (wide_m) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, dim3(256), 0, st, a);
+    else if (wide_n) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(128), 0, st, a);
+    // fixed-order sum of the pixel-range partials into dw [K][ldw]
+    ConvArgs r{nullptr, nullptr, nullptr, nullptr, dw, K, 1, 1, 0, 1, 1, Cout, 1, 1, 1, 0, 0, 0, ldw, 0, 0, (float*)workspace, (int)msplit, 0};
+    if (Cout % 4 == 0) hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)(((long)K * (Cout / 4) + 255) / 256)), dim3(256), 0, st, r);
+    else hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3((unsigned)(((long)K * Cout + 255) / 256)), dim3(256), 0, st, r);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_dilate2(const float* dy, float* out, int N, int Ho, int Wo, int C, void* stream) {
+    if (!dy || !out || C % 4) return -1;
+    const long total = (long)N * 2 * Ho * 2 * Wo * (C / 4);
+    hipLaunchKernelGGL(dilate2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, out, N, Ho, Wo, C);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo,
+                                          void* stream) {
+    if (!x || !dy || !dx || C % 4) return -1;
+    const long total = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H,
+                       W, C, Ho, Wo);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_avgpool_relu_backward(const float* y, const float* dy, float* dx, int N, int HW, int C, int ldy, void* stream) {
+    if (!y || !dy || !dx) return -1;
+    const long total = (long)N * HW * C;
+    hipLaunchKernelGGL(avgpool_relu_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, N, HW,
+                       C, ldy);
     return (int)hipGetLastError();
 }
 

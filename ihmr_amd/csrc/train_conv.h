@@ -1,0 +1,276 @@
+// Training-mode kernels of the image encoder (groundwork for `train_baseline.py`): what
+// `loss.backward()` runs through for `InterHandEncoder` (models/networks.py:30-80) / `ResNet` (models/resnet.py:97-156;
+// Bottleneck :58-94) in train mode -- BatchNorm2d with batch statistics (forward and backward), the weight gradient of a
+// convolution as an implicit GEMM on the fp32 matrix cores, zero insertion for the input gradient of the stride-2
+// convolutions (the input gradient itself is a stride-1 convolution with the flipped, transposed filter and runs through
+// conv_igemm_kernel), and the backward passes of MaxPool2d(3, 2, 1) and AvgPool2d(7) + ReLU.  NHWC activations as in
+// encoder.h; every reduction has a fixed order (deterministic results).
+#pragma once
+#include "encoder.h"
+
+// ------------------------------------------------------------------------------------- column reductions (BatchNorm)
+// z [M][C] (row stride ld).  grid = (ceil(C / 64), S), block = 256: workgroup (cb, s) owns columns [64 cb, 64 cb + 64) and
+// rows [s * rows_per, (s + 1) * rows_per); lane = column, the four waves take every fourth row; per-wave partial sums are
+// added in wave order.  part [S][nq][C].
+//   MODE 0: sum z                      (mean)
+//   MODE 1: sum (z - mean)^2           (biased variance, second pass as torch's batch_norm_cpu_update_stats does)
+//   MODE 2: sum g, sum g * xhat        (backward: g = gradient w.r.t. the BN output, xhat = (z - mean) * invstd)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ z, const float* __restrict__ g, int M, int C, int ld,
+                                                         int ldg, int rows_per, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, float* __restrict__ part) {
+    constexpr int NQ = MODE == 2 ? 2 : 1;
+    __shared__ float red[4][NQ][64];
+    const int lane = threadIdx.x % 64, wave = threadIdx.x / 64, c = blockIdx.x * 64 + lane, s = blockIdx.y;
+    const int r0 = s * rows_per, r1 = min(M, r0 + rows_per);
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        const float mu = MODE >= 1 ? mean[c] : 0.f, is = MODE == 2 ? invstd[c] : 0.f;
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const float v = z[(size_t)r * ld + c];
+            if (MODE == 0) a0 += v;
+            else if (MODE == 1) { const float d = v - mu; a0 += d * d; }
+            else { const float gv = g[(size_t)r * ldg + c]; a0 += gv; a1 += gv * ((v - mu) * is); }
+        }
+    }
+    red[wave][0][lane] = a0;
+    if (NQ == 2) red[wave][NQ - 1][lane] = a1;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            part[((size_t)s * NQ + q) * C + c] = (red[0][q][lane] + red[1][q][lane]) + (red[2][q][lane] + red[3][q][lane]);
+    }
+}
+
+// out[q][c] = sum_s part[s][q][c] (float64 accumulation in chunk order) * scale; MODE 1 of the caller turns the variance into
+// invstd = 1 / sqrt(var + eps) and keeps the variance too
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ part, int S, int NQ, int C, double scale,
+                                                        float* __restrict__ out, float* __restrict__ invstd_out, float eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NQ * C) return;
+    const int q = i / C, c = i % C;
+    double s = 0.0;
+    for (int k = 0; k < S; ++k) s += (double)part[((size_t)k * NQ + q) * C + c];
+    const float v = (float)(s * scale);
+    out[(size_t)q * C + c] = v;
+    if (invstd_out) invstd_out[c] = 1.0f / sqrtf(v + eps);
+}
+
+// y = [relu]( gamma * (z - mean) * invstd + beta [+ residual] ), 4 channels per thread (C % 4 == 0)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ residual,
+                                                       float* __restrict__ y, long M, int C, int relu) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = C / 4;
+    if (idx >= M * c4) return;
+    const int c = (int)(idx % c4) * 4;
+    const size_t off = (size_t)(idx / c4) * C + c;
+    const float4 v = *reinterpret_cast<const float4*>(z + off);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = (v.x - mu.x) * is.x * ga.x + be.x; o.y = (v.y - mu.y) * is.y * ga.y + be.y;
+    o.z = (v.z - mu.z) * is.z * ga.z + be.z; o.w = (v.w - mu.w) * is.w * ga.w + be.w;
+    if (residual) { const float4 r = *reinterpret_cast<const float4*>(residual + off); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *reinterpret_cast<float4*>(y + off) = o;
+}
+
+// dz = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M)   (torch's batch_norm_backward in training mode)
+__global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ z, const float* __restrict__ g,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                                float* __restrict__ dz, long M, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = C / 4;
+    if (idx >= M * c4) return;
+    const int c = (int)(idx % c4) * 4;
+    const size_t off = (size_t)(idx / c4) * C + c;
+    const float inv_m = 1.0f / (float)M;
+    const float4 v = *reinterpret_cast<const float4*>(z + off), gv = *reinterpret_cast<const float4*>(g + off);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 s1 = *reinterpret_cast<const float4*>(sums + c), s2 = *reinterpret_cast<const float4*>(sums + C + c);
+    float4 o;
+    o.x = ga.x * is.x * (gv.x - s1.x * inv_m - (v.x - mu.x) * is.x * (s2.x * inv_m));
+    o.y = ga.y * is.y * (gv.y - s1.y * inv_m - (v.y - mu.y) * is.y * (s2.y * inv_m));
+    o.z = ga.z * is.z * (gv.z - s1.z * inv_m - (v.z - mu.z) * is.z * (s2.z * inv_m));
+    o.w = ga.w * is.w * (gv.w - s1.w * inv_m - (v.w - mu.w) * is.w * (s2.w * inv_m));
+    *reinterpret_cast<float4*>(dz + off) = o;
+}
+
+// ------------------------------------------------------------------------------------- pooling backward
+// MaxPool2d(3, stride 2, padding 1) backward: the gradient of an output pixel goes to the FIRST maximum of its window in
+// (row, column) order, as torch records it.  One thread per (input pixel, 4 channels) gathers from the <= 2 x 2 windows
+// that contain it (no atomics: deterministic).
+__global__ __launch_bounds__(256) void maxpool3x3s2_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                    float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = C / 4;
+    if (idx >= (long)N * H * W * c4) return;
+    const int c = (int)(idx % c4) * 4;
+    long p = idx / c4;
+    const int wi = (int)(p % W); p /= W;
+    const int hi = (int)(p % H);
+    const int n = (int)(p / H);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ho = (hi + 1) / 2 - ((hi + 1) % 2 == 0 ? 1 : 0); ho <= (hi + 1) / 2; ++ho) {      // windows with 2 ho - 1 <= hi <= 2 ho + 1
+        if (ho < 0 || ho >= Ho) continue;
+        for (int wo = (wi + 1) / 2 - ((wi + 1) % 2 == 0 ? 1 : 0); wo <= (wi + 1) / 2; ++wo) {
+            if (wo < 0 || wo >= Wo) continue;
+            float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            int arg[4] = {-1, -1, -1, -1};
+            for (int dh = 0; dh < 3; ++dh) {
+                const int h2 = ho * 2 + dh - 1;
+                if (h2 < 0 || h2 >= H) continue;
+                for (int dw = 0; dw < 3; ++dw) {
+                    const int w2 = wo * 2 + dw - 1;
+                    if (w2 < 0 || w2 >= W) continue;
+                    const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)(n * H + h2) * W + w2) * C + c);
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (vv[e] > best[e] || vv[e] != vv[e]) { best[e] = vv[e]; arg[e] = h2 * W + w2; }
+                }
+            }
+            const float4 g = *reinterpret_cast<const float4*>(dy + ((size_t)(n * Ho + ho) * Wo + wo) * C + c);
+            const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (arg[e] == hi * W + wi) acc[e] += gg[e];
+        }
+    }
+    *reinterpret_cast<float4*>(dx + ((size_t)(n * H + hi) * W + wi) * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// AvgPool2d over the whole map followed by ReLU, backward: dx[n][p][c] = (y[n][c] > 0 ? dy[n][c] : 0) / HW
+__global__ __launch_bounds__(256) void avgpool_relu_backward_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                                    float* __restrict__ dx, int N, int HW, int C, int ldy) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * HW * C) return;
+    const int c = (int)(idx % C);
+    const int n = (int)(idx / ((long)HW * C));
+    dx[idx] = y[(size_t)n * ldy + c] > 0.f ? dy[(size_t)n * ldy + c] / (float)HW : 0.f;
+}
+
+// zero insertion for the input gradient of a stride-2 convolution: out [N][2 Ho][2 Wo][C], out[n][2 ho][2 wo] = dy[n][ho][wo]
+__global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ dy, float* __restrict__ out, int N, int Ho, int Wo, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = C / 4;
+    if (idx >= (long)N * 2 * Ho * 2 * Wo * c4) return;
+    const int c = (int)(idx % c4) * 4;
+    long p = idx / c4;
+    const int w = (int)(p % (2 * Wo)); p /= 2 * Wo;
+    const int h = (int)(p % (2 * Ho));
+    const int n = (int)(p / (2 * Ho));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(h & 1) && !(w & 1)) v = *reinterpret_cast<const float4*>(dy + ((size_t)(n * Ho + h / 2) * Wo + w / 2) * C + c);
+    *reinterpret_cast<float4*>(out + idx * 4) = v;
+}
+
+// ------------------------------------------------------------------------------------- weight gradient
+// dW[k][n] = sum_m A(x)[m][k] . dY[m][n]:  k = (filter tap, input channel) as in the forward's K index, m = output pixel.
+// The same tiling as conv_igemm_kernel with the roles turned: the REDUCTION runs over the pixels (16 per step), a workgroup
+// owns BM values of k x BN output channels; the x patch of 16 pixels x BM k-values is gathered as float4 along the channel
+// (Cin % 4 == 0: a float4 never straddles a filter tap; the tap of a loader is fixed for the whole kernel, only the pixel
+// moves) and stored pixel-major in LDS -- exactly what the MFMA's A operand wants, no transposition; dY rows are the B operand.
+// gridDim.z workgroups split the pixel range; partial sums go to `partial` [z][K][Cout] and conv_splitk_reduce_kernel adds
+// them in order.
+struct WgradArgs {
+    const float* x;      // NHWC input of the convolution, pixel stride ldx
+    const float* dy;     // [M][lddy] gradient w.r.t. the convolution output
+    float* partial;      // [msplit][K][Cout]
+    int N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, ldx, lddy, chunks_per;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int WN_WAVES = BN / 32;
+    constexpr int THREADS = (BM / 64) * WN_WAVES * 64;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int A_F4 = CONV_BK * BM / 4 / THREADS, B_F4 = CONV_BK * BN / 4 / THREADS;
+    constexpr int A_PER_ROW = BM / 4, B_PER_ROW = BN / 4;
+    __shared__ __attribute__((aligned(16))) float As[2][CONV_BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][CONV_BK][LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
+    const int M = a.N * a.Ho * a.Wo, K = a.kh * a.kw * a.Cin, HoWo = a.Ho * a.Wo;
+    const int k0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // A loaders: float4 f -> (pixel of the chunk f / A_PER_ROW, 4 consecutive k at k0 + (f % A_PER_ROW) * 4)
+    int arow[A_F4], acol[A_F4], afh[A_F4], afw[A_F4], ac[A_F4];
+    bool aok[A_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        const int f = tid + i * THREADS;
+        arow[i] = f / A_PER_ROW; acol[i] = (f % A_PER_ROW) * 4;
+        const int k = k0 + acol[i];
+        aok[i] = k < K;
+        const int tap = aok[i] ? k / a.Cin : 0;
+        ac[i] = aok[i] ? k % a.Cin : 0; afh[i] = tap / a.kw; afw[i] = tap % a.kw;
+    }
+    const int nchunks = (M + CONV_BK - 1) / CONV_BK;
+    const int mc0 = blockIdx.z * a.chunks_per, mc1 = min(nchunks, mc0 + a.chunks_per);
+    float4 areg[A_F4], breg[B_F4];
+    auto load_tile = [&](int mc) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int m = mc * CONV_BK + arow[i];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (aok[i] && m < M) {
+                const int n = m / HoWo, r = m % HoWo, ho = r / a.Wo, wo = r % a.Wo;
+                const int hi = ho * a.stride + afh[i] - a.pad, wi = wo * a.stride + afw[i] - a.pad;
+                if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
+                    v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + hi) * a.W + wi) * a.ldx + ac[i]);
+            }
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int g = tid + i * THREADS, m = mc * CONV_BK + g / B_PER_ROW, n4 = (g % B_PER_ROW) * 4;
+            breg[i] = (m < M && n0 + n4 < a.lddy) ? *reinterpret_cast<const float4*>(a.dy + (size_t)m * a.lddy + n0 + n4)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(&As[buf][arow[i]][acol[i]]) = areg[i];
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int g = tid + i * THREADS;
+            *reinterpret_cast<float4*>(&Bs[buf][g / B_PER_ROW][(g % B_PER_ROW) * 4]) = breg[i];
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    const int kl = lane >> 5, l31 = lane & 31;
+    if (mc0 < mc1) { load_tile(mc0); store_tile(0); }
+    __syncthreads();
+    for (int mc = mc0; mc < mc1; ++mc) {
+        const int cur = (mc - mc0) & 1;
+        if (mc + 1 < mc1) load_tile(mc + 1);
+#pragma unroll
+        for (int mm = 0; mm < CONV_BK; mm += 2) {
+            const float a0 = As[cur][mm + kl][wm * 64 + l31], a1 = As[cur][mm + kl][wm * 64 + 32 + l31];
+            const float bf = Bs[cur][mm + kl][wn * 32 + l31];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf, acc[1], 0, 0, 0);
+        }
+        if (mc + 1 < mc1) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + l31;
+    if (n >= a.Cout) return;
+    float* part = a.partial + (size_t)blockIdx.z * K * a.Cout;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = k0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            if (k < K) part[(size_t)k * a.Cout + n] = acc[mi][r];
+        }
+}

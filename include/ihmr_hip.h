@@ -227,6 +227,32 @@ int ihmr_colsum(const float* x, float* out, int rows, int cols, int ldx, void* s
 int ihmr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float grad_scale,
                    float lr, float beta1, float beta2, float eps, int step, void* stream);
 
+/* ------------------------------------------------------------------ encoder training kernels (groundwork) */
+/* The pieces `loss.backward()` needs for `InterHandEncoder` / `ResNet` in train mode (models/networks.py:30-80,
+ * models/resnet.py:58-156), NHWC activations as in ihmr_conv_igemm, every reduction in a fixed order.
+ *   ihmr_bn_train_forward:  nn.BatchNorm2d in training mode on z [M = N*H*W][C]: batch mean / biased variance per
+ *       channel (two passes), y = [relu](gamma * (z - mean) * invstd + beta [+ residual]); mean, var, invstd (C) are
+ *       outputs (the caller keeps them for the backward pass and updates the running statistics).
+ *   ihmr_bn_train_backward: g = gradient w.r.t. the BatchNorm output (after the ReLU mask) -> dz, dgamma, dbeta.
+ *   ihmr_conv_wgrad: dW [kh*kw*Cin][ldw] (the K-major layout ihmr_conv_igemm reads) = A(x)^T . dY as an implicit GEMM on
+ *       the fp32 matrix cores (Cin % 4 == 0; the 3-channel image is padded to 4); workspace holds the pixel-range partial
+ *       sums ([splits][K][Cout], at least K*Cout*4 bytes).
+ *   The input gradient of a convolution is ihmr_conv_igemm itself on dY with the flipped, transposed filter
+ *       w'[(kh-1-fh, kw-1-fw, cout)][cin], padding k-1-pad, stride 1; for the stride-2 convolutions dY is zero-inserted
+ *       first (ihmr_dilate2: [N][Ho][Wo][C] -> [N][2Ho][2Wo][C]).
+ *   ihmr_maxpool3x3s2_backward / ihmr_avgpool_relu_backward: nn.MaxPool2d(3, 2, 1) (gradient to the first maximum of a
+ *       window, as torch) and AvgPool2d(7) + ReLU (resnet.py:107,111,149-151). */
+size_t ihmr_bn_workspace_bytes(int C);
+int ihmr_bn_train_forward(const float* z, long M, int C, const float* gamma, const float* beta, const float* residual, int relu,
+                          float eps, float* y, float* mean, float* var, float* invstd, void* workspace, void* stream);
+int ihmr_bn_train_backward(const float* z, const float* g, long M, int C, const float* mean, const float* invstd,
+                           const float* gamma, float* dz, float* dgamma, float* dbeta, void* workspace, void* stream);
+int ihmr_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh,
+                    int kw, int stride, int pad, int ldx, int lddy, int ldw, void* workspace, size_t workspace_bytes, void* stream);
+int ihmr_dilate2(const float* dy, float* out, int N, int Ho, int Wo, int C, void* stream);
+int ihmr_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int ihmr_avgpool_relu_backward(const float* y, const float* dy, float* dx, int N, int HW, int C, int ldy, void* stream);
+
 /* ------------------------------------------------------------------ image preprocessing */
 /* What the reference's DataLoader workers do per image on the CPU before the encoder sees it, for a whole batch:
  * `DataProcessor.padding_and_resize` (data/data_preprocess.py:45-60: longer side -> final_size with `cv2.resize`
