@@ -136,3 +136,306 @@ def avgpool_relu_backward(y, dy, N, HW, C):
     hip.check(hip.lib().ihmr_avgpool_relu_backward(hip.ptr(y), hip.ptr(dy), hip.ptr(dx), N, HW, C, y.shape[1], hip.stream_ptr()),
               "ihmr_avgpool_relu_backward")
     return dx
+
+
+# ======================================================================================= the whole encoder in train mode
+class _Flat:
+    """Named views into ONE flat parameter buffer (+ gradient, + Adam moments of the same layout)."""
+
+    def __init__(self):
+        self.specs, self.n = [], 0
+
+    def add(self, name, shape):
+        size = int(torch.Size(shape).numel())
+        self.specs.append((name, tuple(shape), self.n, size))
+        self.n += (size + 3) // 4 * 4                       # keep every view 16-byte aligned
+        return name
+
+    def allocate(self, device):
+        self.params = torch.zeros(self.n, device=device)
+        self.grads = torch.zeros(self.n, device=device)
+        self.exp_avg = torch.zeros(self.n, device=device)
+        self.exp_avg_sq = torch.zeros(self.n, device=device)
+        self.p = {n: self.params[o:o + s].view(shape) for n, shape, o, s in self.specs}
+        self.g = {n: self.grads[o:o + s].view(shape) for n, shape, o, s in self.specs}
+
+
+class _Linear:
+    """y = act(x W^T + b) with W kept as the K-major packed matrix [kpad][ldw] inside the flat buffers."""
+
+    def __init__(self, flat, name, in_f, out_f):
+        self.name, self.in_f, self.out_f = name, in_f, out_f
+        self.kpad, self.ldw = _ceil(in_f, 16), _ldw(out_f)
+        flat.add(name + ".weight", (self.kpad, self.ldw))
+        flat.add(name + ".bias", (self.ldw,))
+
+    def bind(self, flat, B, device):
+        self.w, self.b = flat.p[self.name + ".weight"], flat.p[self.name + ".bias"]
+        self.gw, self.gb = flat.g[self.name + ".weight"], flat.g[self.name + ".bias"]
+        self.B, Bp = B, _ceil(B, 16)
+        self.xT = torch.zeros(self.kpad, Bp, device=device)
+        self.wT = torch.zeros(_ceil(self.out_f, 16), _ldw(self.in_f), device=device)
+        self.zero = torch.zeros(max(self.ldw, _ldw(self.in_f)), device=device)
+
+    def load(self, lin):
+        self.w.zero_(); self.b.zero_()
+        self.w[:self.in_f, :self.out_f].copy_(lin.weight.detach().t())
+        self.b[:self.out_f].copy_(lin.bias.detach())
+
+    def store(self, lin):
+        lin.weight.data.copy_(self.w[:self.in_f, :self.out_f].t())
+        lin.bias.data.copy_(self.b[:self.out_f])
+
+    def refresh(self):
+        hip.check(hip.lib().ihmr_transpose(hip.ptr(self.w), hip.ptr(self.wT), self.in_f, self.out_f, self.ldw, self.wT.shape[1], hip.stream_ptr()),
+                  "ihmr_transpose")
+
+    def _gemm(self, x, ldx, M, K, w, ldw, N, bias, y, ldy, act=0, residual=None, ldr=0):
+        ws = _splitk_workspace(x.device)
+        hip.check(hip.lib().ihmr_conv_igemm(hip.ptr(x), hip.ptr(w), hip.ptr(bias), None if residual is None else residual.data_ptr(), y.data_ptr(),
+                                            M, 1, 1, K, 1, 1, N, 1, 1, 1, 0, ldx, ldw, ldy, ldr, act, ws.data_ptr(), ws.numel() * 4, hip.stream_ptr()),
+                  "ihmr_conv_igemm")
+
+    def forward(self, x, out, act=0, residual=None):
+        """x [B][ldx >= kpad, zero padded]; out / residual: (tensor view, row stride)."""
+        y, ldy = out
+        r, ldr = residual if residual is not None else (None, 0)
+        self._gemm(x, x.stride(0), self.B, self.kpad, self.w, self.ldw, self.out_f, self.b, y, ldy, act, r, ldr)
+
+    def backward(self, x, dy, accumulate=False, need_dx=True):
+        """x [B][>= kpad] (the forward input), dy [ceil16(B)][ldw] zero padded -> gw / gb (added when `accumulate`), returns dx
+        [ceil16(B)][ldw(in_f)] or None."""
+        L, st, B = hip.lib(), hip.stream_ptr, self.B
+        hip.check(L.ihmr_transpose(hip.ptr(x), hip.ptr(self.xT), B, self.kpad, x.stride(0), self.xT.shape[1], st()), "ihmr_transpose")
+        gw = torch.empty_like(self.gw) if accumulate else self.gw
+        gb = torch.empty_like(self.gb) if accumulate else self.gb
+        if accumulate:
+            gw.zero_(); gb.zero_()
+        self._gemm(self.xT, self.xT.shape[1], self.kpad, B, dy, dy.shape[1], self.out_f, self.zero, gw, self.ldw)
+        hip.check(L.ihmr_colsum(hip.ptr(dy), hip.ptr(gb), B, self.out_f, dy.shape[1], st()), "ihmr_colsum")
+        if accumulate:
+            self.gw.add_(gw); self.gb.add_(gb)
+        if not need_dx:
+            return None
+        dx = torch.zeros(_ceil(B, 16), _ldw(self.in_f), device=x.device)
+        self._gemm(dy, dy.shape[1], B, self.out_f, self.wT, self.wT.shape[1], self.in_f, self.zero, dx, dx.shape[1])
+        return dx
+
+
+class EncoderTrainer:
+    """``InterHandEncoder`` (models/networks.py:30-80) in TRAIN mode on the HIP path: forward with batch-statistics
+    BatchNorm that keeps what the backward needs, backward from (d loss / d params (B,122), d loss / d hand_type (B,2)) to the
+    gradient of every parameter, ``torch.optim.Adam`` semantics on one flat buffer, data parallelism by one all-reduce."""
+
+    def __init__(self, encoder, batch_size, lr, device):
+        hip.require_gpu()
+        self.enc, self.B, self.lr, self.dev, self.step = encoder, batch_size, float(lr), device, 0
+        me = encoder.main_encoder
+        flat = self.flat = _Flat()
+        self.units = []                                   # conv + bn units in forward order
+        def unit(name, conv, bn, cin):
+            cout, _, k, _ = conv.weight.shape
+            u = dict(name=name, conv=conv, bn=bn, cin=cin, cout=cout, k=k, stride=conv.stride[0], pad=conv.padding[0])
+            flat.add(name + ".w", (_ceil(k * k * cin, 16), _ldw(cout)))
+            flat.add(name + ".gamma", (cout,)); flat.add(name + ".beta", (cout,))
+            self.units.append(u)
+            return u
+        self.stem = unit("stem", me.conv1, me.bn1, 4)     # the 3-channel image is padded to 4 channels
+        self.blocks = []
+        cin = 64
+        for li in range(1, 5):
+            for bi, blk in enumerate(getattr(me, f"layer{li}")):
+                k = f"l{li}.{bi}"
+                b = dict(c1=unit(k + ".c1", blk.conv1, blk.bn1, cin), c2=unit(k + ".c2", blk.conv2, blk.bn2, blk.conv1.weight.shape[0]),
+                         c3=unit(k + ".c3", blk.conv3, blk.bn3, blk.conv2.weight.shape[0]), ds=None)
+                if blk.downsample is not None:
+                    b["ds"] = unit(k + ".ds", blk.downsample[0], blk.downsample[1], cin)
+                self.blocks.append(b)
+                cin = blk.conv3.weight.shape[0]
+        self.nparam = encoder.total_params_dim
+        self.fc1 = _Linear(flat, "fc1", 2048, 1024)
+        self.feat = _Linear(flat, "feat", 1024, 1024)
+        self.reg = _Linear(flat, "reg", 1024 + self.nparam, self.nparam)
+        self.cls = _Linear(flat, "cls", 1024, 2)
+        flat.allocate(device)
+        for l in (self.fc1, self.feat, self.reg, self.cls):
+            l.bind(flat, batch_size, device)
+        self.load_from_module()
+
+    # ---- parameters <-> module
+    def _lin_modules(self):
+        return ((self.fc1, self.enc.main_encoder.fc1), (self.feat, self.enc.feat_encoder[1]), (self.reg, self.enc.regressor_ih[0]),
+                (self.cls, self.enc.hand_classifier[0]))
+
+    def load_from_module(self):
+        for u in self.units:
+            w = u["conv"].weight.detach().to(self.dev)
+            if u is self.stem:
+                w = torch.cat([w, w.new_zeros(w.shape[0], 1, w.shape[2], w.shape[3])], dim=1)
+            self.flat.p[u["name"] + ".w"].copy_(pack_forward_weight(w))
+            self.flat.p[u["name"] + ".gamma"].copy_(u["bn"].weight.detach())
+            self.flat.p[u["name"] + ".beta"].copy_(u["bn"].bias.detach())
+            u["run_mean"] = u["bn"].running_mean.detach().clone().to(self.dev)
+            u["run_var"] = u["bn"].running_var.detach().clone().to(self.dev)
+        for l, m in self._lin_modules():
+            l.load(m.to(self.dev))
+        self._refresh_derived()
+
+    @torch.no_grad()
+    def sync_to_module(self):
+        for u in self.units:
+            cout, cin, k = u["cout"], u["cin"], u["k"]
+            w = unpack_wgrad(self.flat.p[u["name"] + ".w"], (cout, cin, k, k))
+            u["conv"].weight.data.copy_(w[:, :3] if u is self.stem else w)
+            u["bn"].weight.data.copy_(self.flat.p[u["name"] + ".gamma"]); u["bn"].bias.data.copy_(self.flat.p[u["name"] + ".beta"])
+            u["bn"].running_mean.data.copy_(u["run_mean"]); u["bn"].running_var.data.copy_(u["run_var"])
+        for l, m in self._lin_modules():
+            l.store(m)
+        self.enc._packed = None
+
+    def _refresh_derived(self):
+        """Operands derived from the master weights: the flipped, transposed filters of the input gradients and the
+        transposed Linear weights (layout plumbing after every optimizer step)."""
+        for u in self.units:
+            if u is self.stem:
+                continue                                   # no gradient w.r.t. the image
+            cout, cin, k = u["cout"], u["cin"], u["k"]
+            w = self.flat.p[u["name"] + ".w"][:k * k * cin, :cout].reshape(k, k, cin, cout)
+            if "w_dgrad" not in u:
+                u["w_dgrad"] = torch.zeros(_ceil(k * k * cout, 16), _ldw(cin), device=self.dev)
+            u["w_dgrad"][:k * k * cout, :cin].copy_(w.flip(0, 1).permute(0, 1, 3, 2).reshape(k * k * cout, cin))
+        for l in (self.fc1, self.feat, self.reg, self.cls):
+            l.refresh()
+
+    # ---- forward
+    def _unit_forward(self, u, x, N, H, W, residual=None, relu=True):
+        w = self.flat.p[u["name"] + ".w"]
+        z, Ho, Wo = conv_forward(x, w, N, H, W, u["cin"], u["cout"], u["k"], u["stride"], u["pad"])
+        y, saved = bn_train_forward(z, self.flat.p[u["name"] + ".gamma"], self.flat.p[u["name"] + ".beta"], residual, relu)
+        M = z.shape[0]
+        with torch.no_grad():                              # nn.BatchNorm2d's running statistics (momentum 0.1, unbiased variance)
+            u["run_mean"].mul_(0.9).add_(saved[0], alpha=0.1)
+            u["run_var"].mul_(0.9).add_(saved[1], alpha=0.1 * M / max(M - 1, 1))
+        u["save"] = dict(x=x, z=z, y=y, saved=saved, N=N, H=H, W=W, relu=relu)
+        return y, Ho, Wo
+
+    def _block_forward(self, b, x, N, H, W):
+        """Bottleneck (resnet.py:76-94): conv-bn-relu, conv-bn-relu, conv-bn, + identity / downsample, relu."""
+        y1, H1, W1 = self._unit_forward(b["c1"], x, N, H, W)
+        y2, H2, W2 = self._unit_forward(b["c2"], y1, N, H1, W1)
+        res = x
+        if b["ds"] is not None:
+            res, _, _ = self._unit_forward(b["ds"], x, N, H, W, relu=False)
+        return self._unit_forward(b["c3"], y2, N, H2, W2, residual=res, relu=True)
+
+    def _block_backward(self, b, g):
+        """g = gradient w.r.t. the block output (modified in place) -> gradient w.r.t. the block input."""
+        relu_backward_(g, b["c3"]["save"]["y"])                                  # the ReLU after the residual add
+        g3 = self._unit_backward(b["c3"], g)
+        relu_backward_(g3, b["c2"]["save"]["y"])
+        g2 = self._unit_backward(b["c2"], g3)
+        relu_backward_(g2, b["c1"]["save"]["y"])
+        g1 = self._unit_backward(b["c1"], g2)
+        return g1 + (self._unit_backward(b["ds"], g) if b["ds"] is not None else g)
+
+    def forward(self, img):
+        B, dev = self.B, self.dev
+        assert img.shape[0] == B and img.shape[1] == 3
+        H = W = img.shape[2]
+        x = torch.zeros(B, H, W, 4, device=dev)
+        x[..., :3].copy_(img.permute(0, 2, 3, 1))
+        x = x.reshape(B * H * W, 4)
+        y, H, W = self._unit_forward(self.stem, x, B, H, W)
+        Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        xp = torch.empty(B * Hp * Wp, 64, device=dev)
+        hip.check(hip.lib().ihmr_maxpool3x3s2(hip.ptr(y), hip.ptr(xp), B, H, W, 64, Hp, Wp, hip.stream_ptr()), "ihmr_maxpool3x3s2")
+        self._pool = dict(x=y, H=H, W=W)
+        x, H, W = xp, Hp, Wp
+        for b in self.blocks:
+            x, H, W = self._block_forward(b, x, B, H, W)
+        self._last = dict(x=x, HW=H * W)
+        pooled = torch.empty(B, 2048, device=dev)
+        hip.check(hip.lib().ihmr_avgpool_relu(hip.ptr(x), hip.ptr(pooled), B, H * W, 2048, 2048, hip.stream_ptr()), "ihmr_avgpool_relu")
+        self.pooled = pooled
+        self.main_feat = torch.empty(B, 1024, device=dev)
+        self.fc1.forward(pooled, (self.main_feat, 1024), act=1)
+        Kp = self.reg.kpad
+        self.ief = [torch.zeros(B, Kp, device=dev) for _ in range(4)]           # [feat | params_i | 0] for i = 0..3
+        self.feat.forward(self.main_feat, (self.ief[0], Kp), act=1)
+        mp = self.enc.mean_params.to(dev)
+        self.ief[0][:, 1024:1024 + self.nparam].copy_(mp if mp.shape[0] == B else mp[:1].expand(B, -1))
+        for i in range(3):                                                       # networks.py:71-75
+            self.ief[i + 1][:, :1024].copy_(self.ief[0][:, :1024])
+            self.reg.forward(self.ief[i], (self.ief[i + 1][:, 1024:], Kp), act=0, residual=(self.ief[i][:, 1024:], Kp))
+        self.pred_params = self.ief[3][:, 1024:1024 + self.nparam].contiguous()
+        self.hand_type = torch.empty(B, 2, device=dev)
+        self.cls.forward(self.ief[0], (self.hand_type, 2), act=2)
+        return self.pred_params, self.hand_type
+
+    # ---- backward
+    def _unit_backward(self, u, g, need_dx=True):
+        """g = gradient w.r.t. the unit's output (already masked by its ReLU) -> gradient w.r.t. its input."""
+        s = u["save"]
+        dz, dgamma, dbeta = bn_train_backward(s["z"], g, s["saved"], self.flat.p[u["name"] + ".gamma"])
+        self.flat.g[u["name"] + ".gamma"].copy_(dgamma); self.flat.g[u["name"] + ".beta"].copy_(dbeta)
+        conv_wgrad(s["x"], dz, s["N"], s["H"], s["W"], u["cin"], u["cout"], u["k"], u["stride"], u["pad"], out=self.flat.g[u["name"] + ".w"])
+        if not need_dx:
+            return None
+        return conv_dgrad(dz, u["w_dgrad"], s["N"], s["H"], s["W"], u["cin"], u["cout"], u["k"], u["stride"], u["pad"])
+
+    def backward(self, d_params, d_hand):
+        B, dev, Kp, P = self.B, self.dev, self.reg.kpad, self.nparam
+        Bp = _ceil(B, 16)
+        pad = lambda t, ld: torch.cat([torch.cat([t, t.new_zeros(B, ld - t.shape[1])], 1), t.new_zeros(Bp - B, ld)], 0).contiguous()
+        # hand classifier: s = sigmoid(u)
+        du = d_hand * self.hand_type * (1.0 - self.hand_type)
+        dfeat = self.cls.backward(self.ief[0], pad(du, self.cls.ldw))[:B, :1024].clone()
+        # IEF iterations, last first; the regressor's weights are shared: gradients add up
+        g = d_params.clone()
+        for i in (2, 1, 0):
+            dx = self.reg.backward(self.ief[i], pad(g, self.reg.ldw), accumulate=(i != 2))
+            dfeat += dx[:B, :1024]
+            g = g + dx[:B, 1024:1024 + P]
+        # feat_encoder: ReLU, Linear, ReLU
+        gf = pad(dfeat, self.feat.ldw)
+        relu_backward_(gf[:B], self.ief[0])
+        dmain = self.feat.backward(self.main_feat, gf)
+        relu_backward_(dmain[:B], self.main_feat)
+        dpool = self.fc1.backward(self.pooled, dmain)
+        g = avgpool_relu_backward(self.pooled, dpool[:B, :2048].contiguous(), B, self._last["HW"], 2048)
+        for b in reversed(self.blocks):
+            g = self._block_backward(b, g)
+        gp = maxpool_backward(self._pool["x"], g, B, self._pool["H"], self._pool["W"], 64)
+        relu_backward_(gp, self.stem["save"]["y"])
+        self._unit_backward(self.stem, gp, need_dx=False)
+
+    # ---- optimizer (torch.optim.Adam semantics; DistributedDataParallel = one all-reduce of the flat gradient)
+    def optimizer_step(self, world_size: int = 1):
+        scale = 1.0
+        if world_size > 1:
+            from .dist import all_reduce_gradients
+            scale = all_reduce_gradients(self.flat.grads)
+        self.step += 1
+        f = self.flat
+        hip.check(hip.lib().ihmr_adam_step(hip.ptr(f.params), hip.ptr(f.grads), hip.ptr(f.exp_avg), hip.ptr(f.exp_avg_sq), f.n, scale, self.lr,
+                                           0.9, 0.999, 1e-8, self.step, hip.stream_ptr()), "ihmr_adam_step")
+        self._refresh_derived()
+
+    def named_gradients(self):
+        """Gradients under the reference's state_dict keys, torch layouts."""
+        out, me = {}, "main_encoder."
+        def conv_name(u):
+            n = u["name"]
+            if n == "stem":
+                return me + "conv1.weight", me + "bn1"
+            li, bi, c = n.split(".")
+            base = f"{me}layer{li[1:]}.{bi}."
+            return (base + "downsample.0.weight", base + "downsample.1") if c == "ds" else (base + f"conv{c[1]}.weight", base + f"bn{c[1]}")
+        for u in self.units:
+            wn, bn = conv_name(u)
+            w = unpack_wgrad(self.flat.g[u["name"] + ".w"], (u["cout"], u["cin"], u["k"], u["k"]))
+            out[wn] = w[:, :3].contiguous() if u is self.stem else w
+            out[bn + ".weight"] = self.flat.g[u["name"] + ".gamma"].clone(); out[bn + ".bias"] = self.flat.g[u["name"] + ".beta"].clone()
+        for l, key in ((self.fc1, me + "fc1"), (self.feat, "feat_encoder.1"), (self.reg, "regressor_ih.0"), (self.cls, "hand_classifier.0")):
+            out[key + ".weight"] = l.gw[:l.in_f, :l.out_f].t().contiguous(); out[key + ".bias"] = l.gb[:l.out_f].clone()
+        return out
