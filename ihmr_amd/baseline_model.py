@@ -5,8 +5,9 @@
 forward (``baseline_model.py:257-282``): encoder (ResNet-50 + IEF head on the matrix cores) -> slice the
 122-vector ``[cam 3 | pose 96 | shape 20 | trans 3]`` (``:262-270``) -> MANO for predicted AND ground-truth
 parameters with SEPARATE right / left models, no mirroring (``:208-254``) -> orthographic projection;
-``test()`` (``:350-355``) adds the collision term for the metric.  Training (``backward_E``), DDP and
-visualisation are out of scope.
+``test()`` (``:350-355``) adds the collision term for the metric.  The training step (``forward_train`` /
+``optimize_parameters``, ``src/train_baseline.py:75-80``) is in :mod:`ihmr_amd.baseline_train`; visualisation is out of
+scope.
 """
 from __future__ import annotations
 
@@ -19,6 +20,7 @@ import torch
 from . import hip
 from . import mano as mano_shim
 from . import ry_utils
+from .baseline_train import BaselineTrainMixin
 from .networks import InterHandEncoder
 from .sdf import SDFLoss
 
@@ -31,14 +33,13 @@ def batch_orthogonal_project(X, camera):
     return (X[:, :, :2] + camera[:, :, 1:]) * camera[:, :, 0:1]
 
 
-class InterHandModel:
+class InterHandModel(BaselineTrainMixin):
     name = "InterHandModel"
 
     def __init__(self, opt):
         hip.require_gpu()
         self.opt = opt
         self.isTrain = getattr(opt, "isTrain", False)
-        assert not self.isTrain, "training is outside the hot path of this build"
         self.inputSize = opt.inputSize
         self.batch_size = opt.batchSize
         self.cam_params_dim, self.pose_params_dim = opt.cam_params_dim, opt.pose_params_dim
@@ -51,6 +52,8 @@ class InterHandModel:
         self.load_mano_model()
         self.sdf_loss = SDFLoss(self.mano_models["right"].faces, self.mano_models["left"].faces, robustifier=None).to(self.device)
         self.encoder = InterHandEncoder(opt, self.mean_params).to(self.device)
+        if self.isTrain:                                 # baseline_model.py:69-71
+            self._init_train()
 
     # baseline_model.py:105-130
     def load_mean_params(self):
@@ -119,6 +122,8 @@ class InterHandModel:
     # baseline_model.py:257-282
     @torch.no_grad()
     def forward(self):
+        if self.isTrain:                                 # weights trained in this process: refresh the module's copies
+            self.trainer.sync_to_module()
         self.final_params, self.pred_hand_type = self.encoder(self.input_img)
         c, p, s = self.cam_params_dim, self.pose_params_dim, self.shape_params_dim
         self.pred_cam_params = self.final_params[:, :c]
