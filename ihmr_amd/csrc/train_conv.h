@@ -43,18 +43,24 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
-// out[q][c] = sum_s part[s][q][c] (float64 accumulation in chunk order) * scale; MODE 1 of the caller turns the variance into
-// invstd = 1 / sqrt(var + eps) and keeps the variance too
+// out[q][c] = sum_s part[s][q][c] * scale, accumulated in float64: a workgroup owns 64 (q, c) entries, its four waves take every
+// fourth chunk, the four sums are added in wave order.  With `invstd_out` the result is a variance: invstd = 1 / sqrt(var + eps).
 __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ part, int S, int NQ, int C, double scale,
                                                         float* __restrict__ out, float* __restrict__ invstd_out, float eps) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= NQ * C) return;
-    const int q = i / C, c = i % C;
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x % 64, wave = threadIdx.x / 64, i = blockIdx.x * 64 + lane;
+    const bool ok = i < NQ * C;
+    const int q = ok ? i / C : 0, c = ok ? i % C : 0;
     double s = 0.0;
-    for (int k = 0; k < S; ++k) s += (double)part[((size_t)k * NQ + q) * C + c];
-    const float v = (float)(s * scale);
-    out[(size_t)q * C + c] = v;
-    if (invstd_out) invstd_out[c] = 1.0f / sqrtf(v + eps);
+    if (ok)
+        for (int k = wave; k < S; k += 4) s += (double)part[((size_t)k * NQ + q) * C + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && ok) {
+        const float v = (float)(((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * scale);
+        out[(size_t)q * C + c] = v;
+        if (invstd_out) invstd_out[c] = 1.0f / sqrtf(v + eps);
+    }
 }
 
 // y = [relu]( gamma * (z - mean) * invstd + beta [+ residual] ), 4 channels per thread (C % 4 == 0)
