@@ -385,11 +385,43 @@ def gen_mlp_train(ns):
     np.savez_compressed(osp.join(HERE, "mlp_train.npz"), **t2n(out))
     print("mlp_train.npz", {k: np.round(v, 6).tolist() for k, v in out.items() if k.endswith("_losses")})
 
+def gen_encoder_train(ns):
+    """The reference's InterHandEncoder in TRAIN mode (BatchNorm on batch statistics) on seeded weights / images: outputs, the
+    gradient of every parameter for a seeded linear functional of the outputs (norms + samples), the running statistics of
+    the first and the last BatchNorm after the step."""
+    ns.networks.get_model = lambda arch: getattr(ns.resnet, arch)(pretrained=False, num_classes=512)
+    B = 4
+    opt = make_opt(B)
+    rng = np.random.RandomState(3)
+    mean_params = torch.tensor(rng.normal(0, 0.2, (1, 122)), dtype=torch.float32)
+    mean_params[0, 0] = 5.0
+    enc = ns.networks.InterHandEncoder(opt, mean_params.repeat(B, 1))
+    enc.load_state_dict(seeded_state_dict(enc, 100))
+    enc.train()
+    img = torch.tensor(rng.uniform(-1, 1, (B, 3, 224, 224)), dtype=torch.float32)
+    A = torch.tensor(rng.normal(0, 1, (B, 122)), dtype=torch.float32)
+    Bm = torch.tensor(rng.normal(0, 1, (B, 2)), dtype=torch.float32)
+    params, hand = enc(img)
+    ((params * A).sum() + (hand * Bm).sum()).backward()
+    out = dict(params=params.detach(), hand_class=hand.detach(),
+               bn1_running_mean=enc.main_encoder.bn1.running_mean, last_bn_running_var=enc.main_encoder.layer4[2].bn3.running_var)
+    names = []
+    for k, p in enc.named_parameters():
+        names.append(k)
+        out[f"gradnorm/{k}"] = np.array(float(p.grad.double().norm()))
+    for k in ("main_encoder.conv1.weight", "main_encoder.layer1.0.bn1.weight", "main_encoder.layer2.0.downsample.0.weight",
+              "main_encoder.layer4.2.conv3.weight", "main_encoder.fc1.bias", "regressor_ih.0.weight", "hand_classifier.0.weight"):
+        g = dict(enc.named_parameters())[k].grad
+        out[f"grad/{k}"] = g.reshape(g.shape[0], -1)[::4, ::16] if g.dim() > 1 else g
+    out["param_names"] = np.array(names)
+    np.savez_compressed(osp.join(HERE, "encoder_train.npz"), **t2n(out))
+    print("encoder_train.npz", len(names), "parameters")
+
 
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ns = import_reference()
-    which = sys.argv[1:] or ["losses", "select", "opt_traj", "encoder", "mlp_head", "metrics", "mlp_test", "preprocess", "mlp_train"]
+    which = sys.argv[1:] or ["losses", "select", "opt_traj", "encoder", "mlp_head", "metrics", "mlp_test", "preprocess", "mlp_train", "encoder_train"]
     for w in which:
         globals()[f"gen_{w}"](ns)

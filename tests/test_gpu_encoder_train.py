@@ -159,6 +159,13 @@ def test_whole_encoder_train_forward_backward_matches_oracle_autograd():
     for k, rel in rels.items():
         assert rel < (4e-2 if "main_encoder" in k and "fc1" not in k else 1e-4), f"{k}: relative gradient error {rel:.3e}"
     print(f"[parity] whole-encoder gradients: worst relative L2 error over {len(ref_grads)} parameters = {worst:.3e}")
+    # the same quantities as the REFERENCE's own encoder produced them (tests/golden/encoder_train.npz, same seeds)
+    import os
+    gold = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "encoder_train.npz")))
+    _close("train-mode params vs reference", p, torch.tensor(gold["params"]), 2e-4)
+    for k in ref_grads:
+        n_ref, n_got = float(gold[f"gradnorm/{k}"]), float(grads[k].double().norm())
+        assert abs(n_got - n_ref) <= (4e-2 if "main_encoder" in k and "fc1" not in k else 1e-4) * n_ref + 1e-12, (k, n_got, n_ref)
     # running statistics of the first and the last BatchNorm
     tr.sync_to_module()
     _close("stem running_mean", enc.main_encoder.bn1.running_mean, ref.main_encoder.bn1.running_mean, 1e-4)

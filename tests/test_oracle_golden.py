@@ -415,3 +415,38 @@ def test_mlp_train_step_matches_reference(mano_arrays):
                 gr, new = gr[::8, ::8], new[::8, ::8]
             close(gr, g[f"s{sid}_grad_{k}"], 2e-4 * scale + 1e-10, 1e-4, what=f"stage {sid} grad {k}")
             close(new, g[f"s{sid}_new_{k}"], 2e-6, what=f"stage {sid} weights after the step {k}")
+
+
+def test_encoder_train_mode_matches_reference():
+    """oracle InterHandEncoderRef in train() mode (BatchNorm on batch statistics) + autograd == the reference's own
+    InterHandEncoder (encoder_train.npz): outputs, the gradient norm of every parameter, gradient samples, running statistics.
+    This is the reference the GPU training path (tests/test_gpu_encoder_train.py) is compared with."""
+    from helpers import seeded_state_dict
+    from oracle.encoder_ref import InterHandEncoderRef
+    g = gold("encoder_train.npz")
+    B = 4
+    rng = np.random.RandomState(3)
+    mean_params = torch.tensor(rng.normal(0, 0.2, (1, 122)), dtype=torch.float32)
+    mean_params[0, 0] = 5.0
+    ref = InterHandEncoderRef(mean_params.repeat(B, 1))
+    ref.load_state_dict(seeded_state_dict(ref, 100))
+    ref.train()
+    torch.set_num_threads(8)
+    img = torch.tensor(rng.uniform(-1, 1, (B, 3, 224, 224)), dtype=torch.float32)
+    A = torch.tensor(rng.normal(0, 1, (B, 122)), dtype=torch.float32)
+    Bm = torch.tensor(rng.normal(0, 1, (B, 2)), dtype=torch.float32)
+    p, h = ref(img)
+    ((p * A).sum() + (h * Bm).sum()).backward()
+    close(p.detach(), g["params"], 1e-5, what="train-mode params")
+    close(h.detach(), g["hand_class"], 1e-6, what="train-mode hand type")
+    params = dict(ref.named_parameters())
+    assert [str(n) for n in g["param_names"]] == list(params)
+    for k, prm in params.items():
+        n_ref = float(g[f"gradnorm/{k}"])
+        assert abs(float(prm.grad.double().norm()) - n_ref) <= 1e-3 * n_ref + 1e-12, k
+    for key in [k for k in g if k.startswith("grad/")]:
+        gr = params[key[5:]].grad
+        gr = gr.reshape(gr.shape[0], -1)[::4, ::16] if gr.dim() > 1 else gr
+        close(gr, g[key], 1e-3 * float(np.abs(g[key]).max()) + 1e-9, what=key)
+    close(ref.main_encoder.bn1.running_mean, g["bn1_running_mean"], 1e-6, what="bn1 running mean")
+    close(ref.main_encoder.layer4[2].bn3.running_var, g["last_bn_running_var"], 1e-5, what="last bn running var")
