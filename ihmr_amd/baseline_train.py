@@ -4,7 +4,7 @@
 
 for ``InterHandModel`` (``models/baseline_model.py:257-347``): the encoder in train mode
 (:class:`ihmr_amd.encoder_train.EncoderTrainer`: batch-statistics BatchNorm, backward to every parameter, Adam on one flat
-buffer, one all-reduce of the flat gradient for data parallelism), the loss of ``backward_E`` (``:285-341``), and
+buffer, bucketed all-reduces of the flat gradient overlapped with the backward pass for data parallelism), the loss of ``backward_E`` (``:285-341``), and
 ``torch.optim.Adam(encoder.parameters(), lr=opt.lr)`` (``:69-71``).
 
 The loss gradient ``d loss / d final_params`` comes from ``ihmr_mlp_train_grad`` -- the fused two-hand forward, the joint /

@@ -65,3 +65,43 @@ def all_reduce_gradients(flat_grads: torch.Tensor) -> float:
         return 1.0
     dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
     return 1.0 / dist.get_world_size()
+
+
+def plan_gradient_buckets(spans, bucket_floats):
+    """Bucketing of a flat gradient buffer whose parts become final from the END towards the start during the backward pass
+    (the heads first, the stem last).  ``spans`` = the (lo, hi) ranges in the order they complete, each ending where the
+    previous one starts (hi_k == lo_{k-1}); returns ``{index of the span after which to fire: (lo, hi)}``: contiguous slices of
+    at least ``bucket_floats`` floats (the last one takes the remainder) that together cover the buffer exactly once."""
+    fire, hi = {}, None
+    for k, (lo, h) in enumerate(spans):
+        if hi is None:
+            hi = h
+        assert h == (spans[k - 1][0] if k else h), "spans must be contiguous, descending"
+        if hi - lo >= bucket_floats or k == len(spans) - 1:
+            fire[k] = (lo, hi)
+            hi = lo
+    return fire
+
+
+class OverlappedGradientReducer:
+    """DistributedDataParallel's bucketed gradient all-reduce for a flat gradient buffer: ``ready(k)`` is called by the backward
+    pass when span k is final and starts an asynchronous all-reduce (RCCL: on its own stream, behind the kernels already queued)
+    of every bucket that has become complete, so the exchange of the deep layers' gradients runs under the backward pass of the
+    shallow ones; ``finish()`` waits and returns the factor for the optimizer (1 / world size).  25 MB buckets by default: four
+    for the 102 MB of ResNet-50 -- on a ring over xGMI a bucket of that size is bandwidth-bound, smaller ones pay the ring
+    latency of 2 (N - 1) steps per bucket."""
+
+    def __init__(self, flat_grads: torch.Tensor, spans, bucket_bytes: int = 25 << 20):
+        self.grads, self.plan, self.handles = flat_grads, plan_gradient_buckets(spans, bucket_bytes // 4), []
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def ready(self, k: int):
+        if self.active and k in self.plan:
+            lo, hi = self.plan[k]
+            self.handles.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> float:
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        return 1.0 / dist.get_world_size() if self.active else 1.0

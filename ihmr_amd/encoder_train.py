@@ -261,6 +261,13 @@ class EncoderTrainer:
         for l in (self.fc1, self.feat, self.reg, self.cls):
             l.bind(flat, batch_size, device)
         self.load_from_module()
+        # gradient spans in the order the backward pass completes them: the four heads together, the 16 bottlenecks last to
+        # first, the stem (flat layout = forward order, so each span ends where the previous one starts)
+        off = {n: o for n, _, o, _ in flat.specs}
+        starts = [off["fc1.weight"]] + [off[b["c1"]["name"] + ".w"] for b in reversed(self.blocks)] + [0]
+        ends = [flat.n] + starts[:-1]
+        from .dist import OverlappedGradientReducer
+        self.reducer = OverlappedGradientReducer(flat.grads, list(zip(starts, ends)))
 
     # ---- parameters <-> module
     def _lin_modules(self):
@@ -402,19 +409,19 @@ class EncoderTrainer:
         dmain = self.feat.backward(self.main_feat, gf)
         relu_backward_(dmain[:B], self.main_feat)
         dpool = self.fc1.backward(self.pooled, dmain)
+        self.reducer.ready(0)                                                     # the heads' gradients are final
         g = avgpool_relu_backward(self.pooled, dpool[:B, :2048].contiguous(), B, self._last["HW"], 2048)
-        for b in reversed(self.blocks):
+        for k, b in enumerate(reversed(self.blocks)):
             g = self._block_backward(b, g)
+            self.reducer.ready(1 + k)
         gp = maxpool_backward(self._pool["x"], g, B, self._pool["H"], self._pool["W"], 64)
         relu_backward_(gp, self.stem["save"]["y"])
         self._unit_backward(self.stem, gp, need_dx=False)
+        self.reducer.ready(1 + len(self.blocks))
 
     # ---- optimizer (torch.optim.Adam semantics; DistributedDataParallel = one all-reduce of the flat gradient)
     def optimizer_step(self, world_size: int = 1):
-        scale = 1.0
-        if world_size > 1:
-            from .dist import all_reduce_gradients
-            scale = all_reduce_gradients(self.flat.grads)
+        scale = self.reducer.finish()                   # the bucketed all-reduces were started during backward()
         self.step += 1
         f = self.flat
         hip.check(hip.lib().ihmr_adam_step(hip.ptr(f.params), hip.ptr(f.grads), hip.ptr(f.exp_avg), hip.ptr(f.exp_avg_sq), f.n, scale, self.lr,

@@ -2,7 +2,7 @@
 """Counterpart of the reference's ``src/train_baseline.py`` (main loop :60-108) on synthetic data:
 ``set_input -> forward -> optimize_parameters`` per batch, learning-rate update and checkpoint per epoch.  One process per GPU
 (``python -m torch.distributed.run --nproc-per-node N -m ihmr_amd.run_train_baseline``); the encoder's flat gradient
-(26 M floats) is averaged over the ranks with one all-reduce per step.
+(26 M floats) is averaged over the ranks in 25 MB buckets that are all-reduced while the backward pass is still running.
 
     python -m ihmr_amd.run_train_baseline --num_samples 256 --batchSize 64 --total_epoch 2
 """

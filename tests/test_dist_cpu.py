@@ -95,6 +95,38 @@ def test_two_rank_gradient_all_reduce_is_the_mean(tmp_path):
     assert all_reduce_gradients(torch.ones(3)) == 1.0                     # single process: identity
 
 
+def _bucket_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ihmr_amd import dist as D
+    D.init_dist("gloo")
+    n = 1000
+    spans = [(900, 1000), (700, 900), (650, 700), (300, 650), (0, 300)]          # completion order: end of the buffer first
+    g = torch.zeros(n)
+    red = D.OverlappedGradientReducer(g, spans, bucket_bytes=4 * 250)
+    src = torch.from_numpy(np.random.RandomState(200 + rank).normal(size=n).astype(np.float32))
+    for k, (lo, hi) in enumerate(spans):                                          # the "backward pass": fill a span, report it
+        g[lo:hi] = src[lo:hi]
+        red.ready(k)
+    scale = red.finish()
+    if rank == 0:
+        np.save(out, (g * scale).numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_overlapped_bucketed_gradient_reduction(tmp_path):
+    """the encoder trainer's data-parallel exchange: buckets fired while the "backward pass" is still filling the buffer"""
+    from ihmr_amd.dist import plan_gradient_buckets
+    spans = [(900, 1000), (700, 900), (650, 700), (300, 650), (0, 300)]
+    plan = plan_gradient_buckets(spans, 250)
+    assert plan == {1: (700, 1000), 3: (300, 700), 4: (0, 300)}                  # >= 250 floats each, the remainder last
+    assert plan_gradient_buckets(spans, 10 ** 9) == {4: (0, 1000)}               # one bucket when the buffer is small
+    out = str(tmp_path / "bucket.npy")
+    mp.spawn(_bucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ref = sum(np.random.RandomState(200 + r).normal(size=1000).astype(np.float32) for r in range(2)) * np.float32(0.5)
+    assert np.allclose(np.load(out), ref, rtol=0, atol=1e-7)
+
+
 def test_shard_indices_cover_and_pad():
     sys.path.insert(0, ROOT)
     from ihmr_amd.dist import shard_indices
