@@ -111,7 +111,18 @@ class BaselineTrainMixin:
         self.trainer.lr = float(lr)
         return lr
 
+    # baseline_model.py:491-495 / base_model.py:23-43: weights + {'epoch', 'optimizer'} of torch.optim.Adam, torch formats
     def save(self, label, epoch=None):
         self.trainer.sync_to_module()
         os.makedirs(self.save_dir, exist_ok=True)
-        torch.save(self.encoder.state_dict(), osp.join(self.save_dir, f"{label}_net_baseline.pth"))
+        torch.save({k: v.cpu() for k, v in self.encoder.state_dict().items()}, osp.join(self.save_dir, f"{label}_net_baseline.pth"))
+        torch.save(dict(epoch=epoch, optimizer=self.trainer.optimizer_state_dict()), osp.join(self.save_dir, f"{label}_info.pth"))
+
+    # opt.continue_train (baseline_model.py:75-85): resume from <which_epoch>_net_baseline.pth + <which_epoch>_info.pth
+    def load_checkpoint(self, label):
+        if not self.load_network(self.encoder, "baseline", label):
+            return None
+        self.trainer.load_from_module()
+        info = torch.load(osp.join(self.save_dir, f"{label}_info.pth"), map_location="cpu", weights_only=False)
+        self.trainer.load_optimizer_state_dict(info["optimizer"])
+        return info["epoch"]

@@ -428,21 +428,69 @@ class EncoderTrainer:
                                            0.9, 0.999, 1e-8, self.step, hip.stream_ptr()), "ihmr_adam_step")
         self._refresh_derived()
 
+    # ---- flat buffers <-> tensors under the reference's parameter names, torch layouts
+    def _module_names(self, u):
+        me, n = "main_encoder.", u["name"]
+        if n == "stem":
+            return me + "conv1.weight", me + "bn1"
+        li, bi, c = n.split(".")
+        base = f"{me}layer{li[1:]}.{bi}."
+        return (base + "downsample.0.weight", base + "downsample.1") if c == "ds" else (base + f"conv{c[1]}.weight", base + f"bn{c[1]}")
+
+    _HEADS = (("fc1", "main_encoder.fc1"), ("feat", "feat_encoder.1"), ("reg", "regressor_ih.0"), ("cls", "hand_classifier.0"))
+
+    def _views(self, buf):
+        return {n: buf[o:o + sz].view(shape) for n, shape, o, sz in self.flat.specs}
+
+    def _to_named(self, buf):
+        v, out = self._views(buf), {}
+        for u in self.units:
+            wn, bn = self._module_names(u)
+            w = unpack_wgrad(v[u["name"] + ".w"], (u["cout"], u["cin"], u["k"], u["k"]))
+            out[wn] = w[:, :3].contiguous() if u is self.stem else w
+            out[bn + ".weight"], out[bn + ".bias"] = v[u["name"] + ".gamma"].clone(), v[u["name"] + ".beta"].clone()
+        for attr, key in self._HEADS:
+            l = getattr(self, attr)
+            out[key + ".weight"] = v[attr + ".weight"][:l.in_f, :l.out_f].t().contiguous()
+            out[key + ".bias"] = v[attr + ".bias"][:l.out_f].clone()
+        return out
+
+    def _from_named(self, buf, named):
+        v = self._views(buf)
+        buf.zero_()
+        for u in self.units:
+            wn, bn = self._module_names(u)
+            w = named[wn].to(self.dev)
+            if u is self.stem:
+                w = torch.cat([w, w.new_zeros(w.shape[0], 1, w.shape[2], w.shape[3])], dim=1)
+            v[u["name"] + ".w"].copy_(pack_forward_weight(w))
+            v[u["name"] + ".gamma"].copy_(named[bn + ".weight"]); v[u["name"] + ".beta"].copy_(named[bn + ".bias"])
+        for attr, key in self._HEADS:
+            l = getattr(self, attr)
+            v[attr + ".weight"][:l.in_f, :l.out_f].copy_(named[key + ".weight"].to(self.dev).t())
+            v[attr + ".bias"][:l.out_f].copy_(named[key + ".bias"])
+
     def named_gradients(self):
         """Gradients under the reference's state_dict keys, torch layouts."""
-        out, me = {}, "main_encoder."
-        def conv_name(u):
-            n = u["name"]
-            if n == "stem":
-                return me + "conv1.weight", me + "bn1"
-            li, bi, c = n.split(".")
-            base = f"{me}layer{li[1:]}.{bi}."
-            return (base + "downsample.0.weight", base + "downsample.1") if c == "ds" else (base + f"conv{c[1]}.weight", base + f"bn{c[1]}")
-        for u in self.units:
-            wn, bn = conv_name(u)
-            w = unpack_wgrad(self.flat.g[u["name"] + ".w"], (u["cout"], u["cin"], u["k"], u["k"]))
-            out[wn] = w[:, :3].contiguous() if u is self.stem else w
-            out[bn + ".weight"] = self.flat.g[u["name"] + ".gamma"].clone(); out[bn + ".bias"] = self.flat.g[u["name"] + ".beta"].clone()
-        for l, key in ((self.fc1, me + "fc1"), (self.feat, "feat_encoder.1"), (self.reg, "regressor_ih.0"), (self.cls, "hand_classifier.0")):
-            out[key + ".weight"] = l.gw[:l.in_f, :l.out_f].t().contiguous(); out[key + ".bias"] = l.gb[:l.out_f].clone()
-        return out
+        return self._to_named(self.flat.grads)
+
+    # ---- checkpoint / resume: the state of ``torch.optim.Adam(encoder.parameters())`` in torch's own format
+    # (what the reference stores under 'optimizer' in ``<label>_info.pth``, base_model.py:36-43, baseline_model.py:491-495)
+    def optimizer_state_dict(self):
+        names = [k for k, _ in self.enc.named_parameters()]
+        m, v = self._to_named(self.flat.exp_avg), self._to_named(self.flat.exp_avg_sq)
+        state = {i: dict(step=torch.tensor(float(self.step)), exp_avg=m[k].cpu(), exp_avg_sq=v[k].cpu()) for i, k in enumerate(names)} if self.step else {}
+        group = dict(lr=self.lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                     differentiable=False, fused=None, params=list(range(len(names))))
+        return dict(state=state, param_groups=[group])
+
+    def load_optimizer_state_dict(self, sd):
+        names = [k for k, _ in self.enc.named_parameters()]
+        self.lr = float(sd["param_groups"][0]["lr"])
+        if not sd["state"]:
+            self.step = 0
+            self.flat.exp_avg.zero_(); self.flat.exp_avg_sq.zero_()
+            return
+        self.step = int(float(sd["state"][0]["step"]))
+        self._from_named(self.flat.exp_avg, {k: sd["state"][i]["exp_avg"] for i, k in enumerate(names)})
+        self._from_named(self.flat.exp_avg_sq, {k: sd["state"][i]["exp_avg_sq"] for i, k in enumerate(names)})

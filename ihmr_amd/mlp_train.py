@@ -154,14 +154,44 @@ class HeadTrainer:
                   "ihmr_adam_step")
         self._refresh_transposed_weights()
 
-    def named_gradients(self):
-        """Gradients under the reference's parameter names (``regressor.{0,2,4,6}.{weight,bias}``), torch layout."""
+    def _to_named(self, buf):
+        """A flat buffer as tensors under the reference's parameter names (``regressor.{0,2,4,6}.{weight,bias}``), torch layout."""
         out = OrderedDict()
         for l, idx in enumerate((0, 2, 4, 6)):
             i, o = self.dims[l]
-            out[f"regressor.{idx}.weight"] = self.gw[l][:i, :o].t().contiguous()
-            out[f"regressor.{idx}.bias"] = self.gb[l][:o].clone()
+            w = buf[self.offsets[2 * l]:self.offsets[2 * l + 1]].view(self.kpad[l], self.ldw[l])
+            out[f"regressor.{idx}.weight"] = w[:i, :o].t().contiguous()
+            out[f"regressor.{idx}.bias"] = buf[self.offsets[2 * l + 1]:self.offsets[2 * l + 2]][:o].clone()
         return out
+
+    def _from_named(self, buf, named):
+        buf.zero_()
+        for l, idx in enumerate((0, 2, 4, 6)):
+            i, o = self.dims[l]
+            buf[self.offsets[2 * l]:self.offsets[2 * l + 1]].view(self.kpad[l], self.ldw[l])[:i, :o].copy_(named[f"regressor.{idx}.weight"].to(self.dev).t())
+            buf[self.offsets[2 * l + 1]:self.offsets[2 * l + 2]][:o].copy_(named[f"regressor.{idx}.bias"])
+
+    def named_gradients(self):
+        return self._to_named(self.grads)
+
+    # torch.optim.Adam's own state format: what the reference stores under 'optimizer' (mlp_model.py:834-839)
+    def optimizer_state_dict(self):
+        m, v = self._to_named(self.exp_avg), self._to_named(self.exp_avg_sq)
+        names = list(m)
+        state = {i: dict(step=torch.tensor(float(self.step)), exp_avg=m[k].cpu(), exp_avg_sq=v[k].cpu()) for i, k in enumerate(names)} if self.step else {}
+        group = dict(lr=self.lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                     differentiable=False, fused=None, params=list(range(len(names))))
+        return dict(state=state, param_groups=[group])
+
+    def load_optimizer_state_dict(self, sd):
+        names = list(self._to_named(self.grads))
+        self.lr = float(sd["param_groups"][0]["lr"])
+        self.step = int(float(sd["state"][0]["step"])) if sd["state"] else 0
+        if sd["state"]:
+            self._from_named(self.exp_avg, {k: sd["state"][i]["exp_avg"] for i, k in enumerate(names)})
+            self._from_named(self.exp_avg_sq, {k: sd["state"][i]["exp_avg_sq"] for i, k in enumerate(names)})
+        else:
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_()
 
 
 TRAIN_LOSS_NAMES = ("joints_2d_loss", "joints_3d_loss", "mano_pose_loss", "mano_shape_loss", "hand_trans_loss", "shape_reg_loss",
@@ -315,11 +345,26 @@ class MLPTrainMixin:
         self._loss3 = torch.where(ok[:, None], new_loss, prev_loss)
         return ok
 
-    # mlp_model.py:834-839
+    # mlp_model.py:834-839 / base_model.py:23-43: weights + {'epoch', 'optimizer'} in torch's formats
     def save(self, epoch, stage_id):
         import os
         import os.path as osp
+        os.makedirs(self.save_dir, exist_ok=True)
         if stage_id in self.trainers:
             self.trainers[stage_id].sync_to_module()
-        os.makedirs(self.save_dir, exist_ok=True)
-        torch.save(self.sub_network_list[stage_id].state_dict(), osp.join(self.save_dir, f"{epoch}_net_mlp_stage_{stage_id:02d}.pth"))
+            torch.save(dict(epoch=epoch, optimizer=self.trainers[stage_id].optimizer_state_dict()),
+                       osp.join(self.save_dir, f"{epoch}_info_stage_{stage_id:02d}.pth"))
+        torch.save({k: v.cpu() for k, v in self.sub_network_list[stage_id].state_dict().items()},
+                   osp.join(self.save_dir, f"{epoch}_net_mlp_stage_{stage_id:02d}.pth"))
+
+    def load_checkpoint(self, epoch, stage_id):
+        """Resume training of stage `stage_id`: weights (``load``) + the Adam state saved beside them."""
+        import os.path as osp
+        if not self.load(epoch, stage_id):
+            return None
+        tr = self.trainers[stage_id]
+        tr.load_from_module()
+        tr._refresh_transposed_weights()
+        info = torch.load(osp.join(self.save_dir, f"{epoch}_info_stage_{stage_id:02d}.pth"), map_location="cpu", weights_only=False)
+        tr.load_optimizer_state_dict(info["optimizer"])
+        return info["epoch"]

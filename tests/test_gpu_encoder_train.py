@@ -266,3 +266,39 @@ def test_baseline_training_loop_reduces_the_loss():
     log = run_train_baseline.main(["--num_samples", "8", "--batchSize", "8", "--total_epoch", "12", "--lr", "1e-4"])
     assert len(log) == 12
     assert log[-1]["loss_last"] < 0.8 * log[0]["loss_first"], (log[0], log[-1])
+
+
+def test_baseline_checkpoint_resume_is_bit_identical(tmp_path):
+    """save() after two training steps, a fresh model + load_checkpoint(), a third step: weights, BatchNorm statistics and Adam
+    moments equal those of three uninterrupted steps bit for bit (all kernels have a fixed summation order), and the optimizer
+    state is torch.optim.Adam's own format (loads into a torch optimizer over the reference-named parameters)."""
+    from ihmr_amd import two_hand
+    from ihmr_amd.baseline_model import InterHandModel
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    B = 4
+    def make():
+        torch.manual_seed(11)
+        return InterHandModel(types.SimpleNamespace(
+            isTrain=True, dist=False, process_rank=-1, batchSize=B, inputSize=224, input_nc=3, num_joints=42, total_params_dim=122,
+            cam_params_dim=3, pose_params_dim=96, shape_params_dim=20, trans_params_dim=3, model_root="", mean_param_file="mean_mano_params.pkl",
+            checkpoints_dir=str(tmp_path), lr=1e-4, lr_decay_type="none", total_epoch=3))
+    a = make()
+    fwd = lambda p, s, t: two_hand.forward_from_packed(a.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
+    batch = {k: v.cuda() for k, v in synthetic_opt_batch(B, fwd, seed=77, with_image=True).items()}
+    def step(m):
+        m.set_input(batch); m.forward_train(); m.optimize_parameters()
+    step(a); step(a)
+    a.save("latest", 2)
+    step(a)
+    b = make()
+    assert b.load_checkpoint("latest") == 2
+    step(b)
+    torch.cuda.synchronize()
+    for name in ("params", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(a.trainer.flat, name), getattr(b.trainer.flat, name)), name
+    assert a.trainer.step == b.trainer.step == 3
+    assert torch.equal(a.trainer.stem["run_var"], b.trainer.stem["run_var"])
+    info = torch.load(str(tmp_path / "latest_info.pth"), map_location="cpu", weights_only=False)
+    opt = torch.optim.Adam([torch.nn.Parameter(p.detach().cpu().clone()) for p in a.encoder.parameters()], lr=1e-4)
+    opt.load_state_dict(info["optimizer"])                 # torch accepts it: same parameter count, shapes checked on the next step
+    assert len(opt.state_dict()["state"]) == len(list(a.encoder.parameters()))

@@ -200,3 +200,35 @@ def test_train_loop_runs_and_reduces_the_loss():
     for row in log:
         assert row["loss_last"] < row["loss_first"], row
         assert 0 <= row["kept"] <= row["of"]
+
+
+def test_mlp_checkpoint_resume_is_bit_identical(tmp_path):
+    """MLPModel.save() after two steps of a stage, a fresh model + load_checkpoint(), a third step == three uninterrupted steps."""
+    from helpers import seeded_state_dict
+    g = dict(np.load(os.path.join(GOLD, "mlp_train.npz")))
+    batch = {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("in_")}
+    strategy = _strategy()
+    def make():
+        from ihmr_amd.mlp_model import MLPModel
+        m = MLPModel(_opt(batch["init_cam"].shape[0], checkpoints_dir=str(tmp_path)))
+        m.set_update_info(strategy, 10)
+        with torch.no_grad():
+            m.set_input(batch); m.forward(forward_backbone=True); m.compute_loss(); m.save_pred_to_prev()
+        m.add_new_network(0)
+        net = m.sub_network_list[0]
+        net.load_state_dict(seeded_state_dict(net, 950, last_scale=0.05))
+        m.trainers[0].load_from_module(); m.trainers[0]._refresh_transposed_weights()
+        return m
+    def step(m):
+        m.set_input(batch); m.retrive_prev_prediction(); m.forward(); m.compute_loss(strategy[0]["loss_weights"]); m.optimize_parameters()
+    a = make()
+    step(a); step(a)
+    a.save("latest", 0)
+    step(a)
+    b = make()
+    assert b.load_checkpoint("latest", 0) == "latest"
+    step(b)
+    torch.cuda.synchronize()
+    for name in ("params", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(a.trainers[0], name), getattr(b.trainers[0], name)), name
+    assert a.trainers[0].step == b.trainers[0].step == 3
