@@ -667,8 +667,9 @@ extern "C" int ihmr_avgpool_relu_backward(const float* y, const float* dy, float
 extern "C" int ihmr_preprocess_images(const uint8_t* pixels, const int64_t* offsets, const int32_t* sizes, const uint8_t* do_flip,
                                       int B, int final_size, float* img_out, uint8_t* img_u8, const float* joints_in,
                                       float* joints_out, void* stream) {
-    if (!pixels || !offsets || !sizes || !img_out || B <= 0 || final_size <= 0 || (joints_in && !joints_out)) return -1;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((final_size * final_size + PRE_THREADS - 1) / PRE_THREADS, B), dim3(PRE_THREADS), 0,
+    if (!pixels || !offsets || !sizes || !img_out || B <= 0 || final_size <= 0 || final_size % PRE_PPT || (joints_in && !joints_out))
+        return -1;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((final_size * final_size / PRE_PPT + PRE_THREADS - 1) / PRE_THREADS, B), dim3(PRE_THREADS), 0,
                        (hipStream_t)stream, pixels, offsets, sizes, do_flip, final_size, img_out, img_u8, joints_in, joints_out);
     return (int)hipGetLastError();
 }

@@ -264,7 +264,8 @@ int ihmr_avgpool_relu_backward(const float* y, const float* dy, float* dx, int N
  * offsets (B) int64: byte offset of image b in `pixels`;  sizes (B,2) int32: H, W;  do_flip (B) bytes or NULL.
  * img_out (B,3,final_size,final_size) float32 in [-1,1];  img_u8 optional (B,final_size,final_size,3) = the padded
  * uint8 image itself;  joints_in / joints_out optional (B,42,3) [x, y in source pixels, weight] -> [x, y in [-1,1], weight].
- * Every image must keep at least one pixel per side after the resize (the host wrapper checks, as cv2 would raise). */
+ * Every image must keep at least one pixel per side after the resize (the host wrapper checks, as cv2 would raise);
+ * final_size % 4 == 0. */
 int ihmr_preprocess_images(const uint8_t* pixels, const int64_t* offsets, const int32_t* sizes, const uint8_t* do_flip,
                            int B, int final_size, float* img_out, uint8_t* img_u8, const float* joints_in,
                            float* joints_out, void* stream);
