@@ -284,6 +284,7 @@ class EncoderTrainer:
             self.flat.p[u["name"] + ".beta"].copy_(u["bn"].bias.detach())
             u["run_mean"] = u["bn"].running_mean.detach().clone().to(self.dev)
             u["run_var"] = u["bn"].running_var.detach().clone().to(self.dev)
+            u["tracked"] = int(u["bn"].num_batches_tracked)
         for l, m in self._lin_modules():
             l.load(m.to(self.dev))
         self._refresh_derived()
@@ -296,6 +297,7 @@ class EncoderTrainer:
             u["conv"].weight.data.copy_(w[:, :3] if u is self.stem else w)
             u["bn"].weight.data.copy_(self.flat.p[u["name"] + ".gamma"]); u["bn"].bias.data.copy_(self.flat.p[u["name"] + ".beta"])
             u["bn"].running_mean.data.copy_(u["run_mean"]); u["bn"].running_var.data.copy_(u["run_var"])
+            u["bn"].num_batches_tracked.fill_(u["tracked"])
         for l, m in self._lin_modules():
             l.store(m)
         self.enc._packed = None
@@ -323,6 +325,7 @@ class EncoderTrainer:
         with torch.no_grad():                              # nn.BatchNorm2d's running statistics (momentum 0.1, unbiased variance)
             u["run_mean"].mul_(0.9).add_(saved[0], alpha=0.1)
             u["run_var"].mul_(0.9).add_(saved[1], alpha=0.1 * M / max(M - 1, 1))
+        u["tracked"] += 1
         u["save"] = dict(x=x, z=z, y=y, saved=saved, N=N, H=H, W=W, relu=relu)
         return y, Ho, Wo
 
