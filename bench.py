@@ -88,8 +88,8 @@ def pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--epoch", type=int, default=49, help="opt_default epoch per stage (49 -> 200 iterations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -639,6 +639,14 @@ extern "C" int ihmr_conv_wgrad(const float* x, const float* dy, float* dw, int N
     return (int)hipGetLastError();
 }
 
+extern "C" int ihmr_pack_dgrad_weight(const float* w, float* out, int kh, int kw, int Cin, int Cout, int ldw, int ldo, void* stream) {
+    if (!w || !out || ldw < Cout || ldo < Cin) return -1;
+    const long total = (long)kh * kw * Cout * Cin;
+    hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, out, kh, kw, Cin,
+                       Cout, ldw, ldo);
+    return (int)hipGetLastError();
+}
+
 extern "C" int ihmr_dilate2(const float* dy, float* out, int N, int Ho, int Wo, int C, void* stream) {
     if (!dy || !out || C % 4) return -1;
     const long total = (long)N * 2 * Ho * 2 * Wo * (C / 4);

@@ -176,6 +176,20 @@ __global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ 
     *reinterpret_cast<float4*>(out + idx * 4) = v;
 }
 
+// the filter of the input gradient from the forward filter: w [kh*kw*Cin][ldw] (k = (fh, fw, ci), column co) ->
+// out [kh*kw*Cout][ldo] with out[((kh-1-fh) * kw + (kw-1-fw)) * Cout + co][ci] = w[(fh * kw + fw) * Cin + ci][co]; one thread per
+// output element, coalesced over ci (the reads walk a column of w: layout plumbing, once per optimizer step)
+__global__ __launch_bounds__(256) void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int kh, int kw,
+                                                                int Cin, int Cout, int ldw, int ldo) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)kh * kw * Cout * Cin) return;
+    const int ci = (int)(idx % Cin);
+    long r = idx / Cin;
+    const int co = (int)(r % Cout);
+    const int tap = (int)(r / Cout), fh = kh - 1 - tap / kw, fw = kw - 1 - tap % kw;
+    out[(size_t)r * ldo + ci] = w[((size_t)(fh * kw + fw) * Cin + ci) * ldw + co];
+}
+
 // ------------------------------------------------------------------------------------- weight gradient
 // dW[k][n] = sum_m A(x)[m][k] . dY[m][n]:  k = (filter tap, input channel) as in the forward's K index, m = output pixel.
 // The same tiling as conv_igemm_kernel with the roles turned: the REDUCTION runs over the pixels (16 per step), a workgroup

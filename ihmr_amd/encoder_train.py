@@ -104,12 +104,14 @@ def bn_train_forward(z, gamma, beta, residual=None, relu=True):
     return y, (mean, var, invstd)
 
 
-def bn_train_backward(z, g, saved, gamma):
-    """g = gradient w.r.t. the BatchNorm output (after the ReLU mask) -> (dz, dgamma, dbeta)."""
+def bn_train_backward(z, g, saved, gamma, dgamma=None, dbeta=None):
+    """g = gradient w.r.t. the BatchNorm output (after the ReLU mask) -> (dz, dgamma, dbeta); dgamma / dbeta optionally into
+    the caller's buffers."""
     M, C = z.shape
     mean, _, invstd = saved
     dz = torch.empty_like(z)
-    dgamma, dbeta = torch.empty(C, device=z.device), torch.empty(C, device=z.device)
+    dgamma = torch.empty(C, device=z.device) if dgamma is None else dgamma
+    dbeta = torch.empty(C, device=z.device) if dbeta is None else dbeta
     ws = torch.empty(hip.lib().ihmr_bn_workspace_bytes(C) // 4, device=z.device)
     hip.check(hip.lib().ihmr_bn_train_backward(hip.ptr(z), hip.ptr(g), M, C, hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(dz),
                                                hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), hip.stream_ptr()), "ihmr_bn_train_backward")
@@ -309,10 +311,11 @@ class EncoderTrainer:
             if u is self.stem:
                 continue                                   # no gradient w.r.t. the image
             cout, cin, k = u["cout"], u["cin"], u["k"]
-            w = self.flat.p[u["name"] + ".w"][:k * k * cin, :cout].reshape(k, k, cin, cout)
+            w = self.flat.p[u["name"] + ".w"]
             if "w_dgrad" not in u:
                 u["w_dgrad"] = torch.zeros(_ceil(k * k * cout, 16), _ldw(cin), device=self.dev)
-            u["w_dgrad"][:k * k * cout, :cin].copy_(w.flip(0, 1).permute(0, 1, 3, 2).reshape(k * k * cout, cin))
+            hip.check(hip.lib().ihmr_pack_dgrad_weight(hip.ptr(w), hip.ptr(u["w_dgrad"]), k, k, cin, cout, w.shape[1], u["w_dgrad"].shape[1],
+                                                       hip.stream_ptr()), "ihmr_pack_dgrad_weight")
         for l in (self.fc1, self.feat, self.reg, self.cls):
             l.refresh()
 
@@ -386,8 +389,8 @@ class EncoderTrainer:
     def _unit_backward(self, u, g, need_dx=True):
         """g = gradient w.r.t. the unit's output (already masked by its ReLU) -> gradient w.r.t. its input."""
         s = u["save"]
-        dz, dgamma, dbeta = bn_train_backward(s["z"], g, s["saved"], self.flat.p[u["name"] + ".gamma"])
-        self.flat.g[u["name"] + ".gamma"].copy_(dgamma); self.flat.g[u["name"] + ".beta"].copy_(dbeta)
+        dz, _, _ = bn_train_backward(s["z"], g, s["saved"], self.flat.p[u["name"] + ".gamma"], self.flat.g[u["name"] + ".gamma"],
+                                     self.flat.g[u["name"] + ".beta"])
         conv_wgrad(s["x"], dz, s["N"], s["H"], s["W"], u["cin"], u["cout"], u["k"], u["stride"], u["pad"], out=self.flat.g[u["name"] + ".w"])
         if not need_dx:
             return None

@@ -249,6 +249,9 @@ int ihmr_bn_train_backward(const float* z, const float* g, long M, int C, const 
                            const float* gamma, float* dz, float* dgamma, float* dbeta, void* workspace, void* stream);
 int ihmr_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh,
                     int kw, int stride, int pad, int ldx, int lddy, int ldw, void* workspace, size_t workspace_bytes, void* stream);
+/* the flipped, transposed filter above from the forward filter w [kh*kw*Cin][ldw] -> out [kh*kw*Cout][ldo] (rows beyond and
+ * columns >= Cin untouched: zero them once) */
+int ihmr_pack_dgrad_weight(const float* w, float* out, int kh, int kw, int Cin, int Cout, int ldw, int ldo, void* stream);
 int ihmr_dilate2(const float* dy, float* out, int N, int Ho, int Wo, int C, void* stream);
 int ihmr_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int ihmr_avgpool_relu_backward(const float* y, const float* dy, float* dx, int N, int HW, int C, int ldy, void* stream);
