@@ -2,7 +2,8 @@
 ``src/train_baseline.py``): BatchNorm2d with batch statistics, the weight / input gradients of a convolution, and the
 pooling backward passes, as thin wrappers over the C ABI (``ihmr_bn_train_*``, ``ihmr_conv_wgrad``, ``ihmr_conv_igemm`` with
 the flipped filter, ``ihmr_dilate2``, ``ihmr_maxpool3x3s2_backward``, ``ihmr_avgpool_relu_backward``).  Activations are
-NHWC matrices ``[N*H*W, C]`` as everywhere in :mod:`ihmr_amd.networks`.  No CPU fallback.
+NHWC matrices ``[N*H*W, C]`` as everywhere in :mod:`ihmr_amd.networks`.  No CPU fallback.  :class:`EncoderTrainer` (below)
+assembles them into the whole ``InterHandEncoder`` in train mode: forward, backward to every parameter, Adam, checkpointing.
 
 The reference: ``models/resnet.py:58-94`` (Bottleneck: conv-bn-relu x2, conv-bn, + identity / downsample, relu),
 ``:138-156`` (stem, max-pool, four stages, AvgPool2d(7), ReLU, fc1, ReLU), trained through ``loss.backward()`` at
@@ -227,7 +228,8 @@ class _Linear:
 class EncoderTrainer:
     """``InterHandEncoder`` (models/networks.py:30-80) in TRAIN mode on the HIP path: forward with batch-statistics
     BatchNorm that keeps what the backward needs, backward from (d loss / d params (B,122), d loss / d hand_type (B,2)) to the
-    gradient of every parameter, ``torch.optim.Adam`` semantics on one flat buffer, data parallelism by one all-reduce."""
+    gradient of every parameter, ``torch.optim.Adam`` semantics on one flat buffer, data parallelism by bucketed all-reduces of
+    the flat gradient that run under the backward pass (:class:`ihmr_amd.dist.OverlappedGradientReducer`)."""
 
     def __init__(self, encoder, batch_size, lr, device):
         hip.require_gpu()
