@@ -109,8 +109,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        local_rank %= max(torch.cuda.device_count(), 1)     # one rank per GPU on the driver's node; ranks may share a GPU in the
+        torch.cuda.set_device(local_rank)                   # single-GPU check of this code path (IHMR_DIST_BACKEND=gloo)
+        backend = os.environ.get("IHMR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(0)

@@ -23,8 +23,10 @@ def init_dist(backend: str | None = None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:     # IHMR_DIST_BACKEND=gloo: ranks may share one GPU (the single-GPU check of the multi-rank code paths)
+        backend = os.environ.get("IHMR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend != "nccl" and torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
     if backend == "nccl":
         torch.cuda.set_device(local % torch.cuda.device_count())
     if not dist.is_initialized():
