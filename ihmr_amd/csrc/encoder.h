@@ -40,8 +40,18 @@ struct ConvArgs {
 #else
 #define CONV_EXP(bit) 0
 #endif
-template <int BM, int BN>
-__global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(ConvArgs a) {
+// FAST: Cin % 16 == 0 (every layer but the stem), compiled without the generic gather so that its per-loader state does not
+// cost registers or a branch per K step;
+// and the 128 x 128 tile is held to 80 registers (three resident workgroups per CU instead of two; measured: 4 waves per SIMD
+// 6.94 ms, 6 waves 6.86 ms, 8 waves -- with spills -- 7.07 ms per 64-image encoder pass; the runtime `fast` branch inside the
+// K loop and the 32-register residual prefetch of the old epilogue cost 7.8 ms)
+#ifndef CONV_WAVES_PER_EU
+#define CONV_WAVES_PER_EU 6
+#endif
+template <int BM, int BN, bool FAST>
+__global__ __launch_bounds__((BM / 64) * (BN / 32) * 64)
+__attribute__((amdgpu_waves_per_eu((FAST && BM == 128 && BN == 128) ? CONV_WAVES_PER_EU : 4)))
+void conv_igemm_kernel(ConvArgs a) {
     constexpr int WN_WAVES = BN / 32;                      // waves along n; each wave owns a 64 x 32 sub-tile
     constexpr int THREADS = (BM / 64) * WN_WAVES * 64;
     constexpr int LDA = BM + 5, LDB = BN + 4;              // 8*LDA % 32 != 0: the two k-halves of a row hit different banks
@@ -54,7 +64,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(
     const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
     const int M = a.N * a.Ho * a.Wo, K = a.kh * a.kw * a.Cin, Kpad = (K + CONV_BK - 1) / CONV_BK * CONV_BK;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const bool fast = (a.Cin % CONV_BK) == 0;              // a 16-wide K chunk never straddles a filter tap
+    constexpr bool fast = FAST;                            // a 16-wide K chunk never straddles a filter tap
 
     // ---- A loader: float4 f = tid + i*THREADS -> (row f / 4, 4 consecutive k at (f % 4) * 4)
     int arow[A_F4], ak4[A_F4], an[A_F4], aho[A_F4], awo[A_F4];
@@ -191,27 +201,26 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_igemm_kernel(
     }
 #endif
     const float bv = a.bias ? a.bias[n] : 0.f;
-    // residual rows first, all loads in flight together (y may alias nothing here, but the compiler cannot know:
-    // interleaved with the stores it would issue them one by one)
-    float res[2][16];
+    // residual rows first, the loads of one 32-row half in flight together (y may alias nothing here, but the compiler cannot
+    // know: interleaved with the stores it would issue them one by one); one half at a time keeps 16 instead of 32 registers live
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi) {
+        float res[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-            res[mi][r] = (a.residual && m < M) ? a.residual[(size_t)m * a.ldr + n] : 0.f;
+            res[r] = (a.residual && m < M) ? a.residual[(size_t)m * a.ldr + n] : 0.f;
         }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
             if (m >= M) continue;
-            float v = acc[mi][r] + bv + res[mi][r];
+            float v = acc[mi][r] + bv + res[r];
             if (a.act == 1) v = fmaxf(v, 0.f);
             else if (a.act == 2) v = 1.0f / (1.0f + expf(-v));
             a.y[(size_t)m * a.ldy + n] = v;
         }
+    }
 }
 
 // split-K epilogue: y = act(sum_z partial[z] (fixed order) + bias + residual); one thread per VEC output channels

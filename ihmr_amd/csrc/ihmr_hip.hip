@@ -474,11 +474,21 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
     }
     a.ksplit = ksplit;
     const dim3 grid((M + tiles[pick][0] - 1) / tiles[pick][0], (Cout + tiles[pick][1] - 1) / tiles[pick][1], ksplit);
-    switch (pick) {
-        case 0: hipLaunchKernelGGL((conv_igemm_kernel<128, 128>), grid, dim3(512), 0, st, a); break;
-        case 1: hipLaunchKernelGGL((conv_igemm_kernel<64, 128>), grid, dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((conv_igemm_kernel<128, 64>), grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((conv_igemm_kernel<64, 64>), grid, dim3(128), 0, st, a); break;
+    const bool fast = (Cin % CONV_BK) == 0 && (ldx % 4) == 0;
+    if (fast) {
+        switch (pick) {
+            case 0: hipLaunchKernelGGL((conv_igemm_kernel<128, 128, true>), grid, dim3(512), 0, st, a); break;
+            case 1: hipLaunchKernelGGL((conv_igemm_kernel<64, 128, true>), grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((conv_igemm_kernel<128, 64, true>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((conv_igemm_kernel<64, 64, true>), grid, dim3(128), 0, st, a); break;
+        }
+    } else {
+        switch (pick) {
+            case 0: hipLaunchKernelGGL((conv_igemm_kernel<128, 128, false>), grid, dim3(512), 0, st, a); break;
+            case 1: hipLaunchKernelGGL((conv_igemm_kernel<64, 128, false>), grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((conv_igemm_kernel<128, 64, false>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((conv_igemm_kernel<64, 64, false>), grid, dim3(128), 0, st, a); break;
+        }
     }
     if (ksplit > 1) {
         if (Cout % 4 == 0) {
