@@ -85,6 +85,114 @@ def pmc_traffic(kernel):
     return None, None
 
 
+
+def secondary(config):
+    """BASELINE.json configs[1] / configs[2] (parity-test cases, NOT the driver's bench line): IHMR-Baseline batch 64 and
+    IHMR-MLP batch 128 inference on one MI355X with the CPU oracle timed beside them on a bounded sample (BASELINE.md
+    section 3: "reported per config").  One JSON line; `python bench.py --config baseline|mlp`."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import seeded_state_dict
+    from ihmr_amd import two_hand
+    from ihmr_amd.assets import synthetic_mano
+    from ihmr_amd.strategies import make_mlp_strategy
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    torch.cuda.set_device(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(min(32, cores))
+
+    def timeit(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def opt(B):
+        return types.SimpleNamespace(isTrain=False, dist=False, process_rank=-1, batchSize=B, inputSize=224, input_nc=3, num_joints=42,
+                                     total_params_dim=122, cam_params_dim=3, pose_params_dim=96, shape_params_dim=20, trans_params_dim=3,
+                                     model_root="", mean_param_file="mean_mano_params.pkl", checkpoints_dir="./checkpoints",
+                                     strategy="mlp_default")
+    if config == "baseline":
+        from ihmr_amd.baseline_model import InterHandModel
+        from oracle.encoder_ref import InterHandEncoderRef
+        from oracle.mano_ref import ManoRef
+        from oracle.sdf_ref import SDFLossRef
+        B, Bc = 64, 64
+        m = InterHandModel(opt(B)); m.eval()
+        fwd = lambda p, s, t: two_hand.forward_from_packed(m.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
+        cpu_batch = synthetic_opt_batch(B, fwd, seed=1234, with_image=True)
+        batch = {k: v.cuda() for k, v in cpu_batch.items()}
+        def step():
+            m.set_input(batch); m.test(); return m.get_pred_result()
+        dt = timeit(step, 10, 3)
+        enc_dt = timeit(lambda: m.encoder(batch["img"]), 10, 3)
+        # CPU oracle on the first Bc images: encoder + two MANO evaluations (prediction, annotation) + the collision metric
+        right, left = synthetic_mano(True), synthetic_mano(False)
+        ref = InterHandEncoderRef(m.mean_params[:Bc].clone()); ref.load_state_dict({k: v.cpu() for k, v in m.encoder.state_dict().items()}); ref.eval()
+        mr, ml = ManoRef(right), ManoRef(left)
+        sdf = SDFLossRef(right["faces"], left["faces"])
+        def two(pose, shape, trans):
+            o = {}
+            for name, mm, ps, bs in (("right", mr, 0, 0), ("left", ml, 48, 10)):
+                r = mm(global_orient=pose[:, ps:ps + 3], hand_pose=pose[:, ps + 3:ps + 48], betas=shape[:, bs:bs + 10])
+                o[name] = (r.vertices, r.joints)
+            shift = trans.reshape(-1, 1, 3) + (o["right"][1][:, 0:1] - o["left"][1][:, 0:1])
+            return o["right"][0], o["left"][0] + shift
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            fp, _ = ref(cpu_batch["img"][:Bc])
+            rv, lv = two(fp[:, 3:99], fp[:, 99:119], fp[:, 119:122])
+            sdf(torch.stack([rv, lv], 1), return_per_vert_loss=True, return_origin_scale_loss=True)
+            two(cpu_batch["mano_pose"][:Bc], cpu_batch["mano_betas"][:Bc], cpu_batch["hand_trans"][:Bc, 0, :3])
+        tc = time.perf_counter() - t0
+        out = dict(metric="images/sec, IHMR-Baseline (ResNet-50 + MANO regress) batch=64 inference", value=B / dt, unit="images/s", n_gpus=1,
+                   ms_per_step=dt * 1e3, dtype="f32", data="synthetic", higher_is_better=True,
+                   config=dict(workload="BASELINE.json configs[1]: InterHandModel.test() + get_pred_result(), batch 64, 224x224"),
+                   roofline=dict(bound="mfma", kernel="conv_igemm_kernel (whole encoder)", achieved=8.2e9 * B / enc_dt / 1e12,
+                                 peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=8.2e9 * B / enc_dt / 1e12 / FP32_PEAK_TFLOPS, traffic=None,
+                                 encoder_ms_per_batch=enc_dt * 1e3),
+                   cpu_baseline=dict(value=Bc / tc, unit="images/s", cores=cores, kind="port",
+                                     sample=f"{Bc} images through the oracle (encoder + 2 x two-hand MANO + dense voxel SDF) in {tc:.1f}s"))
+    else:
+        from ihmr_amd.mlp_model import MLPModel
+        from oracle.mlp_ref import MLPRef
+        B, Bc = 128, 64
+        strat = make_mlp_strategy()
+        m = MLPModel(opt(B)); m.set_update_info(strat, B)
+        orc = MLPRef(synthetic_mano(True), synthetic_mano(False), Bc, strat, num_data=B)
+        for i in range(len(strat)):
+            m.add_new_network(i)
+            sd = seeded_state_dict(orc.nets[i], 900 + i, last_scale=0.02)
+            orc.nets[i].load_state_dict(sd); m.sub_network_list[i].load_state_dict(sd)
+        m.eval()
+        fwd = lambda p, s, t: two_hand.forward_from_packed(m.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
+        b = synthetic_opt_batch(B, fwd, seed=1234, with_feat=True)
+        b["init_hand_trans"] = b["init_hand_trans"][:, 0, :3].contiguous(); b["img"] = torch.zeros(B, 3, 8, 8)
+        batch = {k: v.cuda() for k, v in b.items()}
+        pend = []
+        def step():
+            m.set_input(batch); m.test(); pend.append(m.get_pred_result_async())
+            if len(pend) > 1:
+                pend.pop(0).wait()
+        dt = timeit(step, 20, 3)
+        orc.set_input({k: v[:Bc].clone() for k, v in b.items()})
+        t0 = time.perf_counter()
+        orc.test()
+        tc = time.perf_counter() - t0
+        out = dict(metric="images/sec, IHMR-MLP refinement head batch=128 inference", value=B / dt, unit="images/s", n_gpus=1, ms_per_step=dt * 1e3,
+                   dtype="f32", data="synthetic", higher_is_better=True,
+                   config=dict(workload="BASELINE.json configs[2]: MLPModel.test() (6 stages: 8 MANO + SDF evaluations, 6 MLPs) + export, batch 128"),
+                   roofline=None,
+                   cpu_baseline=dict(value=Bc / tc, unit="images/s", cores=cores, kind="port",
+                                     sample=f"{Bc} samples through the oracle's MLPRef.test() in {tc:.1f}s"))
+    out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,7 +209,13 @@ def main():
                          "identical to separate batches); batches in flight = streams x fuse")
     ap.add_argument("--streams", type=int, default=4,
                     help="independent batches in flight per GPU (each step is still one full pass over one batch of --batch samples)")
+    ap.add_argument("--config", type=str, default="opt", choices=["opt", "baseline", "mlp"],
+                    help="opt = the driver's bench line (IHMR-OPT); baseline / mlp = the secondary BASELINE.json configs with their own "
+                         "CPU baselines (one process, one GPU)")
     args = ap.parse_args()
+    if args.config != "opt":
+        assert torch.cuda.is_available(), "bench.py needs an MI355X: the hot path has no CPU fallback"
+        return secondary(args.config)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
