@@ -419,6 +419,12 @@ def main():
                         max_batches_per_launch_sequence=G,
                         parallelism=f"dp{world} (independent samples, no collective)"),
             roofline=roofline, cpu_baseline=cpu,
+            # LBS + losses + Adam are nominally HBM work -- 78 KB of algorithmic traffic per sample and
+            # iteration -- and in practice bound by the six dependent kernel boundaries of an iteration
+            lbs_losses_adam=dict(bound="hbm", algorithmic_bytes_per_sample_iteration=78e3, kernel_launches_per_iteration=6,
+                                 achieved=78e3 * B * world / (ms_per_step / (n_iters + 1) * 1e-3) / 1e9, peak=6300.0, unit="GB/s",
+                                 frac=78e3 * B * world / (ms_per_step / (n_iters + 1) * 1e-3) / 1e9 / (6300.0 * world),
+                                 note="whole-iteration rate at the bench's concurrency: the part is latency-, not bandwidth-bound"),
             parity=dict(mean_penetration_depth_m=float(np.mean(res["collision_loss_origin_scale"]))),
         )
         if cpu is not None:
