@@ -1,0 +1,47 @@
+"""The N > 1 code paths on ONE GPU: two ranks share the device (IHMR_DIST_BACKEND=gloo, CUDA tensors through gloo), launched
+exactly as the driver launches them (``python -m torch.distributed.run --nproc-per-node 2 ...``).  RCCL itself needs a
+multi-GPU node; what is covered here is everything around it: rank / seed handling, barriers, the MAX / SUM reductions, rank-0
+output, the gradient exchange of the training loops."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=600):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, IHMR_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_with_two_ranks_prints_one_line():
+    lines = _run(["bench.py", "--gpus", "2", "--steps", "8", "--warmup", "4"])
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["steps"] == 8 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["frac"] > 0
+
+
+def test_run_optimize_two_ranks_equals_one_process():
+    from ihmr_amd import run_optimize
+    two = _run(["-m", "ihmr_amd.run_optimize", "--num_samples", "128", "--batchSize", "32", "--opt_epoch", "9"])[-1]
+    one = run_optimize.main(["--num_samples", "128", "--batchSize", "32", "--opt_epoch", "9"])
+    for k in ("mpjpe_3d", "inter_mpjpe_3d", "collision_ave", "collision_max"):
+        assert abs(two[k] - one[k]) <= 1e-12 * max(1.0, abs(one[k])), (k, two[k], one[k])
+
+
+def test_training_loops_with_two_ranks():
+    log = _run(["-m", "ihmr_amd.run_train_mlp", "--num_samples", "64", "--batchSize", "32", "--epochs", "4", "--stages", "1"])
+    assert log[-1]["steps"] == 8 and log[-1]["loss_last"] < log[-1]["loss_first"]
+    log = _run(["-m", "ihmr_amd.run_train_baseline", "--num_samples", "8", "--batchSize", "8", "--total_epoch", "6", "--lr", "1e-4"])
+    assert len(log) == 6 and log[-1]["loss_last"] < log[0]["loss_first"]
