@@ -657,6 +657,15 @@ extern "C" int ihmr_pack_dgrad_weight(const float* w, float* out, int kh, int kw
     return (int)hipGetLastError();
 }
 
+extern "C" int ihmr_interleave2(const float* p00, const float* p01, const float* p10, const float* p11, float* dx, int N, int Ho, int Wo,
+                                int C, void* stream) {
+    if (!p00 || !p01 || !p10 || !p11 || !dx || C % 4) return -1;
+    const long total = (long)N * 2 * Ho * 2 * Wo * (C / 4);
+    hipLaunchKernelGGL(interleave2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p00, p01, p10, p11, dx, N,
+                       Ho, Wo, C);
+    return (int)hipGetLastError();
+}
+
 extern "C" int ihmr_dilate2(const float* dy, float* out, int N, int Ho, int Wo, int C, void* stream) {
     if (!dy || !out || C % 4) return -1;
     const long total = (long)N * 2 * Ho * 2 * Wo * (C / 4);

@@ -176,6 +176,23 @@ __global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ 
     *reinterpret_cast<float4*>(out + idx * 4) = v;
 }
 
+// the four parity phases of a stride-2 input gradient back into place: dx[n][2 io + pi][2 jo + pj] = phase[2 pi + pj][n][io][jo]
+// (each phase [N][Ho][Wo][C]; dx [N][2Ho][2Wo][C])
+__global__ __launch_bounds__(256) void interleave2_kernel(const float* __restrict__ p00, const float* __restrict__ p01,
+                                                          const float* __restrict__ p10, const float* __restrict__ p11,
+                                                          float* __restrict__ dx, int N, int Ho, int Wo, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = C / 4;
+    if (idx >= (long)N * 2 * Ho * 2 * Wo * c4) return;
+    const int c = (int)(idx % c4) * 4;
+    long p = idx / c4;
+    const int w = (int)(p % (2 * Wo)); p /= 2 * Wo;
+    const int h = (int)(p % (2 * Ho));
+    const int n = (int)(p / (2 * Ho));
+    const float* src = (h & 1) ? ((w & 1) ? p11 : p10) : ((w & 1) ? p01 : p00);
+    *reinterpret_cast<float4*>(dx + idx * 4) = *reinterpret_cast<const float4*>(src + ((size_t)(n * Ho + h / 2) * Wo + w / 2) * C + c);
+}
+
 // the filter of the input gradient from the forward filter: w [kh*kw*Cin][ldw] (k = (fh, fw, ci), column co) ->
 // out [kh*kw*Cout][ldo] with out[((kh-1-fh) * kw + (kw-1-fw)) * Cout + co][ci] = w[(fh * kw + fw) * Cin + ci][co]; one thread per
 // output element, coalesced over ci (the reads walk a column of w: layout plumbing, once per optimizer step)

@@ -60,10 +60,52 @@ def conv_forward(x, w_packed, N, H, W, Cin, Cout, k, stride, pad, out=None):
     return out, Ho, Wo
 
 
+def pack_dgrad_phase_weights(weight: torch.Tensor):
+    """(Cout, Cin, 3, 3) filter of a stride-2, padding-1 convolution -> the four sub-filters of its input gradient, one per
+    output parity (pi, pj): an even output row gets filter row 1 alone, an odd one rows 2 and 0 (dY rows io and io + 1); each
+    [ceil16(kh'*kw'*Cout)][ldw(Cin)] K-major with k = (fh', fw', cout), what ``ihmr_conv_igemm`` reads."""
+    cout, cin = weight.shape[:2]
+    taps = ([1], [2, 0])
+    out = []
+    for pi in (0, 1):
+        for pj in (0, 1):
+            sub = weight[:, :, taps[pi], :][:, :, :, taps[pj]]                       # (cout, cin, kh', kw')
+            K = sub.shape[2] * sub.shape[3] * cout
+            full = weight.new_zeros(_ceil(K, 16), _ldw(cin))
+            full[:K, :cin] = sub.permute(2, 3, 0, 1).reshape(K, cin)
+            out.append(full.contiguous())
+    return out
+
+
+def conv_dgrad_s2_3x3(dy, phase_weights, N, H, W, Cin, Cout):
+    """Input gradient of a 3x3 / stride 2 / padding 1 convolution as four stride-1 convolutions of dY (one per output parity)
+    + one interleave: the work of the forward convolution, not four times it (no zero-inserted dY)."""
+    Ho, Wo = H // 2, W // 2
+    ws = _splitk_workspace(dy.device)
+    phases = []
+    for i, w in enumerate(phase_weights):
+        kh, kw = 1 + i // 2, 1 + i % 2
+        out = torch.empty(N * Ho * Wo, Cin, device=dy.device)
+        hip.check(hip.lib().ihmr_conv_igemm(hip.ptr(dy), hip.ptr(w), None, None, hip.ptr(out), N, Ho, Wo, Cout, Ho, Wo, Cin, kh, kw, 1, 0,
+                                            dy.shape[1], w.shape[1], Cin, 0, 0, ws.data_ptr(), ws.numel() * 4, hip.stream_ptr()), "ihmr_conv_igemm")
+        phases.append(out)
+    dx = torch.empty(N * H * W, Cin, device=dy.device)
+    hip.check(hip.lib().ihmr_interleave2(*(hip.ptr(p) for p in phases), hip.ptr(dx), N, Ho, Wo, Cin, hip.stream_ptr()), "ihmr_interleave2")
+    return dx
+
+
 def conv_dgrad(dy, w_dgrad, N, H, W, Cin, Cout, k, stride, pad):
     """dy [N*Ho*Wo, Cout] -> dx [N*H*W, Cin] (H, W even for the stride-2 layers, as everywhere in ResNet-50 at 224 x 224)."""
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     src, Hs, Ws = dy, Ho, Wo
+    if stride == 2 and k == 1 and pad == 0:
+        # strided 1x1 (the downsample branch): only the even pixels receive a gradient -- the GEMM runs on the Ho x Wo pixels
+        # and its result is spread out, a quarter of the work of a convolution over the zero-inserted dY
+        assert H == 2 * Ho and W == 2 * Wo
+        small, _, _ = conv_forward(dy, w_dgrad, N, Ho, Wo, Cout, Cin, 1, 1, 0)
+        dx = torch.empty(N * H * W, Cin, device=dy.device)
+        hip.check(hip.lib().ihmr_dilate2(hip.ptr(small), hip.ptr(dx), N, Ho, Wo, Cin, hip.stream_ptr()), "ihmr_dilate2")
+        return dx
     if stride == 2:
         assert H == 2 * Ho and W == 2 * Wo
         src = torch.empty(N * H * W, Cout, device=dy.device)
@@ -314,6 +356,9 @@ class EncoderTrainer:
                 continue                                   # no gradient w.r.t. the image
             cout, cin, k = u["cout"], u["cin"], u["k"]
             w = self.flat.p[u["name"] + ".w"]
+            if k == 3 and u["stride"] == 2 and u["pad"] == 1:
+                u["w_phase"] = pack_dgrad_phase_weights(unpack_wgrad(w, (cout, cin, 3, 3)))
+                continue
             if "w_dgrad" not in u:
                 u["w_dgrad"] = torch.zeros(_ceil(k * k * cout, 16), _ldw(cin), device=self.dev)
             hip.check(hip.lib().ihmr_pack_dgrad_weight(hip.ptr(w), hip.ptr(u["w_dgrad"]), k, k, cin, cout, w.shape[1], u["w_dgrad"].shape[1],
@@ -396,6 +441,8 @@ class EncoderTrainer:
         conv_wgrad(s["x"], dz, s["N"], s["H"], s["W"], u["cin"], u["cout"], u["k"], u["stride"], u["pad"], out=self.flat.g[u["name"] + ".w"])
         if not need_dx:
             return None
+        if "w_phase" in u:
+            return conv_dgrad_s2_3x3(dz, u["w_phase"], s["N"], s["H"], s["W"], u["cin"], u["cout"])
         return conv_dgrad(dz, u["w_dgrad"], s["N"], s["H"], s["W"], u["cin"], u["cout"], u["k"], u["stride"], u["pad"])
 
     def backward(self, d_params, d_hand):

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "ihmr_opt_forward_graph_create", "ihmr_graph_launch", "ihmr_graph_destroy", "ihmr_opt_set_params", "ihmr_eval_metrics", "ihmr_conv_igemm", "ihmr_maxpool3x3s2",
     "ihmr_avgpool_relu", "ihmr_preprocess_images", "ihmr_mlp_train_grad", "ihmr_transpose", "ihmr_relu_backward", "ihmr_colsum",
     "ihmr_adam_step", "ihmr_bn_workspace_bytes", "ihmr_bn_train_forward", "ihmr_bn_train_backward", "ihmr_conv_wgrad",
-    "ihmr_dilate2", "ihmr_pack_dgrad_weight", "ihmr_maxpool3x3s2_backward", "ihmr_avgpool_relu_backward", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
+    "ihmr_dilate2", "ihmr_interleave2", "ihmr_pack_dgrad_weight", "ihmr_maxpool3x3s2_backward", "ihmr_avgpool_relu_backward", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
 ]
 
 
@@ -124,6 +124,7 @@ def lib():
         L.ihmr_bn_train_backward.argtypes = [vp, vp, C.c_long, i, vp, vp, vp, vp, vp, vp, vp, vp]
         L.ihmr_conv_wgrad.argtypes = [vp, vp, vp] + [i] * 14 + [vp, C.c_size_t, vp]
         L.ihmr_dilate2.argtypes = [vp, vp, i, i, i, i, vp]
+        L.ihmr_interleave2.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
         L.ihmr_pack_dgrad_weight.argtypes = [vp, vp, i, i, i, i, i, i, vp]
         L.ihmr_maxpool3x3s2_backward.argtypes = [vp, vp, vp, i, i, i, i, i, i, vp]
         L.ihmr_avgpool_relu_backward.argtypes = [vp, vp, vp, i, i, i, i, vp]

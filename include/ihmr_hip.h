@@ -253,6 +253,10 @@ int ihmr_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, in
  * columns >= Cin untouched: zero them once) */
 int ihmr_pack_dgrad_weight(const float* w, float* out, int kh, int kw, int Cin, int Cout, int ldw, int ldo, void* stream);
 int ihmr_dilate2(const float* dy, float* out, int N, int Ho, int Wo, int C, void* stream);
+/* stride-2 3x3 input gradient without the zeros: the four parity phases of dx are stride-1 convolutions of dY with 1x1 / 1x2 /
+ * 2x1 / 2x2 sub-filters (ihmr_conv_igemm); this puts them back: dx[n][2io+pi][2jo+pj] = phase[2pi+pj][n][io][jo] */
+int ihmr_interleave2(const float* p00, const float* p01, const float* p10, const float* p11, float* dx, int N, int Ho, int Wo, int C,
+                     void* stream);
 int ihmr_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int ihmr_avgpool_relu_backward(const float* y, const float* dy, float* dx, int N, int HW, int C, int ldy, void* stream);
 

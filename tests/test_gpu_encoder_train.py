@@ -59,7 +59,7 @@ def test_batchnorm_train_forward_backward(N, C, H, W, res, relu):
 CONVS = [  # N, Cin, H, W, Cout, k, stride, pad
     (4, 64, 16, 16, 64, 1, 1, 0), (2, 64, 14, 14, 64, 3, 1, 1), (2, 128, 16, 16, 128, 3, 2, 1), (2, 256, 8, 8, 512, 1, 2, 0),
     (2, 4, 32, 32, 64, 7, 2, 3), (3, 512, 7, 7, 2048, 1, 1, 0), (2, 512, 7, 7, 512, 3, 1, 1), (8, 64, 56, 56, 256, 1, 1, 0),
-    (2, 16, 6, 10, 24, 3, 1, 1),
+    (2, 16, 6, 10, 24, 3, 1, 1), (3, 64, 12, 20, 32, 3, 2, 1),
 ]
 
 
@@ -87,6 +87,10 @@ def test_conv_weight_and_input_gradients(N, Cin, H, W, Cout, k, stride, pad):
         dx = T.conv_dgrad(dyg, T.pack_dgrad_weight(w.detach()).cuda(), N, H, W, Cin, Cout, k, stride, pad)
         torch.cuda.synchronize()
         _close("conv dX", _nchw(dx, N, H, W), x.grad, 2e-5)
+        if k == 3 and stride == 2 and pad == 1:          # the same gradient from the four parity phases (no zero insertion)
+            dx2 = T.conv_dgrad_s2_3x3(dyg, [p.cuda() for p in T.pack_dgrad_phase_weights(w.detach())], N, H, W, Cin, Cout)
+            torch.cuda.synchronize()
+            _close("conv dX by parity phases", _nchw(dx2, N, H, W), x.grad, 2e-5)
 
 
 def test_pooling_backward():
