@@ -590,14 +590,10 @@ extern "C" int ihmr_bn_train_forward(const float* z, long M, int C, const float*
     const int S = bn_chunks(M, &rows_per);
     float* part = (float*)workspace;
     const dim3 grid((C + 63) / 64, S);
-    hipLaunchKernelGGL(bn_partial_kernel<0>, grid, dim3(256), 0, st, z, (const float*)nullptr, (int)M, C, C, C, rows_per,
+    // one pass over z: sum z and sum (z - z0)^2 with row 0 as the pivot, then mean / variance / invstd
+    hipLaunchKernelGGL(bn_partial_kernel<3>, grid, dim3(256), 0, st, z, (const float*)nullptr, (int)M, C, C, C, rows_per,
                        (const float*)nullptr, (const float*)nullptr, part);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)part, S, 1, C, 1.0 / (double)M, mean,
-                       (float*)nullptr, 0.f);
-    hipLaunchKernelGGL(bn_partial_kernel<1>, grid, dim3(256), 0, st, z, (const float*)nullptr, (int)M, C, C, C, rows_per,
-                       (const float*)mean, (const float*)nullptr, part);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)part, S, 1, C, 1.0 / (double)M, var, invstd,
-                       eps);
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)part, z, S, C, M, mean, var, invstd, eps);
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, st, z, (const float*)mean,
                        (const float*)invstd, gamma, beta, residual, y, M, C, relu);
     return (int)hipGetLastError();
@@ -612,7 +608,7 @@ extern "C" int ihmr_bn_train_backward(const float* z, const float* g, long M, in
     float* part = (float*)workspace;
     float* sums = part + (size_t)256 * 2 * C;            // [2][C]: sum g, sum g * xhat
     hipLaunchKernelGGL(bn_partial_kernel<2>, dim3((C + 63) / 64, S), dim3(256), 0, st, z, g, (int)M, C, C, C, rows_per, mean, invstd, part);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, (const float*)part, S, 2, C, 1.0, sums,
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)part, S, 2, C, 1.0, sums,
                        (float*)nullptr, 0.f);
     hipLaunchKernelGGL(bn_backward_apply_kernel, dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, st, z, g, mean, invstd, gamma,
                        (const float*)sums, dz, M, C);

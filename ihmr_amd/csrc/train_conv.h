@@ -15,21 +15,25 @@
 //   MODE 0: sum z                      (mean)
 //   MODE 1: sum (z - mean)^2           (biased variance, second pass as torch's batch_norm_cpu_update_stats does)
 //   MODE 2: sum g, sum g * xhat        (backward: g = gradient w.r.t. the BN output, xhat = (z - mean) * invstd)
+//   MODE 3: sum z, sum (z - z0)^2      (mean and variance in ONE pass: z0 = row 0 of the matrix, a sample of the channel,
+//                                        as the pivot: var = E(z - z0)^2 - (mean - z0)^2 loses no more than the factor
+//                                        1 + (mean - z0)^2 / var of fp32 precision, a few units for a pivot within 2 sigma)
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ z, const float* __restrict__ g, int M, int C, int ld,
                                                          int ldg, int rows_per, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, float* __restrict__ part) {
-    constexpr int NQ = MODE == 2 ? 2 : 1;
+    constexpr int NQ = MODE >= 2 ? 2 : 1;
     __shared__ float red[4][NQ][64];
     const int lane = threadIdx.x % 64, wave = threadIdx.x / 64, c = blockIdx.x * 64 + lane, s = blockIdx.y;
     const int r0 = s * rows_per, r1 = min(M, r0 + rows_per);
     float a0 = 0.f, a1 = 0.f;
     if (c < C) {
-        const float mu = MODE >= 1 ? mean[c] : 0.f, is = MODE == 2 ? invstd[c] : 0.f;
+        const float mu = MODE == 3 ? z[c] : (MODE >= 1 ? mean[c] : 0.f), is = MODE == 2 ? invstd[c] : 0.f;
         for (int r = r0 + wave; r < r1; r += 4) {
             const float v = z[(size_t)r * ld + c];
             if (MODE == 0) a0 += v;
             else if (MODE == 1) { const float d = v - mu; a0 += d * d; }
+            else if (MODE == 3) { const float d = v - mu; a0 += v; a1 += d * d; }
             else { const float gv = g[(size_t)r * ldg + c]; a0 += gv; a1 += gv * ((v - mu) * is); }
         }
     }
@@ -43,23 +47,51 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
-// out[q][c] = sum_s part[s][q][c] * scale, accumulated in float64: a workgroup owns 64 (q, c) entries, its four waves take every
-// fourth chunk, the four sums are added in wave order.  With `invstd_out` the result is a variance: invstd = 1 / sqrt(var + eps).
+// out[q][c] = sum_s part[s][q][c] * scale, accumulated in float64: a workgroup owns 16 (q, c) entries; thread (g, e) = (tid / 16,
+// tid % 16) adds the chunks g, g + 16, ... of entry e (16 serial additions for 256 chunks instead of 64), the sixteen group sums
+// are added in group order.  With `invstd_out` the result is a variance: invstd = 1 / sqrt(var + eps).
 __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ part, int S, int NQ, int C, double scale,
                                                         float* __restrict__ out, float* __restrict__ invstd_out, float eps) {
-    __shared__ double red[4][64];
-    const int lane = threadIdx.x % 64, wave = threadIdx.x / 64, i = blockIdx.x * 64 + lane;
+    __shared__ double red[16][17];
+    const int e = threadIdx.x % 16, g = threadIdx.x / 16, i = blockIdx.x * 16 + e;
     const bool ok = i < NQ * C;
     const int q = ok ? i / C : 0, c = ok ? i % C : 0;
     double s = 0.0;
     if (ok)
-        for (int k = wave; k < S; k += 4) s += (double)part[((size_t)k * NQ + q) * C + c];
-    red[wave][lane] = s;
+        for (int k = g; k < S; k += 16) s += (double)part[((size_t)k * NQ + q) * C + c];
+    red[g][e] = s;
     __syncthreads();
-    if (wave == 0 && ok) {
-        const float v = (float)(((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * scale);
+    if (g == 0 && ok) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][e];
+        const float v = (float)(t * scale);
         out[(size_t)q * C + c] = v;
         if (invstd_out) invstd_out[c] = 1.0f / sqrtf(v + eps);
+    }
+}
+
+// mean / biased variance / invstd from the MODE 3 partial sums (same thread layout as bn_finish_kernel): part [S][2][C]
+__global__ __launch_bounds__(256) void bn_finish_stats_kernel(const float* __restrict__ part, const float* __restrict__ z, int S, int C,
+                                                              long M, float* __restrict__ mean, float* __restrict__ var,
+                                                              float* __restrict__ invstd, float eps) {
+    __shared__ double red[2][16][17];
+    const int e = threadIdx.x % 16, g = threadIdx.x / 16, c = blockIdx.x * 16 + e;
+    const bool ok = c < C;
+    double s0 = 0.0, s1 = 0.0;
+    if (ok)
+        for (int k = g; k < S; k += 16) { s0 += (double)part[((size_t)k * 2) * C + c]; s1 += (double)part[((size_t)k * 2 + 1) * C + c]; }
+    red[0][g][e] = s0; red[1][g][e] = s1;
+    __syncthreads();
+    if (g == 0 && ok) {
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { t0 += red[0][k][e]; t1 += red[1][k][e]; }
+        const double mu = t0 / (double)M, d = mu - (double)z[c];
+        const float v = (float)fmax(t1 / (double)M - d * d, 0.0);
+        mean[c] = (float)mu;
+        var[c] = v;
+        invstd[c] = 1.0f / sqrtf(v + eps);
     }
 }
 
