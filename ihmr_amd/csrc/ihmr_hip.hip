@@ -592,7 +592,7 @@ extern "C" int ihmr_bn_train_forward(const float* z, long M, int C, const float*
     const dim3 grid((C + 63) / 64, S);
     // one pass over z: sum z and sum (z - z0)^2 with row 0 as the pivot, then mean / variance / invstd
     hipLaunchKernelGGL(bn_partial_kernel<3>, grid, dim3(256), 0, st, z, (const float*)nullptr, (int)M, C, C, C, rows_per,
-                       (const float*)nullptr, (const float*)nullptr, part);
+                       (const float*)nullptr, (const float*)nullptr, part, (const float*)nullptr);
     hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)part, z, S, C, M, mean, var, invstd, eps);
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, st, z, (const float*)mean,
                        (const float*)invstd, gamma, beta, residual, y, M, C, relu);
@@ -600,18 +600,19 @@ extern "C" int ihmr_bn_train_forward(const float* z, long M, int C, const float*
 }
 
 extern "C" int ihmr_bn_train_backward(const float* z, const float* g, long M, int C, const float* mean, const float* invstd,
-                                      const float* gamma, float* dz, float* dgamma, float* dbeta, void* workspace, void* stream) {
+                                      const float* gamma, const float* relu_y, float* dz, float* dgamma, float* dbeta, void* workspace,
+                                      void* stream) {
     if (!z || !g || !mean || !invstd || !gamma || !dz || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0 || C % 4) return -1;
     hipStream_t st = (hipStream_t)stream;
     int rows_per;
     const int S = bn_chunks(M, &rows_per);
     float* part = (float*)workspace;
     float* sums = part + (size_t)256 * 2 * C;            // [2][C]: sum g, sum g * xhat
-    hipLaunchKernelGGL(bn_partial_kernel<2>, dim3((C + 63) / 64, S), dim3(256), 0, st, z, g, (int)M, C, C, C, rows_per, mean, invstd, part);
+    hipLaunchKernelGGL(bn_partial_kernel<2>, dim3((C + 63) / 64, S), dim3(256), 0, st, z, g, (int)M, C, C, C, rows_per, mean, invstd, part, relu_y);
     hipLaunchKernelGGL(bn_finish_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)part, S, 2, C, 1.0, sums,
                        (float*)nullptr, 0.f);
     hipLaunchKernelGGL(bn_backward_apply_kernel, dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, st, z, g, mean, invstd, gamma,
-                       (const float*)sums, dz, M, C);
+                       (const float*)sums, dz, M, C, relu_y);
     HIP_TRY(hipMemcpyAsync(dbeta, sums, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(dgamma, sums + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
     return (int)hipGetLastError();

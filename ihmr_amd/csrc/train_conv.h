@@ -21,7 +21,8 @@
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ z, const float* __restrict__ g, int M, int C, int ld,
                                                          int ldg, int rows_per, const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, float* __restrict__ part) {
+                                                         const float* __restrict__ invstd, float* __restrict__ part,
+                                                         const float* __restrict__ relu_y = nullptr) {
     constexpr int NQ = MODE >= 2 ? 2 : 1;
     __shared__ float red[4][NQ][64];
     const int lane = threadIdx.x % 64, wave = threadIdx.x / 64, c = blockIdx.x * 64 + lane, s = blockIdx.y;
@@ -34,7 +35,11 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
             if (MODE == 0) a0 += v;
             else if (MODE == 1) { const float d = v - mu; a0 += d * d; }
             else if (MODE == 3) { const float d = v - mu; a0 += v; a1 += d * d; }
-            else { const float gv = g[(size_t)r * ldg + c]; a0 += gv; a1 += gv * ((v - mu) * is); }
+            else {      // relu_y: the unit's output; its ReLU mask is applied to g on the fly (no separate masking pass)
+                float gv = g[(size_t)r * ldg + c];
+                if (relu_y && !(relu_y[(size_t)r * ld + c] > 0.f)) gv = 0.f;
+                a0 += gv; a1 += gv * ((v - mu) * is);
+            }
         }
     }
     red[wave][0][lane] = a0;
@@ -120,14 +125,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ z, const float* __restrict__ g,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                                float* __restrict__ dz, long M, int C) {
+                                                                float* __restrict__ dz, long M, int C,
+                                                                const float* __restrict__ relu_y) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int c4 = C / 4;
     if (idx >= M * c4) return;
     const int c = (int)(idx % c4) * 4;
     const size_t off = (size_t)(idx / c4) * C + c;
     const float inv_m = 1.0f / (float)M;
-    const float4 v = *reinterpret_cast<const float4*>(z + off), gv = *reinterpret_cast<const float4*>(g + off);
+    const float4 v = *reinterpret_cast<const float4*>(z + off);
+    float4 gv = *reinterpret_cast<const float4*>(g + off);
+    if (relu_y) {
+        const float4 yy = *reinterpret_cast<const float4*>(relu_y + off);
+        if (!(yy.x > 0.f)) gv.x = 0.f;
+        if (!(yy.y > 0.f)) gv.y = 0.f;
+        if (!(yy.z > 0.f)) gv.z = 0.f;
+        if (!(yy.w > 0.f)) gv.w = 0.f;
+    }
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
     const float4 s1 = *reinterpret_cast<const float4*>(sums + c), s2 = *reinterpret_cast<const float4*>(sums + C + c);

@@ -147,16 +147,16 @@ def bn_train_forward(z, gamma, beta, residual=None, relu=True):
     return y, (mean, var, invstd)
 
 
-def bn_train_backward(z, g, saved, gamma, dgamma=None, dbeta=None):
-    """g = gradient w.r.t. the BatchNorm output (after the ReLU mask) -> (dz, dgamma, dbeta); dgamma / dbeta optionally into
-    the caller's buffers."""
+def bn_train_backward(z, g, saved, gamma, dgamma=None, dbeta=None, relu_y=None):
+    """g = gradient w.r.t. the unit's output -> (dz, dgamma, dbeta); dgamma / dbeta optionally into the caller's buffers.
+    ``relu_y``: the unit's output when a ReLU follows and ``g`` is not masked yet (the mask is applied on the fly)."""
     M, C = z.shape
     mean, _, invstd = saved
     dz = torch.empty_like(z)
     dgamma = torch.empty(C, device=z.device) if dgamma is None else dgamma
     dbeta = torch.empty(C, device=z.device) if dbeta is None else dbeta
     ws = torch.empty(hip.lib().ihmr_bn_workspace_bytes(C) // 4, device=z.device)
-    hip.check(hip.lib().ihmr_bn_train_backward(hip.ptr(z), hip.ptr(g), M, C, hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(dz),
+    hip.check(hip.lib().ihmr_bn_train_backward(hip.ptr(z), hip.ptr(g), M, C, hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(relu_y), hip.ptr(dz),
                                                hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), hip.stream_ptr()), "ihmr_bn_train_backward")
     return dz, dgamma, dbeta
 
@@ -392,10 +392,8 @@ class EncoderTrainer:
         """g = gradient w.r.t. the block output (modified in place) -> gradient w.r.t. the block input."""
         relu_backward_(g, b["c3"]["save"]["y"])                                  # the ReLU after the residual add
         g3 = self._unit_backward(b["c3"], g)
-        relu_backward_(g3, b["c2"]["save"]["y"])
-        g2 = self._unit_backward(b["c2"], g3)
-        relu_backward_(g2, b["c1"]["save"]["y"])
-        g1 = self._unit_backward(b["c1"], g2)
+        g2 = self._unit_backward(b["c2"], g3, masked=False)
+        g1 = self._unit_backward(b["c1"], g2, masked=False)
         return g1 + (self._unit_backward(b["ds"], g) if b["ds"] is not None else g)
 
     def forward(self, img):
@@ -433,11 +431,12 @@ class EncoderTrainer:
         return self.pred_params, self.hand_type
 
     # ---- backward
-    def _unit_backward(self, u, g, need_dx=True):
-        """g = gradient w.r.t. the unit's output (already masked by its ReLU) -> gradient w.r.t. its input."""
+    def _unit_backward(self, u, g, need_dx=True, masked=True):
+        """g = gradient w.r.t. the unit's output -> gradient w.r.t. its input.  masked=False: the unit's ReLU mask has not been
+        applied to g yet; the BatchNorm backward kernels apply it on the fly."""
         s = u["save"]
         dz, _, _ = bn_train_backward(s["z"], g, s["saved"], self.flat.p[u["name"] + ".gamma"], self.flat.g[u["name"] + ".gamma"],
-                                     self.flat.g[u["name"] + ".beta"])
+                                     self.flat.g[u["name"] + ".beta"], relu_y=None if masked or not s["relu"] else s["y"])
         conv_wgrad(s["x"], dz, s["N"], s["H"], s["W"], u["cin"], u["cout"], u["k"], u["stride"], u["pad"], out=self.flat.g[u["name"] + ".w"])
         if not need_dx:
             return None
@@ -470,8 +469,7 @@ class EncoderTrainer:
             g = self._block_backward(b, g)
             self.reducer.ready(1 + k)
         gp = maxpool_backward(self._pool["x"], g, B, self._pool["H"], self._pool["W"], 64)
-        relu_backward_(gp, self.stem["save"]["y"])
-        self._unit_backward(self.stem, gp, need_dx=False)
+        self._unit_backward(self.stem, gp, need_dx=False, masked=False)
         self.reducer.ready(1 + len(self.blocks))
 
     # ---- optimizer (torch.optim.Adam semantics; DistributedDataParallel = one all-reduce of the flat gradient)

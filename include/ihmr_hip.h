@@ -233,7 +233,8 @@ int ihmr_adam_step(float* params, const float* grads, float* exp_avg, float* exp
  *   ihmr_bn_train_forward:  nn.BatchNorm2d in training mode on z [M = N*H*W][C]: batch mean / biased variance per
  *       channel (two passes), y = [relu](gamma * (z - mean) * invstd + beta [+ residual]); mean, var, invstd (C) are
  *       outputs (the caller keeps them for the backward pass and updates the running statistics).
- *   ihmr_bn_train_backward: g = gradient w.r.t. the BatchNorm output (after the ReLU mask) -> dz, dgamma, dbeta.
+ *   ihmr_bn_train_backward: g = gradient w.r.t. the unit's output -> dz, dgamma, dbeta; relu_y = the unit's output y when a
+ *       ReLU follows the BatchNorm and g has NOT been masked yet (the mask y > 0 is applied on the fly), NULL otherwise.
  *   ihmr_conv_wgrad: dW [kh*kw*Cin][ldw] (the K-major layout ihmr_conv_igemm reads) = A(x)^T . dY as an implicit GEMM on
  *       the fp32 matrix cores (Cin % 4 == 0; the 3-channel image is padded to 4); workspace holds the pixel-range partial
  *       sums ([splits][K][Cout], at least K*Cout*4 bytes).
@@ -246,7 +247,7 @@ size_t ihmr_bn_workspace_bytes(int C);
 int ihmr_bn_train_forward(const float* z, long M, int C, const float* gamma, const float* beta, const float* residual, int relu,
                           float eps, float* y, float* mean, float* var, float* invstd, void* workspace, void* stream);
 int ihmr_bn_train_backward(const float* z, const float* g, long M, int C, const float* mean, const float* invstd,
-                           const float* gamma, float* dz, float* dgamma, float* dbeta, void* workspace, void* stream);
+                           const float* gamma, const float* relu_y, float* dz, float* dgamma, float* dbeta, void* workspace, void* stream);
 int ihmr_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh,
                     int kw, int stride, int pad, int ldx, int lddy, int ldw, void* workspace, size_t workspace_bytes, void* stream);
 /* the flipped, transposed filter above from the forward filter w [kh*kw*Cin][ldw] -> out [kh*kw*Cout][ldo] (rows beyond and

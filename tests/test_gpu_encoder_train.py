@@ -47,9 +47,11 @@ def test_batchnorm_train_forward_backward(N, C, H, W, res, relu):
     _close("bn batch mean", saved[0], z.detach().mean(dim=(0, 2, 3)), 2e-6)
     _close("bn batch var (biased)", saved[1], z.detach().var(dim=(0, 2, 3), unbiased=False), 5e-6)
     gm = _nhwc(dy)
-    if relu:
-        T.relu_backward_(gm, y)
-    dz, dgamma, dbeta = T.bn_train_backward(_nhwc(z.detach()), gm, saved, gamma.detach().cuda())
+    if relu and N % 2:
+        T.relu_backward_(gm, y)                      # explicit masking pass ...
+        dz, dgamma, dbeta = T.bn_train_backward(_nhwc(z.detach()), gm, saved, gamma.detach().cuda())
+    else:                                            # ... or the mask applied inside the backward kernels
+        dz, dgamma, dbeta = T.bn_train_backward(_nhwc(z.detach()), gm, saved, gamma.detach().cuda(), relu_y=y if relu else None)
     torch.cuda.synchronize()
     _close("bn dz", _nchw(dz, N, H, W), z.grad, 2e-5)
     _close("bn dgamma", dgamma, gamma.grad, 2e-5)
@@ -254,8 +256,7 @@ def test_stem_and_maxpool_match_torch():
     x[..., :3].copy_(img.cuda().permute(0, 2, 3, 1))
     y, Hs, Ws = tr._unit_forward(tr.stem, x.reshape(N * H * H, 4), N, H, H)
     gp = T.maxpool_backward(y, _nhwc(dy), N, Hs, Ws, 64)
-    T.relu_backward_(gp, y)
-    tr._unit_backward(tr.stem, gp, need_dx=False)
+    tr._unit_backward(tr.stem, gp, need_dx=False, masked=False)
     torch.cuda.synchronize()
     grads = tr.named_gradients()
     _close("stem conv1.weight grad", grads["main_encoder.conv1.weight"], me.conv1.weight.grad, 5e-5)
