@@ -582,8 +582,8 @@ static int bn_chunks(long M, int* rows_per) {
 extern "C" size_t ihmr_bn_workspace_bytes(int C) { return (size_t)256 * 2 * C * sizeof(float) + (size_t)2 * C * sizeof(float); }
 
 extern "C" int ihmr_bn_train_forward(const float* z, long M, int C, const float* gamma, const float* beta, const float* residual,
-                                     int relu, float eps, float* y, float* mean, float* var, float* invstd, void* workspace,
-                                     void* stream) {
+                                     int relu, float eps, float* y, float* mean, float* var, float* invstd, float* running_mean,
+                                     float* running_var, float momentum, void* workspace, void* stream) {
     if (!z || !gamma || !beta || !y || !mean || !var || !invstd || !workspace || M <= 0 || C <= 0 || C % 4) return -1;
     hipStream_t st = (hipStream_t)stream;
     int rows_per;
@@ -593,7 +593,8 @@ extern "C" int ihmr_bn_train_forward(const float* z, long M, int C, const float*
     // one pass over z: sum z and sum (z - z0)^2 with row 0 as the pivot, then mean / variance / invstd
     hipLaunchKernelGGL(bn_partial_kernel<3>, grid, dim3(256), 0, st, z, (const float*)nullptr, (int)M, C, C, C, rows_per,
                        (const float*)nullptr, (const float*)nullptr, part, (const float*)nullptr);
-    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)part, z, S, C, M, mean, var, invstd, eps);
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)part, z, S, C, M, mean, var, invstd, eps, running_mean,
+                       running_var, momentum);
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, st, z, (const float*)mean,
                        (const float*)invstd, gamma, beta, residual, y, M, C, relu);
     return (int)hipGetLastError();

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict_
 // mean / biased variance / invstd from the MODE 3 partial sums (same thread layout as bn_finish_kernel): part [S][2][C]
 __global__ __launch_bounds__(256) void bn_finish_stats_kernel(const float* __restrict__ part, const float* __restrict__ z, int S, int C,
                                                               long M, float* __restrict__ mean, float* __restrict__ var,
-                                                              float* __restrict__ invstd, float eps) {
+                                                              float* __restrict__ invstd, float eps, float* __restrict__ run_mean,
+                                                              float* __restrict__ run_var, float momentum) {
     __shared__ double red[2][16][17];
     const int e = threadIdx.x % 16, g = threadIdx.x / 16, c = blockIdx.x * 16 + e;
     const bool ok = c < C;
@@ -97,6 +98,10 @@ __global__ __launch_bounds__(256) void bn_finish_stats_kernel(const float* __res
         mean[c] = (float)mu;
         var[c] = v;
         invstd[c] = 1.0f / sqrtf(v + eps);
+        if (run_mean) {     // nn.BatchNorm2d's running statistics: (1 - momentum) * running + momentum * batch (unbiased variance)
+            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mu;
+            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (v * (float)M / (float)(M > 1 ? M - 1 : 1));
+        }
     }
 }
 

@@ -136,14 +136,17 @@ def conv_wgrad(x, dy, N, H, W, Cin, Cout, k, stride, pad, out=None):
     return out
 
 
-def bn_train_forward(z, gamma, beta, residual=None, relu=True):
-    """nn.BatchNorm2d (training) [+ residual] [+ ReLU] on z [M, C] -> (y, saved = (mean, var, invstd))."""
+def bn_train_forward(z, gamma, beta, residual=None, relu=True, running=None, momentum=0.1):
+    """nn.BatchNorm2d (training) [+ residual] [+ ReLU] on z [M, C] -> (y, saved = (mean, var, invstd)); ``running`` =
+    (running_mean, running_var) updated in place."""
     M, C = z.shape
     y = torch.empty_like(z)
     mean, var, invstd = (torch.empty(C, device=z.device) for _ in range(3))
     ws = torch.empty(hip.lib().ihmr_bn_workspace_bytes(C) // 4, device=z.device)
+    rm, rv = running if running is not None else (None, None)
     hip.check(hip.lib().ihmr_bn_train_forward(hip.ptr(z), M, C, hip.ptr(gamma), hip.ptr(beta), hip.ptr(residual), int(relu), BN_EPS, hip.ptr(y),
-                                              hip.ptr(mean), hip.ptr(var), hip.ptr(invstd), hip.ptr(ws), hip.stream_ptr()), "ihmr_bn_train_forward")
+                                              hip.ptr(mean), hip.ptr(var), hip.ptr(invstd), hip.ptr(rm), hip.ptr(rv), momentum, hip.ptr(ws),
+                                              hip.stream_ptr()), "ihmr_bn_train_forward")
     return y, (mean, var, invstd)
 
 
@@ -370,11 +373,8 @@ class EncoderTrainer:
     def _unit_forward(self, u, x, N, H, W, residual=None, relu=True):
         w = self.flat.p[u["name"] + ".w"]
         z, Ho, Wo = conv_forward(x, w, N, H, W, u["cin"], u["cout"], u["k"], u["stride"], u["pad"])
-        y, saved = bn_train_forward(z, self.flat.p[u["name"] + ".gamma"], self.flat.p[u["name"] + ".beta"], residual, relu)
-        M = z.shape[0]
-        with torch.no_grad():                              # nn.BatchNorm2d's running statistics (momentum 0.1, unbiased variance)
-            u["run_mean"].mul_(0.9).add_(saved[0], alpha=0.1)
-            u["run_var"].mul_(0.9).add_(saved[1], alpha=0.1 * M / max(M - 1, 1))
+        y, saved = bn_train_forward(z, self.flat.p[u["name"] + ".gamma"], self.flat.p[u["name"] + ".beta"], residual, relu,
+                                    running=(u["run_mean"], u["run_var"]))      # nn.BatchNorm2d's running statistics, momentum 0.1
         u["tracked"] += 1
         u["save"] = dict(x=x, z=z, y=y, saved=saved, N=N, H=H, W=W, relu=relu)
         return y, Ho, Wo

@@ -120,7 +120,7 @@ def lib():
         L.ihmr_adam_step.argtypes = [vp, vp, vp, vp, C.c_size_t, f, f, f, f, f, i, vp]
         L.ihmr_bn_workspace_bytes.argtypes = [i]
         L.ihmr_bn_workspace_bytes.restype = C.c_size_t
-        L.ihmr_bn_train_forward.argtypes = [vp, C.c_long, i, vp, vp, vp, i, f, vp, vp, vp, vp, vp, vp]
+        L.ihmr_bn_train_forward.argtypes = [vp, C.c_long, i, vp, vp, vp, i, f, vp, vp, vp, vp, vp, vp, f, vp, vp]
         L.ihmr_bn_train_backward.argtypes = [vp, vp, C.c_long, i, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.ihmr_conv_wgrad.argtypes = [vp, vp, vp] + [i] * 14 + [vp, C.c_size_t, vp]
         L.ihmr_dilate2.argtypes = [vp, vp, i, i, i, i, vp]

@@ -232,7 +232,8 @@ int ihmr_adam_step(float* params, const float* grads, float* exp_avg, float* exp
  * models/resnet.py:58-156), NHWC activations as in ihmr_conv_igemm, every reduction in a fixed order.
  *   ihmr_bn_train_forward:  nn.BatchNorm2d in training mode on z [M = N*H*W][C]: batch mean / biased variance per
  *       channel (two passes), y = [relu](gamma * (z - mean) * invstd + beta [+ residual]); mean, var, invstd (C) are
- *       outputs (the caller keeps them for the backward pass and updates the running statistics).
+ *       outputs (the caller keeps them for the backward pass); running_mean / running_var (C), optional, are updated in place
+ *       as nn.BatchNorm2d does: (1 - momentum) * running + momentum * batch, with the unbiased variance.
  *   ihmr_bn_train_backward: g = gradient w.r.t. the unit's output -> dz, dgamma, dbeta; relu_y = the unit's output y when a
  *       ReLU follows the BatchNorm and g has NOT been masked yet (the mask y > 0 is applied on the fly), NULL otherwise.
  *   ihmr_conv_wgrad: dW [kh*kw*Cin][ldw] (the K-major layout ihmr_conv_igemm reads) = A(x)^T . dY as an implicit GEMM on
@@ -245,7 +246,8 @@ int ihmr_adam_step(float* params, const float* grads, float* exp_avg, float* exp
  *       window, as torch) and AvgPool2d(7) + ReLU (resnet.py:107,111,149-151). */
 size_t ihmr_bn_workspace_bytes(int C);
 int ihmr_bn_train_forward(const float* z, long M, int C, const float* gamma, const float* beta, const float* residual, int relu,
-                          float eps, float* y, float* mean, float* var, float* invstd, void* workspace, void* stream);
+                          float eps, float* y, float* mean, float* var, float* invstd, float* running_mean, float* running_var,
+                          float momentum, void* workspace, void* stream);
 int ihmr_bn_train_backward(const float* z, const float* g, long M, int C, const float* mean, const float* invstd,
                            const float* gamma, const float* relu_y, float* dz, float* dgamma, float* dbeta, void* workspace, void* stream);
 int ihmr_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh,
