@@ -642,7 +642,10 @@ extern "C" int ihmr_conv_wgrad(const float* x, const float* dy, float* dw, int N
     else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(128), 0, st, a);
     // fixed-order sum of the pixel-range partials into dw [K][ldw]
     ConvArgs r{nullptr, nullptr, nullptr, nullptr, dw, K, 1, 1, 0, 1, 1, Cout, 1, 1, 1, 0, 0, 0, ldw, 0, 0, (float*)workspace, (int)msplit, 0};
-    if (Cout % 4 == 0) hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)(((long)K * (Cout / 4) + 255) / 256)), dim3(256), 0, st, r);
+    if (Cout % 4 == 0 && ldw % 4 == 0 && msplit >= 32)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((long)K * (Cout / 4) + 15) / 16)), dim3(256), 0, st, (const float*)workspace, dw, K,
+                           Cout, ldw, (int)msplit);
+    else if (Cout % 4 == 0) hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)(((long)K * (Cout / 4) + 255) / 256)), dim3(256), 0, st, r);
     else hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3((unsigned)(((long)K * Cout + 255) / 256)), dim3(256), 0, st, r);
     return (int)hipGetLastError();
 }

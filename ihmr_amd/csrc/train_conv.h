@@ -362,3 +362,28 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_wgrad_kernel(
             if (k < K) part[(size_t)k * a.Cout + n] = acc[mi][r];
         }
 }
+
+// dw[k][n] = sum_z partial[z][k][n] for many pixel-range partials: thread (g, e) = (tid / 16, tid % 16) adds the partials g, g + 16, ...
+// of float4 e of its workgroup's 16 (16 serial loads for 256 partials instead of 256), the sixteen group sums are added in group order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int K, int Cout,
+                                                           int ldw, int nsplit) {
+    __shared__ float4 red[16][17];
+    const int e = threadIdx.x % 16, g = threadIdx.x / 16, cv = Cout / 4;
+    const long i = (long)blockIdx.x * 16 + e;
+    const bool ok = i < (long)K * cv;
+    const int k = ok ? (int)(i / cv) : 0, n = ok ? (int)(i % cv) * 4 : 0;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok)
+        for (int z = g; z < nsplit; z += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + ((size_t)z * K + k) * Cout + n);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[g][e] = s;
+    __syncthreads();
+    if (g == 0 && ok) {
+        float4 t = red[0][e];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) { t.x += red[q][e].x; t.y += red[q][e].y; t.z += red[q][e].z; t.w += red[q][e].w; }
+        *reinterpret_cast<float4*>(dw + (size_t)k * ldw + n) = t;
+    }
+}
