@@ -608,14 +608,12 @@ extern "C" int ihmr_bn_train_backward(const float* z, const float* g, long M, in
     int rows_per;
     const int S = bn_chunks(M, &rows_per);
     float* part = (float*)workspace;
-    float* sums = part + (size_t)256 * 2 * C;            // [2][C]: sum g, sum g * xhat
+    // sum g -> dbeta, sum g * xhat -> dgamma (written by the finish kernel itself, read back by the apply kernel)
     hipLaunchKernelGGL(bn_partial_kernel<2>, dim3((C + 63) / 64, S), dim3(256), 0, st, z, g, (int)M, C, C, C, rows_per, mean, invstd, part, relu_y);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)part, S, 2, C, 1.0, sums,
-                       (float*)nullptr, 0.f);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)part, S, 2, C, 1.0, dbeta,
+                       (float*)nullptr, 0.f, dgamma);
     hipLaunchKernelGGL(bn_backward_apply_kernel, dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, st, z, g, mean, invstd, gamma,
-                       (const float*)sums, dz, M, C, relu_y);
-    HIP_TRY(hipMemcpyAsync(dbeta, sums, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dgamma, sums + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
+                       (const float*)dbeta, (const float*)dgamma, dz, M, C, relu_y);
     return (int)hipGetLastError();
 }
 

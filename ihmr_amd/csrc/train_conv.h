@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 // tid % 16) adds the chunks g, g + 16, ... of entry e (16 serial additions for 256 chunks instead of 64), the sixteen group sums
 // are added in group order.  With `invstd_out` the result is a variance: invstd = 1 / sqrt(var + eps).
 __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ part, int S, int NQ, int C, double scale,
-                                                        float* __restrict__ out, float* __restrict__ invstd_out, float eps) {
+                                                        float* __restrict__ out, float* __restrict__ invstd_out, float eps,
+                                                        float* __restrict__ out1 = nullptr) {
     __shared__ double red[16][17];
     const int e = threadIdx.x % 16, g = threadIdx.x / 16, i = blockIdx.x * 16 + e;
     const bool ok = i < NQ * C;
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][e];
         const float v = (float)(t * scale);
-        out[(size_t)q * C + c] = v;
+        if (q == 1 && out1) out1[c] = v;                 // second quantity to its own buffer (dgamma beside dbeta)
+        else out[(size_t)q * C + c] = v;
         if (invstd_out) invstd_out[c] = 1.0f / sqrtf(v + eps);
     }
 }
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // dz = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M)   (torch's batch_norm_backward in training mode)
 __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ z, const float* __restrict__ g,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                                float* __restrict__ dz, long M, int C,
+                                                                const float* __restrict__ gamma, const float* __restrict__ sum_g,
+                                                                const float* __restrict__ sum_gx, float* __restrict__ dz, long M, int C,
                                                                 const float* __restrict__ relu_y) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int c4 = C / 4;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __r
     }
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-    const float4 s1 = *reinterpret_cast<const float4*>(sums + c), s2 = *reinterpret_cast<const float4*>(sums + C + c);
+    const float4 s1 = *reinterpret_cast<const float4*>(sum_g + c), s2 = *reinterpret_cast<const float4*>(sum_gx + c);
     float4 o;
     o.x = ga.x * is.x * (gv.x - s1.x * inv_m - (v.x - mu.x) * is.x * (s2.x * inv_m));
     o.y = ga.y * is.y * (gv.y - s1.y * inv_m - (v.y - mu.y) * is.y * (s2.y * inv_m));
