@@ -143,14 +143,38 @@ class InterHandModel(BaselineTrainMixin):
         hv = torch.stack([self.pred_right_hand_verts, self.pred_left_hand_verts], dim=1).contiguous()
         _, _, self.collision_loss_origin_scale = self.sdf_loss(hv, return_per_vert_loss=True, return_origin_scale_loss=True)
 
+    def _export_sources(self):
+        return OrderedDict(
+            pred_cam_params=self.pred_cam_params, pred_hand_type=self.pred_hand_type,
+            pred_pose_params=self.pred_pose_params, pred_shape_params=self.pred_shape_params,
+            pred_hand_trans=self.pred_hand_trans, gt_right_hand_verts=self.gt_right_hand_verts,
+            gt_left_hand_verts=self.gt_left_hand_verts, pred_right_hand_verts=self.pred_right_hand_verts,
+            pred_left_hand_verts=self.pred_left_hand_verts, mano_params_weight=self.mano_params_weight,
+            pred_joints_3d=self.pred_joints_3d, gt_joints_3d=self.joints_3d,
+            collision_loss_origin_scale=self.collision_loss_origin_scale, do_flip=self.do_flip)
+
     # baseline_model.py:358-375
     def get_pred_result(self):
-        n = lambda t: t.detach().cpu().numpy()
-        return OrderedDict(
-            pred_cam_params=n(self.pred_cam_params), pred_hand_type=n(self.pred_hand_type),
-            pred_pose_params=n(self.pred_pose_params), pred_shape_params=n(self.pred_shape_params),
-            pred_hand_trans=n(self.pred_hand_trans), gt_right_hand_verts=n(self.gt_right_hand_verts),
-            gt_left_hand_verts=n(self.gt_left_hand_verts), pred_right_hand_verts=n(self.pred_right_hand_verts),
-            pred_left_hand_verts=n(self.pred_left_hand_verts), mano_params_weight=n(self.mano_params_weight),
-            pred_joints_3d=n(self.pred_joints_3d), gt_joints_3d=n(self.joints_3d),
-            collision_loss_origin_scale=n(self.collision_loss_origin_scale), do_flip=n(self.do_flip))
+        return OrderedDict((k, v.detach().cpu().numpy()) for k, v in self._export_sources().items())
+
+    def get_pred_result_async(self):
+        """``get_pred_result()`` without stalling the host (as :meth:`OptimizeModel.get_pred_result_async`): the copies are
+        queued behind ``test()`` on the current stream into pinned buffers (two alternating sets); ``wait()`` on the returned
+        handle blocks until they have landed.  The arrays are valid until the next-but-one export."""
+        if not hasattr(self, "_pinned"):
+            self._pinned, self._pin_slot = [None, None], 0
+        self._pin_slot ^= 1
+        src = OrderedDict((k, v.detach().contiguous()) for k, v in self._export_sources().items())
+        if self._pinned[self._pin_slot] is None:
+            self._pinned[self._pin_slot] = OrderedDict((k, torch.empty(v.shape, dtype=v.dtype, pin_memory=True)) for k, v in src.items())
+        dst = self._pinned[self._pin_slot]
+        for k, v in src.items():
+            dst[k].copy_(v, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+
+        class _Pending:
+            def wait(self_inner):
+                ev.synchronize()
+                return OrderedDict((k, v.numpy()) for k, v in dst.items())
+        return _Pending()
