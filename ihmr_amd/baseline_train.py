@@ -35,6 +35,16 @@ from .encoder_train import EncoderTrainer
 from .optimize_model import OptimizeModel
 
 
+def hand_type_bce(s, t, valid):
+    """loss_utils.py:40-43 per element: F.binary_cross_entropy(s, t, 'none') * valid (both logarithms clamped at -100, as torch)."""
+    return -(t * torch.log(s).clamp_min(-100.0) + (1.0 - t) * torch.log(1.0 - s).clamp_min(-100.0)) * valid.reshape(-1, 1)
+
+
+def hand_type_bce_grad(s, t, valid):
+    """d mean(hand_type_bce) / d s."""
+    return (s - t) / (s * (1.0 - s)).clamp_min(1e-12) * valid.reshape(-1, 1) / float(s.numel())
+
+
 class BaselineTrainMixin:
     """Training half of ``InterHandModel``; mixed into :class:`ihmr_amd.baseline_model.InterHandModel`."""
 
@@ -85,17 +95,17 @@ class BaselineTrainMixin:
                       "ihmr_mlp_train_grad")
         finally:
             io.init_joints_2d, io.init_joints_3d = keep
-        # _hand_type_loss (loss_utils.py:40-43): mean(BCE(pred, gt) * valid) over (B, 2); gradient w.r.t. the sigmoid output
-        s, t = self.pred_hand_type, self.hand_type_array
-        self._d_hand = -(t / s - (1.0 - t) / (1.0 - s)) * self.hand_type_valid.reshape(B, 1) / (2.0 * B)
+        # _hand_type_loss (loss_utils.py:40-43): mean(BCE(pred, gt) * valid) over (B, 2); gradient w.r.t. the sigmoid output as
+        # torch's binary_cross_entropy backward forms it, (s - t) / max(s (1 - s), 1e-12): finite when the fp32 sigmoid saturates
+        # (s == 0 or 1 exactly), where the plain quotient -(t / s - (1 - t) / (1 - s)) is 0/0
+        self._d_hand = hand_type_bce_grad(self.pred_hand_type, self.hand_type_array, self.hand_type_valid)
         self.trainer.backward(self._grad122, self._d_hand)
         self.trainer.optimizer_step(self.world_size)
 
     # baseline_model.py:378-400 (evaluated on demand)
     def get_current_errors(self):
         lb, t5, w, B = self._core.buf["loss_batch"], self._terms5.sum(dim=0), self.loss_weights, self.batch_size
-        s, t = self.pred_hand_type, self.hand_type_array
-        bce = -(t * torch.log(s) + (1.0 - t) * torch.log(1.0 - s)) * self.hand_type_valid.reshape(B, 1)
+        bce = hand_type_bce(self.pred_hand_type, self.hand_type_array, self.hand_type_valid)
         d = OrderedDict(hand_type_loss=float(bce.mean()), joints_2d_loss=float(lb[0].mean()), joints_3d_loss=float(lb[1].mean()),
                         mano_pose_loss=float(t5[0]), mano_shape_loss=float(t5[1]), hand_trans_loss=float(t5[2]), shape_reg_loss=float(t5[3]))
         if w["collision"]:

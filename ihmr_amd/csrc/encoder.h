@@ -32,14 +32,8 @@ struct ConvArgs {
     int act;                // 0 none, 1 relu, 2 sigmoid
     float* partial;         // split-K: [ksplit][M][Cout] raw partial sums (bias / residual / activation applied by conv_splitk_reduce_kernel)
     int ksplit;             // gridDim.z; 1 = no split
-    int exp_mask;           // timing experiments (IHMR_CONV_EXPERIMENT builds only)
 };
 
-#ifdef IHMR_CONV_EXPERIMENT
-#define CONV_EXP(bit) ((a.exp_mask >> (bit)) & 1)
-#else
-#define CONV_EXP(bit) 0
-#endif
 // FAST: Cin % 16 == 0 (every layer but the stem), compiled without the generic gather so that its per-loader state does not
 // cost registers or a branch per K step;
 // and the 128 x 128 tile is held to 80 registers (three resident workgroups per CU instead of two; measured: 4 waves per SIMD
@@ -165,17 +159,15 @@ void conv_igemm_kernel(ConvArgs a) {
     for (int kc = kc0; kc < kc1; ++kc) {
         const int cur = (kc - kc0) & 1;
         const int nk = kc1;
-        if (kc + 1 < nk && !CONV_EXP(0)) load_tile(kc + 1);   // in flight during the MFMAs below
+        if (kc + 1 < nk) load_tile(kc + 1);   // in flight during the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < CONV_BK; kk += 2) {
-            float a0, a1, bf;
-            if (CONV_EXP(1)) { a0 = (float)kk; a1 = (float)(kk + 1); bf = (float)lane; }
-            else { a0 = As[cur][kk + kl][wm * 64 + l31]; a1 = As[cur][kk + kl][wm * 64 + 32 + l31]; bf = Bs[cur][kk + kl][wn * 32 + l31]; }
+            const float a0 = As[cur][kk + kl][wm * 64 + l31], a1 = As[cur][kk + kl][wm * 64 + 32 + l31], bf = Bs[cur][kk + kl][wn * 32 + l31];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf, acc[1], 0, 0, 0);
         }
-        if (kc + 1 < nk && !CONV_EXP(2)) store_tile(cur ^ 1);  // the other buffer: its readers finished before the previous barrier
-        if (!CONV_EXP(3)) __syncthreads();
+        if (kc + 1 < nk) store_tile(cur ^ 1);  // the other buffer: its readers finished before the previous barrier
+        __syncthreads();
     }
 
     // ---- epilogue: bias (+ residual) (+ activation); C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -192,14 +184,6 @@ void conv_igemm_kernel(ConvArgs a) {
             }
         return;
     }
-#ifdef IHMR_CONV_EXPERIMENT
-    if (CONV_EXP(4)) {   // ablation: no epilogue (one store keeps the accumulators alive)
-        float sacc = 0.f;
-        for (int mi = 0; mi < 2; ++mi) for (int r = 0; r < 16; ++r) sacc += acc[mi][r];
-        if (sacc == 12345.678f) a.y[0] = sacc;
-        return;
-    }
-#endif
     const float bv = a.bias ? a.bias[n] : 0.f;
     // residual rows first, the loads of one 32-row half in flight together (y may alias nothing here, but the compiler cannot
     // know: interleaved with the stores it would issue them one by one); one half at a time keeps 16 instead of 32 registers live

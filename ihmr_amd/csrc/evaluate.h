@@ -88,3 +88,52 @@ __global__ __launch_bounds__(64) void eval_metrics_kernel(const float* __restric
         o[5] = inter ? (double)cm * 1000.0 : 0.0;
     }
 }
+
+// MPVPE partial sums (BASELINE.json's metric list; the reference exports the meshes -- baseline_model.py:365-368,
+// mlp_model.py:708-711 -- and has no vertex metric of its own).  Same convention as the MPJPE above: per hand,
+// root-relative, L2 per point, / scale; the root of a mesh is its wrist regressed with row 0 of the MANO joint
+// regressor (root_w (2,778): right, left).  A hand counts when mano_params_weight[b][h] > 0 (a GT mesh exists).
+// grid = (B, 2), block = 256.  out (B,2,2) doubles: per hand [sum of the per-vertex errors, number of them].
+__global__ __launch_bounds__(256) void eval_mpvpe_kernel(const float* __restrict__ pred_r, const float* __restrict__ pred_l,
+                                                         const float* __restrict__ gt_r, const float* __restrict__ gt_l,
+                                                         const float* __restrict__ root_w, const float* __restrict__ params_weight,
+                                                         const float* __restrict__ scale, int B, double* __restrict__ hand_out) {
+    __shared__ float part[4][8];
+    __shared__ float root[6];
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
+    double* o = hand_out + ((size_t)b * 2 + h) * 2;
+    if (!(params_weight[b * 2 + h] > 0.f)) {
+        if (tid == 0) { o[0] = 0.0; o[1] = 0.0; }
+        return;
+    }
+    const float* P = (h ? pred_l : pred_r) + (size_t)b * NV3;
+    const float* G = (h ? gt_l : gt_r) + (size_t)b * NV3;
+    const float* W = root_w + (size_t)h * NV;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int v = tid; v < NV; v += 256) {
+        const float w = W[v];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { acc[k] += w * P[3 * v + k]; acc[3 + k] += w * G[3 * v + k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float s = wave_reduce_sum(acc[k]);
+        if (lane == 0) part[wave][k] = s;
+    }
+    __syncthreads();
+    if (tid < 6) root[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    __syncthreads();
+    const float sc = scale ? scale[b] : 1.0f;
+    float err = 0.f;
+    for (int v = tid; v < NV; v += 256) {
+        const float dx = (P[3 * v] - root[0]) - (G[3 * v] - root[3]);
+        const float dy = (P[3 * v + 1] - root[1]) - (G[3 * v + 1] - root[4]);
+        const float dz = (P[3 * v + 2] - root[2]) - (G[3 * v + 2] - root[5]);
+        err += sqrtf(dx * dx + dy * dy + dz * dz) / sc;
+    }
+    const float s = wave_reduce_sum(err);
+    __syncthreads();
+    if (lane == 0) part[wave][0] = s;
+    __syncthreads();
+    if (tid == 0) { o[0] = ((double)part[0][0] + (double)part[1][0]) + ((double)part[2][0] + (double)part[3][0]); o[1] = (double)NV; }
+}

@@ -25,15 +25,6 @@
 // dot product in the fixed order of the SDF arithmetic spec: fma(z, fma(y, x*x'))
 #define DOT3(ax, ay, az, bx, by, bz) __builtin_fmaf((az), (bz), __builtin_fmaf((ay), (by), (ax) * (bx)))
 
-// optional in-kernel phase stamps (debug builds only: -DIHMR_TIMING); thread 0 of workgroup (0,0) writes
-// the shader clock at named points, read back through ihmr_debug_read
-#ifdef IHMR_TIMING
-__device__ long long g_dbg[256];
-__device__ long long g_blk[2][1024];   // per-workgroup start / end stamps of the kernel under study (wall clock)
-#define TSTAMP(slot) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_dbg[slot] = clock64(); } while (0)
-#else
-#define TSTAMP(slot) do { } while (0)
-#endif
 
 struct ihmr_mano {
     // device pointers (fp32 unless stated)

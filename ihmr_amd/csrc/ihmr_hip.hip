@@ -291,8 +291,9 @@ extern "C" int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* fa
 extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
 
 // `prev` = the Adam step of the previous iteration (group < 0: none), applied at the head of the skeleton kernel
+static const ParamStep kNoStep{0, 0.f, 0.f, 1.f, -1, 0, 0};
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
-                       const ihmr_opt_weights& w, const AdamStep& prev, hipStream_t st) {
+                       const ihmr_opt_weights& w, const ParamStep& prev, hipStream_t st, int need_cam = 0) {
     hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B).inside_count);
     hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m, (const float*)wk.lbs.skel,
                        2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
@@ -301,7 +302,7 @@ static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
     int rc = sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, B, ws, 0.f, nullptr, nullptr, nullptr, nullptr, false, st);
     if (rc) return rc;
     // collision sampling (loss_batch[2], masked by hand type; gradient -> g_verts) and the joint losses in one launch
-    hipLaunchKernelGGL(opt_sample_loss_kernel, dim3(B), dim3(SDF_SAMPLE_THREADS), 0, st, *io, wk, B, w, vl, ws);
+    hipLaunchKernelGGL(opt_sample_loss_kernel, dim3(B), dim3(SDF_SAMPLE_THREADS), 0, st, *io, wk, B, w, vl, ws, need_cam);
     return (int)hipGetLastError();
 }
 
@@ -310,33 +311,38 @@ extern "C" int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_le
     if (!m || !io || !w || B <= 0) return -1;
     hipStream_t st = (hipStream_t)stream;
     OptWork wk = opt_carve(io->workspace, B);
-    int rc = opt_forward(m, m_left, io, wk, B, *w, AdamStep{-1, 0.f, 0.f, 1.f, -1, 0}, st);
+    int rc = opt_forward(m, m_left, io, wk, B, *w, kNoStep, st);
     if (rc) return rc;
     return (int)hipGetLastError();
 }
 
-extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, int group,
-                                  const ihmr_opt_weights* w, float lr, int n_iters, int save_freq, float filter_factor_j3d, float filter_factor_coll,
-                                  int select_on_collision, void* stream) {
-    if (!m || !io || !w || B <= 0 || group < 0 || group > 3 || n_iters <= 0 || save_freq <= 0) return -1;
+extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                                  const ihmr_opt_weights* w, const ihmr_opt_stage* sg, void* stream) {
+    if (!m || !io || !w || !sg || B <= 0 || sg->n_iters <= 0 || sg->save_freq <= 0) return -1;
+    if (sg->param_mask <= 0 || sg->param_mask > 255 || sg->select_loss < 0 || sg->select_loss > 2) return -1;
+    if (sg->optimizer != IHMR_OPTIM_ADAM && sg->optimizer != IHMR_OPTIM_SGD) return -1;
     hipStream_t st = (hipStream_t)stream;
     OptWork wk = opt_carve(io->workspace, B);
-    const int P = group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
-    const int need_mask = group == IHMR_GROUP_TRANS ? 8 : (group == IHMR_GROUP_ORIENT ? 1 : (group == IHMR_GROUP_POSE ? 2 : 4));
+    const int pm = sg->param_mask;
+    // what the LBS backward has to deliver (bit0 orient, bit1 pose, bit2 betas, bit3 trans)
+    const int need_mask = ((pm & (IHMR_PB_ORIENT_R | IHMR_PB_ORIENT_L)) ? 1 : 0) | ((pm & (IHMR_PB_POSE_R | IHMR_PB_POSE_L)) ? 2 : 0) |
+                          ((pm & (IHMR_PB_SHAPE_R | IHMR_PB_SHAPE_L)) ? 4 : 0) | ((pm & IHMR_PB_TRANS) ? 8 : 0);
+    const int need_cam = (pm & IHMR_PB_CAM) ? 1 : 0, sgd = sg->optimizer == IHMR_OPTIM_SGD;
     int S = 0;
-    AdamStep step{-1, 0.f, 0.f, 1.f, -1, 1};   // iteration 0: no step yet, zero the Adam moments
-    for (int it = 0; it < n_iters; ++it) {
-        int rc = opt_forward(m, m_left, io, wk, B, *w, step, st);   // applies the step of iteration it - 1 first
+    ParamStep step{0, 0.f, 0.f, 1.f, -1, 1, 0};   // iteration 0: no step yet, zero the optimizer state
+    for (int it = 0; it < sg->n_iters; ++it) {
+        int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam);   // applies the step of iteration it - 1 first
         if (rc) return rc;
-        lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
-                            wk.lbs, st);
+        if (need_mask)
+            lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
+                                wk.lbs, st);
         const double t = (double)(it + 1);
         const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
-        step = AdamStep{group, w->shape_reg, (float)((double)lr / bc1), (float)sqrt(bc2), (it % save_freq == 0) ? S++ : -1, 0};
+        step = ParamStep{pm, w->shape_reg, sgd ? sg->lr : (float)((double)sg->lr / bc1), (float)sqrt(bc2),
+                         (it % sg->save_freq == 0) ? S++ : -1, 0, sgd};
     }
     hipLaunchKernelGGL(opt_adam_kernel, dim3(B), dim3(128), 0, st, *io, wk, B, step);
-    hipLaunchKernelGGL(opt_select_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B, group, S, filter_factor_j3d,
-                       filter_factor_coll, select_on_collision);
+    hipLaunchKernelGGL(opt_select_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B, S, *sg);
     return (int)hipGetLastError();
 }
 
@@ -377,15 +383,10 @@ static int capture_graph(F&& enqueue, ihmr_graph** out) {
     return 0;
 }
 
-extern "C" int ihmr_opt_stage_graph_create(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, int group,
-                                           const ihmr_opt_weights* w, float lr, int n_iters, int save_freq,
-                                           float filter_factor_j3d, float filter_factor_coll, int select_on_collision,
-                                           ihmr_graph** out) {
+extern "C" int ihmr_opt_stage_graph_create(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                                           const ihmr_opt_weights* w, const ihmr_opt_stage* stage, ihmr_graph** out) {
     if (!out) return -1;
-    return capture_graph([&](hipStream_t cs) {
-        return ihmr_opt_run_stage(m, m_left, io, B, group, w, lr, n_iters, save_freq, filter_factor_j3d, filter_factor_coll,
-                                  select_on_collision, (void*)cs);
-    }, out);
+    return capture_graph([&](hipStream_t cs) { return ihmr_opt_run_stage(m, m_left, io, B, w, stage, (void*)cs); }, out);
 }
 
 extern "C" int ihmr_opt_forward_graph_create(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
@@ -420,7 +421,7 @@ extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, c
     ihmr_kernel_timer* keep = g_timer;
     g_timer = nullptr;
     g_collect_stats = 1;
-    int rc = opt_forward(m, m_left, io, wk, B, *w, AdamStep{-1, 0.f, 0.f, 1.f, -1, 0}, st);
+    int rc = opt_forward(m, m_left, io, wk, B, *w, kNoStep, st);
     g_collect_stats = 0;
     g_timer = keep;
     if (rc) return rc;
@@ -434,10 +435,7 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
                                int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int ldx, int ldw,
                                int ldy, int ldr, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !y || N <= 0 || Cout <= 0) return -1;
-    ConvArgs a{x, w, bias, residual, y, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, ldx, ldw, ldy, ldr, act, (float*)workspace, 1, 0};
-#ifdef IHMR_CONV_EXPERIMENT
-    if (const char* e = getenv("IHMR_CONV_EXP")) a.exp_mask = atoi(e);
-#endif
+    ConvArgs a{x, w, bias, residual, y, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, ldx, ldw, ldy, ldr, act, (float*)workspace, 1};
     const int M = N * Ho * Wo, nk = (kh * kw * Cin + CONV_BK - 1) / CONV_BK;
     hipStream_t st = (hipStream_t)stream;
     // Tile and K split, from per-layer measurements on MI355X (scripts/prof_encoder.py with IHMR_CONV_FORCE):
@@ -465,13 +463,15 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
     } else if (blocks(pick) < 384 && nk >= 64 && cap >= 2) {
         ksplit = 2;
     }
-    if (const char* force = getenv("IHMR_CONV_FORCE")) {   // experiments: "<tile 0-3> <ksplit>"
+#ifdef IHMR_TUNING_BUILD   // per-layer tile / split measurements (scripts/prof_encoder.py builds its own library with this macro)
+    if (const char* force = getenv("IHMR_CONV_FORCE")) {   // "<tile 0-3> <ksplit>"
         int ft = -1, fk = 1;
         if (sscanf(force, "%d %d", &ft, &fk) >= 1 && ft >= 0 && ft < 4 && usable(ft)) {
             pick = ft;
             ksplit = (int)std::max<long>(1, std::min<long>(std::min<long>(fk, cap), std::max(1, nk / 4)));
         }
     }
+#endif
     a.ksplit = ksplit;
     const dim3 grid((M + tiles[pick][0] - 1) / tiles[pick][0], (Cout + tiles[pick][1] - 1) / tiles[pick][1], ksplit);
     const bool fast = (Cin % CONV_BK) == 0 && (ldx % 4) == 0;
@@ -524,6 +524,15 @@ extern "C" int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_jo
     return (int)hipGetLastError();
 }
 
+extern "C" int ihmr_eval_mpvpe(const float* pred_right, const float* pred_left, const float* gt_right, const float* gt_left,
+                               const float* root_weights, const float* mano_params_weight, const float* sample_scale, int B,
+                               double* out4, void* stream) {
+    if (!pred_right || !pred_left || !gt_right || !gt_left || !root_weights || !mano_params_weight || !out4 || B <= 0) return -1;
+    hipLaunchKernelGGL(eval_mpvpe_kernel, dim3(B, 2), dim3(256), 0, (hipStream_t)stream, pred_right, pred_left, gt_right, gt_left,
+                       root_weights, mano_params_weight, sample_scale, B, out4);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ IHMR-MLP training step
 extern "C" int ihmr_mlp_train_grad(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                                    const ihmr_opt_weights* w, const ihmr_train_weights* tw, const float* gt_pose,
@@ -535,7 +544,7 @@ extern "C" int ihmr_mlp_train_grad(const ihmr_mano* m, const ihmr_mano* m_left, 
         return -1;
     hipStream_t st = (hipStream_t)stream;
     OptWork wk = opt_carve(io->workspace, B);
-    int rc = opt_forward(m, m_left, io, wk, B, *w, AdamStep{-1, 0.f, 0.f, 1.f, -1, 0}, st);
+    int rc = opt_forward(m, m_left, io, wk, B, *w, kNoStep, st);
     if (rc) return rc;
     lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, 15, wk.lbs, st);
     hipLaunchKernelGGL(mlp_train_grad_kernel, dim3(B), dim3(128), 0, st, *io, wk, B, *tw, gt_pose, gt_shape, params_weight, init_shape,
@@ -639,7 +648,7 @@ extern "C" int ihmr_conv_wgrad(const float* x, const float* dy, float* dw, int N
     else if (wide_n) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(128), 0, st, a);
     // fixed-order sum of the pixel-range partials into dw [K][ldw]
-    ConvArgs r{nullptr, nullptr, nullptr, nullptr, dw, K, 1, 1, 0, 1, 1, Cout, 1, 1, 1, 0, 0, 0, ldw, 0, 0, (float*)workspace, (int)msplit, 0};
+    ConvArgs r{nullptr, nullptr, nullptr, nullptr, dw, K, 1, 1, 0, 1, 1, Cout, 1, 1, 1, 0, 0, 0, ldw, 0, 0, (float*)workspace, (int)msplit};
     if (Cout % 4 == 0 && ldw % 4 == 0 && msplit >= 32)
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((long)K * (Cout / 4) + 15) / 16)), dim3(256), 0, st, (const float*)workspace, dw, K,
                            Cout, ldw, (int)msplit);
@@ -722,21 +731,5 @@ extern "C" int ihmr_flush_kernel_timer(void) {
     return 0;
 }
 
-#ifdef IHMR_TIMING
-extern "C" int ihmr_debug_read(long long* out256) {
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_dbg), 256 * sizeof(long long)));
-    if (getenv("IHMR_DEBUG_BLK")) {
-        static long long blk[2][1024];
-        HIP_TRY(hipMemcpyFromSymbol(blk, HIP_SYMBOL(g_blk), sizeof(blk)));
-        long long t0 = blk[0][0];
-        for (int i = 0; i < 128; ++i) t0 = std::min(t0, blk[0][i]);
-        printf("blk start/end (x10 ns since first start):");
-        for (int i = 0; i < 128; ++i) printf(" %lld-%lld", blk[0][i] - t0, blk[1][i] - t0);
-        printf("\n");
-    }
-    return 0;
-}
-#endif
 
 extern "C" const char* ihmr_version(void) { return "ihmr_hip 0.1 (gfx950)"; }

@@ -237,7 +237,6 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
     __shared__ float beta_s[10][LBS_HG];  // [l][hand]
     __shared__ float shift_s[LBS_HG][4];
     const int tid = threadIdx.x, gx = blockIdx.x, tile = blockIdx.y % 4, gs = blockIdx.y / 4;
-    TSTAMP(0);
     for (int idx = tid; idx < LBS_HG * 136; idx += LBS_THREADS) {
         const int hh = idx / 136, e = idx % 136, hid = lbs_group_hand(gx, gs, hh);
         const float v = (hid < N && e < NPF) ? skel[(size_t)hid * SK_STRIDE + SK_PF + e] : 0.f;
@@ -256,7 +255,6 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
         shift_s[hh][k] = (hid < N && k < 3) ? skel[(size_t)hid * SK_STRIDE + SK_SHIFT + k] : 0.f;
     }
     __syncthreads();
-    TSTAMP(1);
     const int v = tile * LBS_TILE_V + tid;
     if (tid >= LBS_TILE_V || v >= NV) return;
 
@@ -281,7 +279,6 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
             }
         }
     }
-    TSTAMP(2);
     // pose blend: v_posed = v_shaped + pose_feature . posedirs.  The basis rows are fetched 9 at a time into two
     // register batches, the next batch in flight while the current one is consumed (explicit batches +
     // scheduling barriers: left alone, hipcc issues one load per use and waits vmcnt(0) on each).
@@ -326,7 +323,6 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
         }
         consume(pa, NPF - 9);
     }
-    TSTAMP(3);
     float w[NJ];
     {
         const float4* w4 = reinterpret_cast<const float4*>(m.weights + v * NJ);
@@ -382,7 +378,6 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
             }
         }
     }
-    TSTAMP(4);
 }
 
 // ------------------------------------------------------------------------------------- backward 1
@@ -420,7 +415,6 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
     const int b = TWO_HAND ? (left ? h - B : h) : 0;
     const bool need_orient = need_mask & 1, need_pose = need_mask & 2, need_betas = need_mask & 4, need_trans = need_mask & 8;
 
-    TSTAMP(10);
     // constants this workgroup reads later, requested first so their latency hides behind the phases in between:
     // the skinning weights of this thread's (up to 4) vertices and the kinematic tree
     constexpr int VR = (NV + LBS_THREADS - 1) / LBS_THREADS;
@@ -484,7 +478,6 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
         if ((need_mask & 7) == 0) return;  // stage 0: only the translation moves
     }
 
-    TSTAMP(11);
     // ---- skeleton record of this iteration's forward, output gradients into the raw hand frame
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -518,7 +511,6 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
         bw.nchild[p] = n;
     }
 
-    TSTAMP(12);
     // ---- per vertex: d v_posed = T.R^T g, T.R = sum_j w_j A_j.R over all 16 joints (no branches: a zero weight adds
     //      an exact zero), the matrices read from LDS as broadcast rows
 #pragma unroll
@@ -549,7 +541,6 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
             if (need_pose) wk.dvp[(size_t)h * NV3 + 3 * v + c] = d;
         }
     }
-    TSTAMP(13);
     // ---- dA[j][e] = sum_v W[v][j] * [g (x) v_posed | g][e].  The CSR-by-joint list is cut into single-joint
     //      segments of <= 13 entries, one lane each (balanced: the wrist alone owns ~600 entries), then the
     //      segment partials of a joint are summed in index order -- fixed order, bit-reproducible.
@@ -598,7 +589,6 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
     }
     __syncthreads();
 
-    TSTAMP(14);
     // ---- chain backward by tree level
     // dG_j = [dA_j.R - dA_j.t (x) J_j | dA_j.t + d posed_joint_j];  dJ_j(direct) = -G_j.R^T dA_j.t
     if (tid < NJ * 12) {
@@ -663,7 +653,6 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
     if (tid >= 64 && tid < 67) bw.dJ[0][tid - 64] += bw.dG[0][4 * (tid - 64) + 3];
     __syncthreads();
 
-    TSTAMP(15);
     // ---- global orientation gradient (the root rotation is not part of the pose feature)
     if (need_orient && tid == 0) {
         float dr[3];
@@ -706,7 +695,6 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
             if (lane == 0) d_betas[h * 10 + l] = acc;
         }
     }
-    TSTAMP(16);
 }
 
 // ------------------------------------------------------------------------------------- backward 2

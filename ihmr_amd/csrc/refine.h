@@ -8,7 +8,7 @@
 #include "ihmr_common.h"
 
 #define LOSS_THREADS 64
-#define OPT_PMAX 90  // largest parameter group: 2 x 45 finger pose
+#define OPT_NPARAM IHMR_OPT_NPARAM  // parameter slots of a sample, see ihmr_hip.h (block order of IHMR_PB_*)
 
 struct OptWork {  // carved from ihmr_opt_io.workspace
     LbsWork lbs;        // skeleton records, v_posed, bwd scratch for 2B hands
@@ -16,6 +16,7 @@ struct OptWork {  // carved from ihmr_opt_io.workspace
     float* g_verts;     // (2,B,778,3)
     float* g_joints;    // (B,42,3)
     float* g_trans_direct;  // (B,3)
+    float* g_cam;       // (B,3)  camera gradient of the 2-D term (only written when the stage refines the camera)
     float* g_orient;    // (2,B,3)
     float* g_pose;      // (2,B,45)
     float* g_shape;     // (2,B,10)
@@ -28,9 +29,9 @@ static inline size_t opt_ws_bytes(int B) {
     n += (size_t)2 * B * NV3 * 4;         // g_verts
     n += lbs_ws_bytes(2 * B);
     n += (size_t)B * 42 * 3 * 4 * 2;      // joints_raw, g_joints
-    n += (size_t)B * (3 + 6 + 90 + 20 + 3 + 1) * 4;
+    n += (size_t)B * (3 + 6 + 90 + 20 + 3 + 3 + 1) * 4;
     n = (n + 255) & ~(size_t)255;
-    n += 4096;
+    n += 8192;
     return n + sdf_ws_bytes(2 * B);
 }
 
@@ -47,6 +48,7 @@ static inline OptWork opt_carve(void* ws, int B) {
     w.g_pose = (float*)take((size_t)B * 90 * 4);
     w.g_shape = (float*)take((size_t)B * 20 * 4);
     w.g_trans = (float*)take((size_t)B * 3 * 4);
+    w.g_cam = (float*)take((size_t)B * 3 * 4);
     w.sdf_ws = (void*)p;
     return w;
 }
@@ -78,7 +80,7 @@ struct LossShared {
     } while (0)
 
 __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWork& wk, int B, const ihmr_opt_weights& w,
-                                              LossShared& sh, int b, int j) {
+                                              LossShared& sh, int b, int j, int need_cam) {
     const bool act = j < 42;
     const int Bn = io.norm_batch > 0 ? io.norm_batch : B;   // the batch the reference's means run over
     // ---- every global input of this sample first, in one batch (the stores below may alias them as far as the
@@ -122,6 +124,12 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
         const float sx = dx > 0.f ? -1.f : (dx < 0.f ? 1.f : 0.f), sy = dy > 0.f ? -1.f : (dy < 0.f ? 1.f : 0.f);
         g_raw[0] = s2 * sx * t2[2] * cs;
         g_raw[1] = s2 * sy * t2[2] * cs;
+        if (need_cam) {   // p = (X + cam[1:3]) * cam[0]: d/d scale, d/d tx, d/d ty of this joint's term
+            const float gx = s2 * sx * t2[2], gy = s2 * sy * t2[2];
+            sh.acc[5][j] = gx * (r[0] + ctx) + gy * (r[1] + cty);
+            sh.acc[6][j] = gx * cs;
+            sh.acc[7][j] = gy * cs;
+        }
     }
 
     // ---- 3D: two successive in-place root alignments (GT weights first, then init weights); lane 0 holds joint 0,
@@ -239,6 +247,10 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
         if (j == 2) io.loss_batch[3 * B + b] = s;
         if (j == 3) io.loss_batch[4 * B + b] = s / 84.f;
         if (j == 4) io.loss_batch[5 * B + b] = s / 126.f;
+    } else if (need_cam && j < 8) {
+        float s = 0.f;
+        for (int q = 0; q < 42; ++q) s += sh.acc[j][q];
+        wk.g_cam[b * 3 + (j - 5)] = s;
     }
     // ---- translation loss (loss_utils.py:114-118) and the collision gradient scale
     if (j == 5) {
@@ -262,11 +274,11 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
 // evaluates the joint losses and their gradient (-> g_joints); the two halves share nothing but the launch.
 #define OPT_SAMPLE_WORKERS (SDF_SAMPLE_THREADS - WAVE)
 __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void opt_sample_loss_kernel(ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,
-                                                                             VertLayout vl, SdfWorkspace ws) {
+                                                                             VertLayout vl, SdfWorkspace ws, int need_cam) {
     __shared__ LossShared sh;
     __shared__ float red16[SDF_SAMPLE_THREADS / WAVE];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid >= OPT_SAMPLE_WORKERS) opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS);
+    if (tid >= OPT_SAMPLE_WORKERS) opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS, need_cam);
     // collision gradient scale: weight * [two-hand sample] / (num_hands^2 * B)   (loss_utils.py:186-188)
     const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
     const float gs = w.collision * mask / (4.0f * (float)(io.norm_batch > 0 ? io.norm_batch : B));
@@ -274,35 +286,46 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void opt_sample_loss_kernel(ihm
                      io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
 }
 
-// One Adam step of parameter e (< P) of sample b: adds the direct (non-MANO) gradient terms, takes the snapshot
-// (before the step, as optimize_model.py:401-403) and applies torch.optim.Adam's single-tensor update.
-// Element e: hand = e / D, d = e % D.
-struct AdamStep {
-    int group;            // IHMR_GROUP_*, or < 0: no update
-    float w_shape_reg, step_size, bc2_sqrt;
+// One optimizer step of parameter slot e (< 122) of sample b: adds the direct (non-MANO) gradient terms, takes the
+// snapshot (before the step, as optimize_model.py:401-403) and applies torch.optim.Adam's single-tensor update
+// (or torch.optim.SGD with momentum 0.9, optimize_model.py:345-347).  Slots follow the IHMR_PB_* block order:
+// [cam 3 | trans 3 | R orient 3 | L orient 3 | R pose 45 | L pose 45 | R shape 10 | L shape 10]; only the slots of the
+// blocks in `mask` (the stage's update_params) move, are snapshotted and own optimizer state.
+struct ParamStep {
+    int mask;             // IHMR_PB_* bits, 0: no update
+    float w_shape_reg, step_size, bc2_sqrt;   // Adam: lr / (1 - beta1^t), sqrt(1 - beta2^t); SGD: step_size = lr
     int snap_idx;         // >= 0: snapshot slot of this iteration
-    int reset_state;      // first iteration of a stage: zero the Adam moments instead of stepping
+    int reset_state;      // first iteration of a stage: zero the optimizer state instead of stepping
+    int sgd;              // 0 = Adam, 1 = SGD(momentum 0.9)
 };
-__device__ __forceinline__ int adam_group_size(int group) {
-    return group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
+__device__ __forceinline__ int opt_slot_block(int e) {
+    return e < 3 ? 0 : (e < 6 ? 1 : (e < 9 ? 2 : (e < 12 ? 3 : (e < 57 ? 4 : (e < 102 ? 5 : (e < 112 ? 6 : 7))))));
 }
-__device__ __forceinline__ void opt_adam_apply(const ihmr_opt_io& io, const OptWork& wk, int B, const AdamStep& st, int b, int e) {
-    const int group = st.group, P = adam_group_size(group);
-    const int D = group == IHMR_GROUP_TRANS ? 3 : P / 2;
-    const int hnd = e / D, d = e % D;
-    float* p;
+// pointer to slot e of sample b in the caller's parameter buffers
+__device__ __forceinline__ float* opt_slot_ptr(const ihmr_opt_io& io, int B, int b, int e, int blk) {
+    switch (blk) {
+        case 0: return io.cam + b * 3 + e;
+        case 1: return io.trans + b * 3 + (e - 3);
+        case 2: case 3: return io.orient + ((size_t)(blk - 2) * B + b) * 3 + (e - 6 - 3 * (blk - 2));
+        case 4: case 5: return io.pose + ((size_t)(blk - 4) * B + b) * 45 + (e - 12 - 45 * (blk - 4));
+        default: return io.shape + ((size_t)(blk - 6) * B + b) * 10 + (e - 102 - 10 * (blk - 6));
+    }
+}
+__device__ __forceinline__ void opt_param_apply(const ihmr_opt_io& io, const OptWork& wk, int B, const ParamStep& st, int b, int e) {
+    const int blk = opt_slot_block(e);
+    if (!((st.mask >> blk) & 1)) return;
+    float* p = opt_slot_ptr(io, B, b, e, blk);
     float g;
-    if (group == IHMR_GROUP_TRANS) {
-        p = io.trans + b * 3 + d;
-        g = wk.g_trans[b * 3 + d] + wk.g_trans_direct[b * 3 + d];
-    } else if (group == IHMR_GROUP_ORIENT) {
-        p = io.orient + ((size_t)hnd * B + b) * 3 + d;
-        g = wk.g_orient[((size_t)hnd * B + b) * 3 + d];
-    } else if (group == IHMR_GROUP_POSE) {
-        p = io.pose + ((size_t)hnd * B + b) * 45 + d;
-        g = wk.g_pose[((size_t)hnd * B + b) * 45 + d];
+    if (blk == 0) {
+        g = wk.g_cam[b * 3 + e];
+    } else if (blk == 1) {
+        g = wk.g_trans[b * 3 + (e - 3)] + wk.g_trans_direct[b * 3 + (e - 3)];
+    } else if (blk < 4) {
+        g = wk.g_orient[((size_t)(blk - 2) * B + b) * 3 + (e - 6 - 3 * (blk - 2))];
+    } else if (blk < 6) {
+        g = wk.g_pose[((size_t)(blk - 4) * B + b) * 45 + (e - 12 - 45 * (blk - 4))];
     } else {
-        p = io.shape + ((size_t)hnd * B + b) * 10 + d;
+        const int hnd = blk - 6, d = e - 102 - 10 * hnd;
         g = wk.g_shape[((size_t)hnd * B + b) * 10 + d];
         // shape regulariser mean((beta_r - beta_l)^2) (loss_utils.py:121-128)
         const float diff = io.shape[(size_t)b * 10 + d] - io.shape[((size_t)B + b) * 10 + d];
@@ -310,41 +333,48 @@ __device__ __forceinline__ void opt_adam_apply(const ihmr_opt_io& io, const OptW
         g += hnd == 0 ? gr : -gr;
     }
     const float x = *p;
-    if (st.snap_idx >= 0) {
-        io.snap_params[((size_t)st.snap_idx * B + b) * OPT_PMAX + e] = x;
-        if (e == 0) {
-            io.snap_loss[((size_t)st.snap_idx * 2 + 0) * B + b] = io.loss_batch[1 * B + b];
-            io.snap_loss[((size_t)st.snap_idx * 2 + 1) * B + b] = io.loss_batch[2 * B + b];
-        }
+    if (st.snap_idx >= 0) io.snap_params[((size_t)st.snap_idx * B + b) * OPT_NPARAM + e] = x;
+    float m = io.adam_m[b * OPT_NPARAM + e];
+    if (st.sgd) {
+        m = m * 0.9f;                        // buf.mul_(momentum).add_(grad); the first step's buf = grad (state zeroed)
+        m = m + g;
+        io.adam_m[b * OPT_NPARAM + e] = m;
+        *p = x + (-st.step_size) * m;        // param.add_(buf, alpha = -lr)
+        return;
     }
-    float m = io.adam_m[b * OPT_PMAX + e], v = io.adam_v[b * OPT_PMAX + e];
+    float v = io.adam_v[b * OPT_NPARAM + e];
     m = m + 0.1f * (g - m);                  // exp_avg.lerp_(grad, 1 - beta1)
     v = v * 0.999f;                          // exp_avg_sq.mul_(beta2)
     v = v + (0.001f * g) * g;                //            .addcmul_(grad, grad, value = 1 - beta2)
     const float denom = sqrtf(v) / st.bc2_sqrt + 1e-8f;
-    io.adam_m[b * OPT_PMAX + e] = m;
-    io.adam_v[b * OPT_PMAX + e] = v;
+    io.adam_m[b * OPT_NPARAM + e] = m;
+    io.adam_v[b * OPT_NPARAM + e] = v;
     *p = x + (-st.step_size) * (m / denom);  // param.addcdiv_(exp_avg, denom, value = -step_size)
 }
+// the three per-sample losses a stage may filter / select on (IHMR_LOSS_* = rows 0..2 of loss_batch), kept per snapshot
+__device__ __forceinline__ void opt_snapshot_losses(const ihmr_opt_io& io, int B, const ParamStep& st, int b, int e) {
+    if (st.snap_idx >= 0 && e < 3) io.snap_loss[((size_t)st.snap_idx * 3 + e) * B + b] = io.loss_batch[e * B + b];
+}
 
-// stand-alone step (the last iteration of a stage): grid = B, block = 128, thread e < P.  The shape group reads
-// both hands' values of a sample while updating them: its 20 threads sit in one wave, reads before writes.
-__global__ __launch_bounds__(128) void opt_adam_kernel(ihmr_opt_io io, OptWork wk, int B, AdamStep st) {
-    if ((int)threadIdx.x < adam_group_size(st.group)) opt_adam_apply(io, wk, B, st, blockIdx.x, threadIdx.x);
+// stand-alone step (the last iteration of a stage): grid = B, block = 128, thread e < 122.  The shape slots read
+// both hands' values of a sample while updating them: they sit in one wave (slots 102..121), reads before writes.
+__global__ __launch_bounds__(128) void opt_adam_kernel(ihmr_opt_io io, OptWork wk, int B, ParamStep st) {
+    opt_snapshot_losses(io, B, st, blockIdx.x, threadIdx.x);
+    if ((int)threadIdx.x < OPT_NPARAM) opt_param_apply(io, wk, B, st, blockIdx.x, threadIdx.x);
 }
 
 // Head of a refinement iteration: the Adam step that closes the PREVIOUS iteration (its gradients and losses are
 // still in place), then both skeletons of sample b from the updated parameters.  grid = B, block = 2 x 192
 // (threads [0,192) right hand, [192,384) left hand).  The whole sample lives in one workgroup because the left
 // hand's wrist shift reads the right hand's shape and the shared translation (optimize_model.py:196-206).
-__global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_opt_io io, OptWork wk, int B, AdamStep st,
+__global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_opt_io io, OptWork wk, int B, ParamStep st,
                                                             int* inside_count) {
     __shared__ float sk[2][SK_STRIDE];
     const int b = blockIdx.x, tid = threadIdx.x;
     // the collision kernels of this iteration append to the inside-voxel counter: start it at zero
     if (b == 0 && tid >= 192 && tid < 192 + SDF_NXCD) inside_count[tid - 192] = 0;
-    if (st.reset_state && tid < OPT_PMAX) { io.adam_m[b * OPT_PMAX + tid] = 0.f; io.adam_v[b * OPT_PMAX + tid] = 0.f; }
-    if (st.group >= 0 && tid < adam_group_size(st.group)) opt_adam_apply(io, wk, B, st, b, tid);
+    if (st.reset_state && tid < OPT_NPARAM) { io.adam_m[b * OPT_NPARAM + tid] = 0.f; io.adam_v[b * OPT_NPARAM + tid] = 0.f; }
+    if (st.mask && tid < OPT_NPARAM) { opt_snapshot_losses(io, B, st, b, tid); opt_param_apply(io, wk, B, st, b, tid); }
     __syncthreads();   // the updated parameters are read back below by other threads of this workgroup
     const int hl = tid / 192;
     lbs_skel_hand<true>(m, io.orient, io.pose, io.shape, io.trans, B, wk.lbs.skel, wk.joints_raw, sk[hl], hl * B + b, tid % 192);
@@ -367,31 +397,28 @@ __global__ __launch_bounds__(128) void opt_unpack_params_kernel(ihmr_opt_io io, 
     else io.trans[b * 3 + (e - 119)] = v;
 }
 
-// utils/opt_utils.py:104-153: validity filter, 1e11 for invalid rows, row 0 restored, first argmin,
-// selected parameters written back.  grid = ceil(B/64), one thread per sample.
-__global__ void opt_select_kernel(ihmr_opt_io io, int B, int group, int S, float fac_j3d, float fac_coll,
-                                  int select_on_collision) {
+// utils/opt_utils.py:104-153: validity filter (every criterion of the stage: loss <= origin * factor), 1e11 for
+// invalid rows, row 0 restored, first argmin of the select loss, selected parameters written back.
+// One thread per sample.  A loss without a criterion is NOT compared at all (use_filter = 0), as in the reference.
+__global__ void opt_select_kernel(ihmr_opt_io io, int B, int S, ihmr_opt_stage sg) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int P = group == IHMR_GROUP_TRANS ? 3 : (group == IHMR_GROUP_ORIENT ? 6 : (group == IHMR_GROUP_POSE ? 90 : 20));
-    const int D = group == IHMR_GROUP_TRANS ? 3 : P / 2;
-    const float j0 = io.snap_loss[(size_t)0 * B + b], c0 = io.snap_loss[(size_t)1 * B + b];
-    const float bar_j = j0 * fac_j3d, bar_c = c0 * fac_coll;
+    float bar[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) bar[l] = io.snap_loss[(size_t)l * B + b] * sg.filter_factor[l];
     int best = 0;
-    float best_v = select_on_collision ? c0 : j0;
+    float best_v = io.snap_loss[(size_t)sg.select_loss * B + b];
     for (int s = 1; s < S; ++s) {
-        const float js = io.snap_loss[((size_t)s * 2) * B + b], cs = io.snap_loss[((size_t)s * 2 + 1) * B + b];
-        const bool valid = (js <= bar_j) && (cs <= bar_c);
-        const float key = valid ? (select_on_collision ? cs : js) : 100000000000.0f;
+        bool valid = true;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+            if (sg.use_filter[l]) valid = valid && (io.snap_loss[((size_t)s * 3 + l) * B + b] <= bar[l]);
+        const float key = valid ? io.snap_loss[((size_t)s * 3 + sg.select_loss) * B + b] : 100000000000.0f;
         if (key < best_v) { best_v = key; best = s; }
     }
     io.selected[b] = best;
-    for (int e = 0; e < P; ++e) {
-        const float x = io.snap_params[((size_t)best * B + b) * OPT_PMAX + e];
-        const int hnd = e / D, d = e % D;
-        if (group == IHMR_GROUP_TRANS) io.trans[b * 3 + d] = x;
-        else if (group == IHMR_GROUP_ORIENT) io.orient[((size_t)hnd * B + b) * 3 + d] = x;
-        else if (group == IHMR_GROUP_POSE) io.pose[((size_t)hnd * B + b) * 45 + d] = x;
-        else io.shape[((size_t)hnd * B + b) * 10 + d] = x;
+    for (int e = 0; e < OPT_NPARAM; ++e) {
+        const int blk = opt_slot_block(e);
+        if ((sg.param_mask >> blk) & 1) *opt_slot_ptr(io, B, b, e, blk) = io.snap_params[((size_t)best * B + b) * OPT_NPARAM + e];
     }
 }

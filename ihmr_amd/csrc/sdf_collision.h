@@ -206,10 +206,6 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     const float* own = vl.hand(b, hnd);
     const float* other = vl.hand(b, 1 - hnd);
     const int32_t* faces = hnd == 0 ? faces_r : faces_l;  // SoA [3][NFP]
-    TSTAMP(20);
-#ifdef IHMR_TIMING
-    if (tid == 0 && blockIdx.x < 1024) g_blk[0][blockIdx.x] = wall_clock64();
-#endif
     // ---- bounding box (min / max are exact, any order); a thread owns vertices tid, tid + SDF_PREP_THREADS, ...
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     float oq[SDF_PREP_VPT][3];
@@ -262,7 +258,6 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     __syncthreads();
     const float cx = box[0], cy = box[1], cz = box[2], sc = box[3];
     if (tid < 4) ws.box[H * 4 + tid] = box[tid];
-    TSTAMP(21);
     // ---- normalise own vertices into [-1,1]^3; which voxels will the other hand's vertices read?
 #pragma unroll
     for (int rep = 0; rep < SDF_PREP_VPT; ++rep) {
@@ -293,7 +288,6 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         }
     }
     __syncthreads();
-    TSTAMP(22);
     // ---- lane = triangle: records for the distance kernel + ray parity of the needed voxels it can hit
     float4* sph = ws.sph + (size_t)H * NFP;
     float* rad = ws.rad + (size_t)H * NFP;
@@ -329,17 +323,11 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             sph[f] = make_float4(-2.0f * qx, -2.0f * qy, -2.0f * qz, qx * qx + qy * qy + qz * qz);
             rad[f] = f < NF ? sqrtf(r2) * 1.0001f + 1e-6f : 0.0f;
         }
-#ifdef IHMR_TIMING
-        if (blockIdx.x == 0 && lane == 0) g_dbg[120 + wave + 16 * it] = clock64() - g_dbg[22];
-#endif
         if (!ok) continue;                                   // degenerate in yz: the +x ray never counts it
         const float inv = 1.0f / det;
         const bool tri_safe = sdf_ray_tri_safe(e1x, e1y, e1z, e2x, e2y, e2z, inv);
         int j0, j1, k0, k1;
         tri_col_range(a[1], bb[1], c[1], a[2], bb[2], c[2], j0, j1, k0, k1);
-#ifdef IHMR_TIMING
-        { int ncol_ = (k1 - k0 + 1) * (j1 - j0 + 1); for (int o = 32; o > 0; o >>= 1) ncol_ = max(ncol_, __shfl_xor(ncol_, o)); if (blockIdx.x == 0 && lane == 0) g_dbg[160 + wave + 16 * it] = ncol_; }
-#endif
         // one flat loop over the bounding box's columns: a wave then iterates max(ncol) times, not
         // max(k range) * max(j range) as two nested divergent loops would
         const int ncol = (j1 >= j0 && k1 >= k0) ? (k1 - k0 + 1) * (j1 - j0 + 1) : 0;
@@ -362,11 +350,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             if (hits) atomicXor(&parity[col], hits);
         }
     }
-#ifdef IHMR_TIMING
-    { const long long tnow = clock64(); if (blockIdx.x == 0 && lane == 0) g_dbg[100 + wave] = tnow - g_dbg[22]; }
-#endif
     __syncthreads();
-    TSTAMP(27);
     // ---- publish: a thread owns SDF_PREP_CPT adjacent columns; phi = 0 for the outside voxels, inside voxels
     //      into the batch-wide list
     float* phi = ws.phi + (size_t)H * SDF_NVOX;
@@ -391,7 +375,6 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     const int blk_padded = (blk_total + SDF_ITEM - 1) & ~(SDF_ITEM - 1);
     if (tid == 0) { blk_inside = blk_total; blk_base = blk_total > 0 ? atomicAdd(&ws.inside_count[xcd], blk_padded) : 0; }
     __syncthreads();
-    TSTAMP(28);
     if (tid < blk_padded - blk_total) ws.inside_list[(size_t)xcd * ws.xcd_cap + blk_base + blk_total + tid] = 0xffffffffu;
 #pragma unroll
     for (int rep = 0; rep < SDF_PREP_CPT; ++rep) {
@@ -405,7 +388,6 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             glist[o++] = ((unsigned)H << 16) | (unsigned)(col * SDF_G + i);
         }
     }
-    TSTAMP(29);
     if (collect_stats) {
         unsigned long long c = st_tests;
 #pragma unroll
@@ -418,10 +400,6 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         if (lane == 0) { atomicAdd(&ws.stats[0], c); atomicAdd(&ws.stats[3], nv); }   // ray tests, needed voxels
         if (tid == 0) atomicAdd(&ws.stats[2], (unsigned long long)blk_inside);            // inside voxels
     }
-    TSTAMP(26);
-#ifdef IHMR_TIMING
-    if (tid == 0 && blockIdx.x < 1024) g_blk[1][blockIdx.x] = wall_clock64();
-#endif
 }
 
 // squared distance point -> triangle, closest point by Voronoi region.  Same values, operation for
@@ -490,7 +468,6 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
     unsigned short* mylist = surv[wave];
     int curH = -1;
     unsigned long long st_dist = 0;
-    TSTAMP(40);
     for (int item = slot; item * SDF_ITEM < total; item += nslot) {
         const unsigned ent_l = lane < SDF_ITEM ? glist[item * SDF_ITEM + lane] : 0xffffffffu;
         const int H = (int)((unsigned)__builtin_amdgcn_readlane((int)ent_l, 0) >> 16);   // entry 0 of an item is always valid
@@ -584,7 +561,6 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
             }
         }
     }
-    TSTAMP(41);
     if (collect_stats) {
         unsigned long long d = st_dist;
 #pragma unroll
@@ -606,7 +582,6 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
                                                  float* __restrict__ gverts, int B, float gs,
                                                  const float* __restrict__ hand_type, float* red16, int b, int nworkers) {
     const int tid = threadIdx.x;
-    TSTAMP(50);
     float acc = 0.f;
     for (int e = tid; e < 2 * NV && tid < nworkers; e += nworkers) {
         const int hnd = e / NV, v = e % NV;
@@ -666,12 +641,10 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
         }
         acc += val;
     }
-    TSTAMP(51);
     // fixed-order block sum: DPP inside each wave, the 16 wave totals through LDS
     const float wsum = wave_reduce_sum_dpp(acc);
     if (tid % WAVE == 0) red16[tid / WAVE] = wsum;
     __syncthreads();
-    TSTAMP(52);
     if (tid == 0) {
         float tot = 0.f;
         for (int wv = 0; wv < SDF_SAMPLE_THREADS / WAVE; ++wv) tot += red16[wv];

@@ -3,7 +3,8 @@
 
 ``Evaluator.update(data_idxs, pred_results)`` consumes the dict of ``get_pred_result()`` exactly like
 ``evaluator.py:38-97``; the four reported metrics are ``mpjpe_3d``, ``inter_mpjpe_3d``, ``collision_ave``,
-``collision_max`` (``evaluator.py:149-181``, printed by ``optimize.py:98-102``).  For multi-GPU runs
+``collision_max`` (``evaluator.py:149-181``, printed by ``optimize.py:98-102``), plus ``mpvpe_3d`` for the models that
+export GT meshes (IHMR-Baseline / IHMR-MLP; see :func:`get_single_verts_error`).  For multi-GPU runs
 ``metric_sums()`` returns the additive form that :func:`ihmr_amd.dist.reduce_metrics` all-reduces.
 
 ``Evaluator.update_device(...)`` is the same arithmetic on the GPU (``ihmr_eval_metrics``): it takes
@@ -46,17 +47,35 @@ def get_single_pa_inter_joints_error(pred, gt, joints_valid, scale_factor):
     return (np.linalg.norm(calc_transform_no_rot(p.copy(), g.copy()) - g, axis=1) / scale_factor).tolist()
 
 
+def get_single_verts_error(pred_verts, gt_verts, root_weights, scale_factor):
+    """MPVPE of ONE hand (BASELINE.json names the metric; the reference exports what it needs -- predicted and GT
+    meshes, ``baseline_model.py:365-368``, ``mlp_model.py:708-711`` -- but never computes it).
+    Defined like the reference's MPJPE (``metric_utils.py:23-38``: root-relative per hand, L2 per point, / scale):
+    both meshes are made relative to their own wrist, the wrist being regressed from the mesh itself with row 0 of
+    the MANO joint regressor (``root_weights`` (778,)), then the 778 per-vertex distances."""
+    pr = pred_verts.astype(np.float64) - root_weights.astype(np.float64) @ pred_verts.astype(np.float64)
+    gr = gt_verts.astype(np.float64) - root_weights.astype(np.float64) @ gt_verts.astype(np.float64)
+    return (np.linalg.norm(pr - gr, axis=1) / scale_factor).tolist()
+
+
 class Evaluator:
     def __init__(self, mano_models=None, data_list=None):
         self.left_hand_faces = None if mano_models is None else mano_models["left"].faces
         self.right_hand_faces = None if mano_models is None else mano_models["right"].faces
+        # wrist row of the joint regressor per hand (MPVPE root), (2,778): 0 = right, 1 = left
+        self.root_weights = None
+        if mano_models is not None and hasattr(mano_models["right"], "J_regressor"):
+            jr = lambda m: np.asarray(m.J_regressor.detach().cpu().numpy() if hasattr(m.J_regressor, "detach") else m.J_regressor)[0]
+            self.root_weights = np.stack([jr(mano_models["right"]), jr(mano_models["left"])]).astype(np.float32)
         self.data_list = data_list or {}
         self.pred_results = []
         self._device_parts = []        # (B,6) float64 device tensors + keep masks, summed lazily
+        self._device_vert_parts = []   # (B,2) float64 [sum of per-vertex errors, count]
 
     def clear(self):
         self.pred_results = []
         self._device_parts = []
+        self._device_vert_parts = []
 
     def update_device(self, pred_joints_3d, gt_joints_3d, collision_loss_origin_scale, keep=None, interacting=None, scale=None):
         """Metrics of one batch straight from device tensors: pred_joints_3d (B,42,3), gt_joints_3d (B,42,4),
@@ -82,6 +101,29 @@ class Evaluator:
             part = part * keep.to(dev, torch.float64)[:, None]
         self._device_parts.append(part)
 
+    def update_device_verts(self, pred_right, pred_left, gt_right, gt_left, mano_params_weight, keep=None, scale=None):
+        """MPVPE partial sums of one batch from device tensors: the four meshes (B,778,3) and ``mano_params_weight`` (B,2)
+        (a hand counts when its MANO annotation exists, i.e. weight > 0).  ``ihmr_eval_mpvpe``."""
+        import torch
+
+        from . import hip
+        hip.require_gpu()
+        assert self.root_weights is not None, "Evaluator needs the MANO models (J_regressor) for MPVPE"
+        B, dev = pred_right.shape[0], pred_right.device
+        f = lambda t: t.detach().to(dev, torch.float32).contiguous()
+        pr, pl, gr, gl, w = f(pred_right), f(pred_left), f(gt_right), f(gt_left), f(mano_params_weight)
+        if not hasattr(self, "_root_w_dev") or self._root_w_dev.device != dev:
+            self._root_w_dev = torch.from_numpy(self.root_weights).to(dev).contiguous()
+        sc = None if scale is None else f(scale)
+        out = torch.empty(B, 4, device=dev, dtype=torch.float64)
+        hip.check(hip.lib().ihmr_eval_mpvpe(pr.data_ptr(), pl.data_ptr(), gr.data_ptr(), gl.data_ptr(), self._root_w_dev.data_ptr(),
+                                            w.data_ptr(), None if sc is None else sc.data_ptr(), B, out.data_ptr(), hip.stream_ptr()),
+                  "ihmr_eval_mpvpe")
+        out = out[:, 0:2] + out[:, 2:4]
+        if keep is not None:
+            out = out * keep.to(dev, torch.float64)[:, None]
+        self._device_vert_parts.append(out)
+
     def gather_pred(self, pred_results):
         self.pred_results += pred_results
 
@@ -99,6 +141,13 @@ class Evaluator:
             single["j3d_error"] = get_single_joints_error(single["pred_joints_3d"], gt[:, :3], gt[:, 3:], single["scale"])
             single["pa_no_rot_inter_j3d_error"] = get_single_pa_inter_joints_error(
                 single["pred_joints_3d"], gt[:, :3], gt[:, 3:], single["scale"])
+            single["v3d_error"] = []
+            if "gt_right_hand_verts" in pred_results and self.root_weights is not None:   # Baseline / MLP exports
+                for h, side in enumerate(("right", "left")):
+                    if pred_results["mano_params_weight"][i][h] > 0:
+                        single["v3d_error"] += get_single_verts_error(pred_results[f"pred_{side}_hand_verts"][i],
+                                                                      pred_results[f"gt_{side}_hand_verts"][i],
+                                                                      self.root_weights[h], single["scale"])
             self.pred_results.append(single)
 
     def remove_redunc(self):
@@ -111,26 +160,33 @@ class Evaluator:
         self.pred_results = out
 
     def metric_sums(self):
-        """[sum mpjpe, n, sum inter, n, sum coll_ave, sum coll_max, n_interacting] (float64, additive over ranks)."""
+        """[sum mpjpe, n, sum inter, n, sum coll_ave, sum coll_max, n_interacting, sum mpvpe, n] (float64, additive over ranks)."""
         e = [x for p in self.pred_results for x in p["j3d_error"]]
         pa = [x for p in self.pred_results for x in p["pa_no_rot_inter_j3d_error"]]
         inter = [p for p in self.pred_results if p["hand_type"] == "interacting"]
         ca = [np.mean(p["collision_loss_origin_scale"].astype(np.float64)) * 1000 for p in inter]
         cm = [np.max(p["collision_loss_origin_scale"].astype(np.float64)) * 1000 for p in inter]
         f64 = lambda x: float(np.sum(np.asarray(x, dtype=np.float64)))
-        sums = np.array([f64(e), len(e), f64(pa), len(pa), f64(ca), f64(cm), len(inter)], dtype=np.float64)
+        ve = [x for p in self.pred_results for x in p.get("v3d_error", [])]
+        sums = np.array([f64(e), len(e), f64(pa), len(pa), f64(ca), f64(cm), len(inter), f64(ve), len(ve)], dtype=np.float64)
         if self._device_parts:
             import torch
             # one reduction over all samples in the order they were added: the float64 sum does not depend on how
             # the samples were grouped into batches / launch sequences
             dsum = torch.cat(self._device_parts, dim=0).sum(dim=0).cpu().numpy()
-            sums = sums + dsum
+            sums[:7] = sums[:7] + dsum
+        if self._device_vert_parts:
+            import torch
+            sums[7:9] = sums[7:9] + torch.cat(self._device_vert_parts, dim=0).sum(dim=0).cpu().numpy()
         return sums
 
     @staticmethod
     def metrics_from_sums(s):
         d = lambda a, b: float(a / b) if b > 0 else float("nan")
-        return dict(mpjpe_3d=d(s[0], s[1]), inter_mpjpe_3d=d(s[2], s[3]), collision_ave=d(s[4], s[6]), collision_max=d(s[5], s[6]))
+        out = dict(mpjpe_3d=d(s[0], s[1]), inter_mpjpe_3d=d(s[2], s[3]), collision_ave=d(s[4], s[6]), collision_max=d(s[5], s[6]))
+        if len(s) > 8:
+            out["mpvpe_3d"] = d(s[7], s[8])
+        return out
 
     @property
     def mpjpe_3d(self): return self.metrics_from_sums(self.metric_sums())["mpjpe_3d"]
@@ -140,3 +196,5 @@ class Evaluator:
     def collision_ave(self): return self.metrics_from_sums(self.metric_sums())["collision_ave"]
     @property
     def collision_max(self): return self.metrics_from_sums(self.metric_sums())["collision_max"]
+    @property
+    def mpvpe_3d(self): return self.metrics_from_sums(self.metric_sums())["mpvpe_3d"]

@@ -20,8 +20,13 @@ LIB_PATH = osp.join(_HERE, "libihmr_hip.so")
 SRC_DIR = osp.join(_HERE, "csrc")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"]
 
-NUM_VERTS, NUM_FACES, NUM_JOINTS, OPT_PMAX = 778, 1538, 16, 90
-GROUP_TRANS, GROUP_ORIENT, GROUP_POSE, GROUP_SHAPE = 0, 1, 2, 3
+NUM_VERTS, NUM_FACES, NUM_JOINTS, OPT_NPARAM = 778, 1538, 16, 122
+# include/ihmr_hip.h: parameter blocks (slot order of the 122-vector), filter / select losses, optimizers
+PARAM_BLOCKS = dict(pred_cam_params=(1, 0, 3), pred_hand_trans=(2, 3, 3), pred_right_orient=(4, 6, 3), pred_left_orient=(8, 9, 3),
+                    pred_right_pose_params=(16, 12, 45), pred_left_pose_params=(32, 57, 45),
+                    pred_right_shape_params=(64, 102, 10), pred_left_shape_params=(128, 112, 10))   # name -> (bit, first slot, size)
+LOSS_IDS = dict(joints_2d_loss_p=0, joints_3d_loss_p=1, collision_loss=2)
+OPTIMIZERS = dict(adam=0, sgd=1)
 
 # every symbol include/ihmr_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = [
@@ -29,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "ihmr_mano_lbs_bwd",
     "ihmr_sdf_workspace_bytes", "ihmr_sdf_collision", "ihmr_sdf_dense_grid", "ihmr_opt_workspace_bytes",
     "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_opt_sdf_stats", "ihmr_opt_stage_graph_create",
-    "ihmr_opt_forward_graph_create", "ihmr_graph_launch", "ihmr_graph_destroy", "ihmr_opt_set_params", "ihmr_eval_metrics", "ihmr_conv_igemm", "ihmr_maxpool3x3s2",
+    "ihmr_opt_forward_graph_create", "ihmr_graph_launch", "ihmr_graph_destroy", "ihmr_opt_set_params", "ihmr_eval_metrics", "ihmr_eval_mpvpe", "ihmr_conv_igemm", "ihmr_maxpool3x3s2",
     "ihmr_avgpool_relu", "ihmr_preprocess_images", "ihmr_mlp_train_grad", "ihmr_transpose", "ihmr_relu_backward", "ihmr_colsum",
     "ihmr_adam_step", "ihmr_bn_workspace_bytes", "ihmr_bn_train_forward", "ihmr_bn_train_backward", "ihmr_conv_wgrad",
     "ihmr_dilate2", "ihmr_interleave2", "ihmr_pack_dgrad_weight", "ihmr_maxpool3x3s2_backward", "ihmr_avgpool_relu_backward", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
@@ -48,6 +53,11 @@ class OptIO(C.Structure):
         "hand_type_array",
         "verts", "joints_3d", "joints_2d", "loss_batch", "coll_per_vert", "coll_origin_scale",
         "snap_params", "snap_loss", "selected", "adam_m", "adam_v", "workspace")] + [("norm_batch", C.c_int)]
+
+
+class OptStage(C.Structure):
+    _fields_ = [("param_mask", C.c_int), ("optimizer", C.c_int), ("lr", C.c_float), ("n_iters", C.c_int), ("save_freq", C.c_int),
+                ("use_filter", C.c_int * 3), ("filter_factor", C.c_float * 3), ("select_loss", C.c_int)]
 
 
 class OptWeights(C.Structure):
@@ -81,13 +91,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
 _LIB = None
 
 
+def _resolve_library() -> str:
+    """The product library.  `IHMR_HIP_LIBRARY` selects another build (profiling / A-B scripts use it instead of
+    overwriting the product .so); otherwise the in-tree library, rebuilt when it is missing or older than its sources
+    (hipcc present) -- a stale .so is never loaded silently."""
+    override = os.environ.get("IHMR_HIP_LIBRARY")
+    if override:
+        if not osp.isfile(override):
+            raise FileNotFoundError(f"IHMR_HIP_LIBRARY={override} does not exist")
+        return override
+    import shutil
+    if shutil.which("hipcc"):
+        return build()
+    if not osp.isfile(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} is missing and hipcc is not available to build it")
+    return LIB_PATH
+
+
 def lib():
     """Load (building on demand when hipcc is present).  Raises if unavailable -- never falls back."""
     global _LIB
     if _LIB is None:
-        if not osp.isfile(LIB_PATH):
-            build()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(_resolve_library())
         vp, i, f = C.c_void_p, C.c_int, C.c_float
         L.ihmr_mano_create.argtypes = [C.POINTER(ManoArrays), C.POINTER(vp)]
         L.ihmr_mano_destroy.argtypes = [vp]
@@ -102,13 +127,14 @@ def lib():
         L.ihmr_sdf_dense_grid.argtypes = [vp, vp, vp, i, vp, vp, vp]
         L.ihmr_opt_workspace_bytes.argtypes = [i]
         L.ihmr_opt_workspace_bytes.restype = C.c_size_t
-        L.ihmr_opt_run_stage.argtypes = [vp, vp, C.POINTER(OptIO), i, i, C.POINTER(OptWeights), f, i, i, f, f, i, vp]
+        L.ihmr_opt_run_stage.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(OptStage), vp]
         L.ihmr_opt_forward_losses.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), vp]
-        L.ihmr_opt_stage_graph_create.argtypes = [vp, vp, C.POINTER(OptIO), i, i, C.POINTER(OptWeights), f, i, i, f, f, i, C.POINTER(vp)]
+        L.ihmr_opt_stage_graph_create.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(OptStage), C.POINTER(vp)]
         L.ihmr_opt_forward_graph_create.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(vp)]
         L.ihmr_graph_launch.argtypes = [vp, vp]
         L.ihmr_opt_set_params.argtypes = [C.POINTER(OptIO), vp, i, vp]
         L.ihmr_eval_metrics.argtypes = [vp, vp, vp, vp, vp, i, vp, vp]
+        L.ihmr_eval_mpvpe.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, vp]
         L.ihmr_graph_destroy.argtypes = [vp]
         L.ihmr_conv_igemm.argtypes = [vp, vp, vp, vp, vp] + [i] * 16 + [vp, C.c_size_t, vp]
         L.ihmr_maxpool3x3s2.argtypes = [vp, vp, i, i, i, i, i, i, vp]

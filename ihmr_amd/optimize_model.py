@@ -28,35 +28,52 @@ from . import hip
 from . import mano as mano_shim
 from .strategies import OPT_DEFAULT_LOSS_WEIGHTS, get_strategy
 
-_GROUPS = {
-    ("pred_hand_trans",): hip.GROUP_TRANS,
-    ("pred_left_orient", "pred_right_orient"): hip.GROUP_ORIENT,
-    ("pred_left_pose_params", "pred_right_pose_params"): hip.GROUP_POSE,
-    ("pred_left_shape_params", "pred_right_shape_params"): hip.GROUP_SHAPE,
-}
-
-
 def _filter_factor(criterion: str) -> float:
     """utils/opt_utils.py:104-114: bar = origin * (1 + (float(c) + 0.1) / 100), evaluated in float32."""
-    assert criterion[0] in "+-"
+    if not (isinstance(criterion, str) and criterion and criterion[0] in "+-"):
+        raise ValueError(f"filter criterion {criterion!r}: the reference requires a signed percentage string such as '+0' or '-10'")
     return float(np.float32(1 + (float(criterion) + 0.1) / 100))
 
 
-def stage_to_args(stage):
-    names = tuple(sorted(stage["update_params"]))
-    if names not in _GROUPS:
-        raise ValueError(f"unsupported update_params {stage['update_params']}")
-    filt = dict(stage["filter_loss"])
-    for k in filt:
-        if k not in ("joints_3d_loss_p", "collision_loss"):
-            raise ValueError(f"unsupported filter loss {k}")
-    if stage["select_loss"] not in ("joints_3d_loss_p", "collision_loss"):
-        raise ValueError(f"unsupported select loss {stage['select_loss']}")
-    big = float(np.float32(3.0e38))  # "no filter on this loss"
-    return dict(group=_GROUPS[names],
-                fac_j3d=_filter_factor(filt["joints_3d_loss_p"]) if "joints_3d_loss_p" in filt else big,
-                fac_coll=_filter_factor(filt["collision_loss"]) if "collision_loss" in filt else big,
-                select_on_collision=int(stage["select_loss"] == "collision_loss"))
+def _loss_id(name: str, field: str) -> int:
+    """utils/opt_utils.py:57-67 + optimize_model.py:366-371: a criterion must not be GT-based and needs a `_batch` twin."""
+    if name in ("joints_3d_loss", "joints_2d_loss", "hand_trans_loss"):
+        raise ValueError(f"stage['{field}']: '{name}' is computed from the ground truth; the reference (opt_utils.check_valid_loss) "
+                         "forbids it as a filter / select criterion")
+    if name not in hip.LOSS_IDS:
+        raise ValueError(f"stage['{field}']: no per-sample loss '{name}_batch' exists in OptimizeModel "
+                         f"(available: {sorted(hip.LOSS_IDS)})")
+    return hip.LOSS_IDS[name]
+
+
+def stage_to_args(stage, optimizer="adam", save_mid_freq=1) -> hip.OptStage:
+    """A strategy entry (strategies/opt_default.py) + opt.optimizer / opt.save_mid_freq -> the C ABI's ``ihmr_opt_stage``."""
+    mask = 0
+    for name in stage["update_params"]:
+        if name not in hip.PARAM_BLOCKS:
+            raise ValueError(f"stage['update_params']: '{name}' is not a refinable parameter of OptimizeModel "
+                             f"(leaf tensors of optimize_model.py:235-251: {sorted(hip.PARAM_BLOCKS)})")
+        mask |= hip.PARAM_BLOCKS[name][0]
+    if mask == 0:
+        raise ValueError("stage['update_params'] is empty")
+    if optimizer not in hip.OPTIMIZERS:
+        raise ValueError(f"opt.optimizer = {optimizer!r}: the reference knows 'adam' and 'sgd' (optimize_model.py:343-347)")
+    if len(stage["filter_loss"]) == 0:
+        raise ValueError("stage['filter_loss'] is empty (opt_utils.filter_by_losses asserts at least one criterion)")
+    sg = hip.OptStage(param_mask=mask, optimizer=hip.OPTIMIZERS[optimizer], lr=float(stage["lr"]), n_iters=int(stage["epoch"]) + 1,
+                      save_freq=int(save_mid_freq), select_loss=_loss_id(stage["select_loss"], "select_loss"))
+    for l in range(3):
+        sg.use_filter[l], sg.filter_factor[l] = 0, 1.0
+    for name, criterion in stage["filter_loss"]:
+        l, fac = _loss_id(name, "filter_loss"), _filter_factor(criterion)
+        # losses are non-negative, so two criteria on one loss keep what the stricter one keeps
+        sg.filter_factor[l] = min(sg.filter_factor[l], fac) if sg.use_filter[l] else fac
+        sg.use_filter[l] = 1
+    return sg
+
+
+def _stage_key(sg: hip.OptStage):
+    return (sg.param_mask, sg.optimizer, sg.lr, sg.n_iters, sg.save_freq, tuple(sg.use_filter), tuple(sg.filter_factor), sg.select_loss)
 
 
 def _weights(w) -> hip.OptWeights:
@@ -92,7 +109,7 @@ class OptimizeModel:
         self.norm_batch = int(opt.batchSize)
         self.batch_size = self.norm_batch * self.fuse_batches
         assert opt.total_params_dim == opt.cam_params_dim + opt.trans_params_dim + opt.pose_params_dim + opt.shape_params_dim
-        assert getattr(opt, "optimizer", "adam") == "adam", "the fused refinement step implements Adam (the reference default)"
+        self.optimizer = getattr(opt, "optimizer", "adam")
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.load_mano_model()
         epoch = getattr(opt, "opt_epoch", None)
@@ -128,8 +145,8 @@ class OptimizeModel:
             gt_joints_2d=z(B, 42, 3), gt_joints_3d=z(B, 42, 4), gt_hand_trans=z(B, 4), hand_type_array=z(B, 2),
             verts=z(2, B, 778, 3), joints_3d=z(B, 42, 3), joints_2d=z(B, 42, 2), loss_batch=z(8, B),
             coll_per_vert=z(B, 1556), coll_origin_scale=z(B, 1556),
-            snap_params=z(self.S_max, B, hip.OPT_PMAX), snap_loss=z(self.S_max, 2, B),
-            selected=torch.zeros(B, device=dev, dtype=torch.int32), adam_m=z(B, hip.OPT_PMAX), adam_v=z(B, hip.OPT_PMAX),
+            snap_params=z(self.S_max, B, hip.OPT_NPARAM), snap_loss=z(self.S_max, 3, B),
+            selected=torch.zeros(B, device=dev, dtype=torch.int32), adam_m=z(B, hip.OPT_NPARAM), adam_v=z(B, hip.OPT_NPARAM),
             workspace=torch.empty(hip.lib().ihmr_opt_workspace_bytes(B), device=dev, dtype=torch.uint8),
         )
         self.io = hip.OptIO(**{k: v.data_ptr() for k, v in self.buf.items()}, norm_batch=self.norm_batch)
@@ -197,24 +214,21 @@ class OptimizeModel:
         return dict(ray_tests=int(out[0]), dist_evals=int(out[1]), inside_voxels=int(out[2]), needed_voxels=int(out[3]))
 
     def run_stage(self, stage):
-        a = stage_to_args(stage)
+        sg = stage_to_args(stage, self.optimizer, self.save_mid_freq)
+        if (sg.n_iters - 1) // sg.save_freq + 1 > self.S_max:
+            raise ValueError("stage takes more snapshots than the ring allocated at construction holds")
         w = _weights(stage["loss_weights"])
         mr, ml = self._mano_handles()
         if self.use_graphs:
-            key = ("stage", a["group"], float(stage["lr"]), int(stage["epoch"]), int(self.save_mid_freq), a["fac_j3d"], a["fac_coll"],
-                   a["select_on_collision"]) + tuple(sorted(stage["loss_weights"].items()))
+            key = ("stage",) + _stage_key(sg) + tuple(sorted(stage["loss_weights"].items()))
             if key not in self._graphs:
                 g = C.c_void_p()
-                hip.check(hip.lib().ihmr_opt_stage_graph_create(mr, ml, C.byref(self.io), self.batch_size, a["group"], C.byref(w),
-                                                                float(stage["lr"]), int(stage["epoch"]) + 1, int(self.save_mid_freq),
-                                                                a["fac_j3d"], a["fac_coll"], a["select_on_collision"], C.byref(g)),
-                          "ihmr_opt_stage_graph_create")
+                hip.check(hip.lib().ihmr_opt_stage_graph_create(mr, ml, C.byref(self.io), self.batch_size, C.byref(w), C.byref(sg),
+                                                                C.byref(g)), "ihmr_opt_stage_graph_create")
                 self._graphs[key] = g
             hip.check(hip.lib().ihmr_graph_launch(self._graphs[key], hip.stream_ptr()), "ihmr_graph_launch")
             return
-        hip.check(hip.lib().ihmr_opt_run_stage(mr, ml, C.byref(self.io), self.batch_size, a["group"], C.byref(w),
-                                               float(stage["lr"]), int(stage["epoch"]) + 1, int(self.save_mid_freq),
-                                               a["fac_j3d"], a["fac_coll"], a["select_on_collision"], hip.stream_ptr()),
+        hip.check(hip.lib().ihmr_opt_run_stage(mr, ml, C.byref(self.io), self.batch_size, C.byref(w), C.byref(sg), hip.stream_ptr()),
                   "ihmr_opt_run_stage")
 
     # optimize_model.py:390-415
@@ -263,6 +277,8 @@ class OptimizeModel:
     def collision_loss_origin_scale(self): return self.buf["coll_origin_scale"]
     @property
     def joints_3d_loss_p_batch(self): return self.buf["loss_batch"][1]
+    @property
+    def joints_2d_loss_p_batch(self): return self.buf["loss_batch"][0]
 
     def _export_sources(self):
         return OrderedDict(

@@ -109,12 +109,12 @@ typedef struct ihmr_opt_io {
     float* coll_per_vert;     /* (B,1556) */
     float* coll_origin_scale; /* (B,1556) */
     /* snapshot ring (S_max, B, *) and stage selection */
-    float* snap_params;  /* (S_max, B, 90) active parameters, right hand first */
-    float* snap_loss;    /* (S_max, 2, B): joints_3d_loss_p_batch, collision_loss_batch */
+    float* snap_params;  /* (S_max, B, 122) parameter slots in IHMR_PB_* block order; only the stage's blocks are written */
+    float* snap_loss;    /* (S_max, 3, B): rows IHMR_LOSS_* = joints_2d_loss_p_batch, joints_3d_loss_p_batch, collision_loss_batch */
     int32_t* selected;   /* (B) argmin index of the last stage */
-    /* Adam state, zeroed by the first kernel of every stage */
-    float* adam_m;       /* (B,90) */
-    float* adam_v;       /* (B,90) */
+    /* optimizer state, zeroed by the first kernel of every stage (a fresh torch.optim.* per stage, optimize_model.py:343-347) */
+    float* adam_m;       /* (B,122) Adam exp_avg / SGD momentum buffer */
+    float* adam_v;       /* (B,122) Adam exp_avg_sq */
     void* workspace;     /* ihmr_opt_workspace_bytes(B) */
     /* batch size the reference's batch-mean losses are averaged over (optimize_model.py:276-330); 0 = B.
        With norm_batch = 64 and B = k * 64 one launch carries k independent batches of 64, each with exactly the
@@ -126,18 +126,39 @@ typedef struct ihmr_opt_weights { /* strategies/opt_default.py loss_weights */
     float joints_2d, joints_3d, trans, shape_reg, collision, finger_reg;
 } ihmr_opt_weights;
 
-enum { IHMR_GROUP_TRANS = 0, IHMR_GROUP_ORIENT = 1, IHMR_GROUP_POSE = 2, IHMR_GROUP_SHAPE = 3, IHMR_GROUP_NONE = 4 };
+/* The refinable parameters of a sample are 122 slots in eight blocks, in this order (= the slot order of snap_params /
+ * adam_m / adam_v); a stage's `update_params` list (strategies/opt_default.py) is a set of blocks:
+ *   pred_cam_params 3 | pred_hand_trans 3 | pred_right_orient 3 | pred_left_orient 3 | pred_right_pose_params 45 |
+ *   pred_left_pose_params 45 | pred_right_shape_params 10 | pred_left_shape_params 10 */
+#define IHMR_OPT_NPARAM 122
+enum { IHMR_PB_CAM = 1, IHMR_PB_TRANS = 2, IHMR_PB_ORIENT_R = 4, IHMR_PB_ORIENT_L = 8, IHMR_PB_POSE_R = 16, IHMR_PB_POSE_L = 32,
+       IHMR_PB_SHAPE_R = 64, IHMR_PB_SHAPE_L = 128 };
+/* the per-sample losses a stage may filter / select on: every non-GT loss with a `_batch` twin (utils/opt_utils.py:57-67,
+ * optimize_model.py:366-371); the values are the rows of io->loss_batch */
+enum { IHMR_LOSS_JOINTS_2D_P = 0, IHMR_LOSS_JOINTS_3D_P = 1, IHMR_LOSS_COLLISION = 2 };
+enum { IHMR_OPTIM_ADAM = 0, IHMR_OPTIM_SGD = 1 };
+
+/* one entry of a strategy (strategies/opt_default.py:3-78) + the two options that shape a stage */
+typedef struct ihmr_opt_stage {
+    int param_mask;          /* IHMR_PB_* bits: stage['update_params'] */
+    int optimizer;           /* opt.optimizer: Adam(lr, betas 0.9 / 0.999, eps 1e-8) or SGD(lr, momentum 0.9) (optimize_model.py:343-347) */
+    float lr;                /* stage['lr'] */
+    int n_iters;             /* stage['epoch'] + 1 (optimize_model.py:397) */
+    int save_freq;           /* opt.save_mid_freq: snapshot before the step at iterations 0, f, 2f, ... (:401-403) */
+    int use_filter[3];       /* per IHMR_LOSS_*: stage['filter_loss'] holds a criterion on that loss */
+    float filter_factor[3];  /* float32(1 + (float(criterion) + 0.1) / 100): keep snapshots with loss <= origin * factor
+                                (utils/opt_utils.py:104-114); several criteria on one loss = the smallest factor */
+    int select_loss;         /* IHMR_LOSS_*: stage['select_loss'], per-sample first argmin over the kept snapshots */
+} ihmr_opt_stage;
 
 size_t ihmr_opt_workspace_bytes(int B);
 /* `m` = right-hand model (used for both hands, optimize_model.py:194); `m_left` supplies only the left
  * faces for the collision term (loss_utils.py:34-38), NULL = use the right faces.
- * one stage of optimize() (:393-407): `n_iters` = epoch+1 iterations of forward -> losses ->
- * snapshot (every save_freq, before the step) -> backward -> Adam(lr, 0.9, 0.999, eps 1e-8).
- * Then (:377-387) filter (loss <= origin * factor for both criteria) + per-sample argmin of the
- * joints_3d_loss_p snapshots, and write the selected parameters back. */
-int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, int group,
-                       const ihmr_opt_weights* w, float lr, int n_iters, int save_freq, float filter_factor_j3d, float filter_factor_coll,
-                       int select_on_collision, void* stream);
+ * one stage of optimize() (:393-407): `n_iters` iterations of forward -> losses -> snapshot -> backward -> optimizer
+ * step on the stage's parameter blocks.  Then (:377-387) filter + per-sample argmin of the select loss over the
+ * snapshots, and write the selected parameters back. */
+int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                       const ihmr_opt_weights* w, const ihmr_opt_stage* stage, void* stream);
 /* forward() + __compute_loss(weights) only (:413-414), no step */
 int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                             const ihmr_opt_weights* w, void* stream);
@@ -146,9 +167,8 @@ int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_left, const i
  * per-iteration Adam constants are baked into the nodes), replay with ihmr_graph_launch.  *_create allocate
  * (graph instantiation) and must not be called inside a capture; launch is asynchronous on `stream`. */
 typedef struct ihmr_graph ihmr_graph;
-int ihmr_opt_stage_graph_create(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, int group,
-                                const ihmr_opt_weights* w, float lr, int n_iters, int save_freq, float filter_factor_j3d,
-                                float filter_factor_coll, int select_on_collision, ihmr_graph** out);
+int ihmr_opt_stage_graph_create(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
+                                const ihmr_opt_weights* w, const ihmr_opt_stage* stage, ihmr_graph** out);
 int ihmr_opt_forward_graph_create(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                                   const ihmr_opt_weights* w, ihmr_graph** out);
 int ihmr_graph_launch(ihmr_graph* g, void* stream);
@@ -188,6 +208,15 @@ int ihmr_avgpool_relu(const float* x, float* y, int N, int HW, int C, int ldy, v
  * out6 (B,6) float64: [sum MPJPE errors, count, sum aligned errors, count, mean depth mm, max depth mm]. */
 int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_joints_3d, const float* coll_origin_scale,
                       const float* sample_scale, const unsigned char* interacting, int B, double* out6, void* stream);
+
+/* MPVPE (named by BASELINE.json; the reference exports predicted and GT meshes -- models/baseline_model.py:365-368,
+ * models/mlp_model.py:708-711 -- but computes no vertex metric).  Same convention as the MPJPE above
+ * (utils/metric_utils.py:23-38): per hand, root-relative, L2 per point, / scale; a mesh's root is its wrist regressed with
+ * row 0 of the MANO joint regressor: root_weights (2,778) [right, left].  Meshes (B,778,3); mano_params_weight (B,2): a hand
+ * counts when its weight is > 0 (a GT mesh exists).  out4 (B,4) float64: [sum right, count right, sum left, count left]. */
+int ihmr_eval_mpvpe(const float* pred_right, const float* pred_left, const float* gt_right, const float* gt_left,
+                    const float* root_weights, const float* mano_params_weight, const float* sample_scale, int B,
+                    double* out4, void* stream);
 
 /* ------------------------------------------------------------------ IHMR-MLP training step */
 /* Gradient of the training objective `MLPModel.compute_loss(stage['loss_weights'])` (models/mlp_model.py:514-583)

@@ -40,7 +40,7 @@ def filter_by_losses(all_losses, filter_losses):
     filter; others -> 1e11; row 0 (the stage's starting point) restored."""
     origin = {n: all_losses[n][0].clone().reshape(1, -1) for n in all_losses}
     first = next(iter(all_losses.values()))
-    keep = torch.ones(first.size(), dtype=torch.bool)
+    keep = torch.ones(first.size(), dtype=torch.bool, device=first.device)
     for name, crit in filter_losses:
         assert crit[0] in "+-"
         percent = (float(crit) + 0.1) / 100
@@ -54,34 +54,48 @@ def filter_by_losses(all_losses, filter_losses):
 def select_params(all_params, all_losses, select_loss_name):
     """opt_utils.py:144-153: per-sample argmin over the snapshot axis."""
     idxs = torch.argmin(all_losses[select_loss_name], dim=0)
-    ar = torch.arange(idxs.numel()).long()
+    ar = torch.arange(idxs.numel(), device=idxs.device).long()
     return {n: p[idxs, ar, ...] for n, p in all_params.items()}, idxs
 
 
 # ----------------------------------------------------------------------------- optimize_model.py
 class OptimizeRef:
     def __init__(self, mano_right_arrays, mano_left_arrays, batch_size, strategy, save_mid_freq=1,
-                 default_loss_weights=None, record=False):
+                 default_loss_weights=None, record=False, optimizer="adam", smplx_create=None, sdf_loss_cls=None, device="cpu"):
+        """``smplx_create`` / ``sdf_loss_cls`` / ``device``: the two third-party seams of the reference
+        (``smplx.create``, ``sdf.SDFLoss``) can be filled with another implementation -- the tests use
+        this to run THIS reference-shaped loop (autograd + torch.optim) over the product's seam-A / seam-B modules on the
+        GPU, i.e. the import-swap integration route of INTEGRATION.md.  Default: the CPU restatements."""
         self.batch_size = batch_size
-        self.mano_right = ManoRef(mano_right_arrays, batch_size=2 * batch_size)
-        self.mano_left = ManoRef(mano_left_arrays, batch_size=2 * batch_size)
-        # optimize_model.py:109-113 -- flip the left shapedirs x-sign if identical to the right
+        self.device = torch.device(device)
+        if smplx_create is None:
+            self.mano_right = ManoRef(mano_right_arrays, batch_size=2 * batch_size)
+            self.mano_left = ManoRef(mano_left_arrays, batch_size=2 * batch_size)
+        else:   # optimize_model.py:102-108
+            self.mano_right = smplx_create("", "mano", use_pca=False, is_rhand=True, batch_size=2 * batch_size)
+            self.mano_left = smplx_create("", "mano", use_pca=False, is_rhand=False, batch_size=2 * batch_size)
+        # optimize_model.py:109-113 -- flip the left shapedirs x-sign if identical to the right (IN PLACE, before .cuda())
         d = torch.mean(torch.abs(self.mano_left.shapedirs[:, 0, :] - self.mano_right.shapedirs[:, 0, :]))
         if d < 1e-7:
             self.mano_left.shapedirs[:, 0, :] *= -1
-        self.sdf = SDFLossRef(self.mano_right.faces, self.mano_left.faces, robustifier=None)
+        if self.device.type == "cuda":   # optimize_model.py:114-117, loss_utils.py:38
+            self.mano_right, self.mano_left = self.mano_right.cuda(), self.mano_left.cuda()
+        self.sdf = (sdf_loss_cls or SDFLossRef)(self.mano_right.faces, self.mano_left.faces, robustifier=None)
+        if self.device.type == "cuda":
+            self.sdf = self.sdf.cuda()
         self.strategy = strategy
         self.save_mid_freq = save_mid_freq
         self.default_loss_weights = default_loss_weights or dict(
             joints_2d_loss=10.0, joints_3d_loss=1000.0, trans_loss_weight=100.0,
             shape_reg_loss_weight=0.1, collision_loss_weight=1.0, finger_reg_loss_weight=100000.0)
         self.record = record
+        self.optimizer_name = optimizer
         self.trace = []
         self.selected = []
 
     # optimize_model.py:120-168
     def set_input(self, data):
-        f = lambda k: data[k].detach().clone().float()
+        f = lambda k: data[k].detach().clone().float().to(self.device)
         self.hand_type_array = f("hand_type_array")
         self.joints_2d = f("joints_2d")
         self.joints_3d = f("joints_3d")
@@ -181,7 +195,11 @@ class OptimizeRef:
                 p = getattr(self, name)
                 p.requires_grad = True
                 params.append(p)
-            optimizer = torch.optim.Adam(params, lr=stage["lr"], betas=(0.9, 0.999))
+            if self.optimizer_name == "adam":   # optimize_model.py:343-347
+                optimizer = torch.optim.Adam(params, lr=stage["lr"], betas=(0.9, 0.999))
+            else:
+                assert self.optimizer_name == "sgd"
+                optimizer = torch.optim.SGD(params, lr=stage["lr"], momentum=0.9)
             mid = []
             for j in range(stage["epoch"] + 1):
                 self.forward()
@@ -196,14 +214,14 @@ class OptimizeRef:
                 if self.record:
                     self.trace.append(dict(
                         loss=float(self.loss.detach()),
-                        grads={n: getattr(self, n).grad.detach().clone().numpy() for n in stage["update_params"]},
-                        j3d_batch=self.joints_3d_loss_p_batch.detach().clone().numpy(),
-                        coll_batch=self.collision_loss_batch.detach().clone().numpy()))
+                        grads={n: getattr(self, n).grad.detach().clone().cpu().numpy() for n in stage["update_params"]},
+                        j3d_batch=self.joints_3d_loss_p_batch.detach().clone().cpu().numpy(),
+                        coll_batch=self.collision_loss_batch.detach().clone().cpu().numpy()))
                 optimizer.step()
             all_params, all_losses = gather_params_losses(mid, stage)
             all_losses = filter_by_losses(all_losses, stage["filter_loss"])
             sel, idxs = select_params(all_params, all_losses, stage["select_loss"])
-            self.selected.append(idxs.numpy().copy())
+            self.selected.append(idxs.cpu().numpy().copy())
             for n, v in sel.items():
                 setattr(self, n, v)
         self.forward()

@@ -2,11 +2,10 @@
 # A/B of library builds at a launch batch: usage ab_batch.sh <B> lib1.so lib2.so ...
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 B=$1; shift
-cp ihmr_amd/libihmr_hip.so /tmp/keep.so
 for lib in "$@"; do
-  cp $lib ihmr_amd/libihmr_hip.so; echo "== $lib (B=$B)"
+  export IHMR_HIP_LIBRARY=$(realpath $lib); echo "== $lib (B=$B)"
   rm -rf gpurun_out/pb; timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/pb -o pb -- python3 bench.py --steps 2 --warmup 1 --streams 1 --fuse 1 --batch $B --no-cpu-baseline 2>&1 | tail -1 | cut -c95-135
   python3 scripts/rocprof_summary.py gpurun_out/pb/pb_results.db /tmp/pb.csv | grep -E "${ABK:-skin}"
   timeout 200 python3 bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c95-140
 done
-cp /tmp/keep.so ihmr_amd/libihmr_hip.so; rm -rf gpurun_out/pb
+rm -rf gpurun_out/pb

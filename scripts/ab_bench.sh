@@ -1,9 +1,7 @@
 #!/bin/bash
 # default bench.py, 3 runs per library build: usage ab_bench.sh lib1.so lib2.so ...
 cd $GRAFT_REPO_ROOT
-cp ihmr_amd/libihmr_hip.so /tmp/keep.so
 for r in 1 2 3; do for lib in "$@"; do
-  cp $lib ihmr_amd/libihmr_hip.so; echo -n "$lib run $r: "
+  export IHMR_HIP_LIBRARY=$(realpath $lib); echo -n "$lib run $r: "
   timeout 200 python3 bench.py --no-cpu-baseline --steps 64 --warmup 16 2>&1 | tail -1 | python3 -c "import sys,json; print(round(json.loads(sys.stdin.read())['value']))"
 done; done
-cp /tmp/keep.so ihmr_amd/libihmr_hip.so

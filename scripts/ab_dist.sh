@@ -2,7 +2,7 @@
 # A/B of library builds: usage ab_dist.sh lib1.so lib2.so ...
 cd $GRAFT_REPO_ROOT
 for lib in "$@"; do
-  cp $lib ihmr_amd/libihmr_hip.so
+  export IHMR_HIP_LIBRARY=$(realpath $lib)
   echo "== $lib"
   cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
   rm -rf gpurun_out/ab; timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/ab -o ab -- python3 bench.py --steps 4 --warmup 2 --streams 1 --no-cpu-baseline 2>&1 | tail -1 | cut -c95-135

@@ -177,6 +177,78 @@ def gen_opt_traj(ns):
     print("opt_traj.npz", {k: np.asarray(v).shape for k, v in res.items() if k.startswith("pred_")})
 
 
+def _ref_opt_run(ns, B, strategy, freq, batch, optimizer="adam"):
+    """One pass of the reference's own OptimizeModel over `batch`; returns the dict stored in the fixture."""
+    ns.strategies.strategies["golden_tmp"] = strategy
+    ns.optimize_model.strategies["golden_tmp"] = strategy
+    opt = make_opt(B, strategy="golden_tmp", save_mid_freq=freq)
+    opt.optimizer = optimizer
+    ref = ns.optimize_model.OptimizeModel(opt)
+    ref.set_input(batch)
+    ref.init_optimize()
+    ref.optimize(0, 1)
+    res = ref.get_pred_result()
+    out = {f"in_{k}": v for k, v in batch.items()}
+    out.update({f"out_{k}": v for k, v in res.items()})
+    out["out_pred_joints_2d"] = ref.pred_joints_2d.detach()
+    out["out_joints_3d_loss_p_batch"] = ref.joints_3d_loss_p_batch.detach()
+    out["out_joints_2d_loss_p_batch"] = ref.joints_2d_loss_p_batch.detach()
+    out["out_loss"] = ref.loss.detach()
+    return out
+
+
+def _synthetic_batch(B, seed):
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    from oracle.opt_ref import OptimizeRef
+    from ihmr_amd.assets import synthetic_mano
+    helper = OptimizeRef(synthetic_mano(True), synthetic_mano(False), B, [], save_mid_freq=1)
+
+    def fwd(pose, shape, trans):
+        helper.pred_right_orient, helper.pred_left_orient = pose[:, :3], pose[:, 48:51]
+        helper.pred_right_pose_params, helper.pred_left_pose_params = pose[:, 3:48], pose[:, 51:]
+        helper.pred_right_shape_params, helper.pred_left_shape_params = shape[:, :10], shape[:, 10:]
+        helper.pred_hand_trans = trans.view(-1, 1, 3)
+        return helper.get_mano_output()[2]
+
+    return synthetic_opt_batch(B, fwd, seed=seed)
+
+
+def gen_opt_traj_ragged(ns):
+    """The reference's OptimizeModel.optimize() on a RAGGED batch (tests/helpers.py:ragged_opt_batch: single-hand samples,
+    missing / half-weight wrists, zero-weight joints, no 3-D target, separated hands): B=8, 4 stages x 4 iterations,
+    snapshot every 2."""
+    from helpers import ragged_opt_batch
+    from ihmr_amd.strategies import make_opt_strategy
+    B, epoch, freq = 8, 3, 2
+    batch = ragged_opt_batch(_synthetic_batch(B, 777))
+    out = _ref_opt_run(ns, B, make_opt_strategy(epoch), freq, batch)
+    out["meta_epoch_freq"] = np.array([epoch, freq])
+    np.savez_compressed(osp.join(HERE, "opt_traj_ragged.npz"), **t2n(out))
+    print("opt_traj_ragged.npz", float(out["out_loss"]))
+
+
+def gen_opt_traj_variants(ns):
+    """Two more passes of the reference's OptimizeModel (B=3, 4 x 6 iterations, snapshot every 2): (a) Adam with the
+    non-default filter / select criteria of `variant_strategy`, (b) `--optimizer sgd` (torch.optim.SGD, momentum 0.9,
+    optimize_model.py:345-347) with the default criteria.  Sample 2 has separated hands (origin collision loss 0)."""
+    from helpers import variant_strategy
+    from ihmr_amd.strategies import make_opt_strategy
+    B, epoch, freq = 3, 5, 2
+    batch = _synthetic_batch(B, 555)
+    batch["init_hand_trans"][2, 0, 0] += 0.4
+    out = {}
+    for tag, strategy, optimizer in (("crit", variant_strategy(epoch), "adam"), ("sgd", make_opt_strategy(epoch), "sgd")):
+        r = _ref_opt_run(ns, B, strategy, freq, {k: v.clone() for k, v in batch.items()}, optimizer)
+        for k, v in r.items():
+            if k.startswith("in_"):
+                out[k] = v
+            elif "verts" not in k:
+                out[f"{tag}_{k}"] = v
+    out["meta_epoch_freq"] = np.array([epoch, freq])
+    np.savez_compressed(osp.join(HERE, "opt_traj_variants.npz"), **t2n(out))
+    print("opt_traj_variants.npz", float(out["crit_out_loss"]), float(out["sgd_out_loss"]))
+
+
 from helpers import seeded_state_dict  # tests/helpers.py (shared with the tests)
 
 
@@ -422,6 +494,6 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ns = import_reference()
-    which = sys.argv[1:] or ["losses", "select", "opt_traj", "encoder", "mlp_head", "metrics", "mlp_test", "preprocess", "mlp_train", "encoder_train"]
+    which = sys.argv[1:] or ["losses", "select", "opt_traj", "opt_traj_ragged", "opt_traj_variants", "encoder", "mlp_head", "metrics", "mlp_test", "preprocess", "mlp_train", "encoder_train"]
     for w in which:
         globals()[f"gen_{w}"](ns)

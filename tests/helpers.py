@@ -30,3 +30,64 @@ def seeded_state_dict(module, seed, last_scale=None):
         new[last] = new[last] * last_scale
         new[last.replace('weight', 'bias')] = new[last.replace('weight', 'bias')] * last_scale
     return new
+
+
+def ragged_opt_batch(batch):
+    """Turn a synthetic IHMR-OPT batch (>= 8 samples, ``ihmr_amd.synthetic.synthetic_opt_batch``) into a RAGGED one, in
+    place, covering the branches the reference's loss code takes on real annotation
+    (``loss_utils.py:90-98`` root choice, ``:186-188`` hand-type mask, zero joint weights):
+
+      0  both hands, fully annotated (control)
+      1  right hand only  (hand_type [1,0]; left joints unannotated; no translation target)
+      2  left hand only   (hand_type [0,1]; right joints unannotated -> root = joint 21)
+      3  both hands, right wrist unannotated in both target sets (root = joint 21 twice)
+      4  init wrist weight 0.3 (second alignment skipped), GT wrist weight 1
+      5  GT wrist weight 0.3 (first alignment skipped), init wrist weight 0 (second one about joint 21), random
+         zero-weight joints in every target set
+      6  no 3-D target at all (every init 3-D weight 0), a few 2-D weights 0
+      7  hands 0.4 m apart: collision term exactly 0 although both hands are present
+    Samples >= 8 are left alone."""
+    B = batch["init_cam"].shape[0]
+    assert B >= 8
+    rng = np.random.RandomState(99)
+    j2, j3, i2, i3 = batch["joints_2d"], batch["joints_3d"], batch["init_joints_2d"], batch["init_joints_3d"]
+    # 1: right only
+    batch["hand_type_array"][1] = torch.tensor([1.0, 0.0])
+    for t in (j2, j3, i2, i3):
+        t[1, 21:, -1] = 0.0
+    batch["init_hand_trans_j"][1, 0, 3] = 0.0
+    batch["hand_trans"][1, 0, 3] = 0.0
+    # 2: left only
+    batch["hand_type_array"][2] = torch.tensor([0.0, 1.0])
+    for t in (j2, j3, i2, i3):
+        t[2, :21, -1] = 0.0
+    batch["init_hand_trans_j"][2, 0, 3] = 0.0
+    batch["hand_trans"][2, 0, 3] = 0.0
+    # 3: no right wrist
+    j3[3, 0, 3] = 0.0
+    i3[3, 0, 3] = 0.0
+    # 4 / 5: in-between weights
+    i3[4, 0, 3] = 0.3
+    j3[5, 0, 3] = 0.3
+    i3[5, 0, 3] = 0.0
+    for t in (j2, j3, i2, i3):
+        drop = torch.from_numpy(rng.rand(42) < 0.3)
+        drop[0] = False
+        t[5, drop, -1] = 0.0
+    # 6: no 3-D target
+    i3[6, :, 3] = 0.0
+    i2[6, torch.from_numpy(rng.rand(42) < 0.2), 2] = 0.0
+    # 7: separated hands
+    batch["init_hand_trans"][7, 0, 0] += 0.4
+    return batch
+
+
+def variant_strategy(epoch):
+    """opt_default's stages with filter / select criteria the reference accepts but its default strategy does not use
+    (utils/opt_utils.py:57-67: any loss with a `_batch` twin that is not GT-based)."""
+    from ihmr_amd.strategies import make_opt_strategy
+    st = make_opt_strategy(epoch)
+    st[0]["filter_loss"], st[0]["select_loss"] = [("joints_2d_loss_p", "+5")], "collision_loss"
+    st[1]["filter_loss"], st[1]["select_loss"] = [("collision_loss", "-10")], "joints_2d_loss_p"
+    st[3]["filter_loss"], st[3]["select_loss"] = [("joints_3d_loss_p", "+0"), ("joints_3d_loss_p", "-1"), ("joints_2d_loss_p", "+20")], "joints_3d_loss_p"
+    return st

@@ -62,8 +62,68 @@ def test_mlp_model_matches_reference_golden_and_oracle(mano_arrays):
     _report("mlp collision_loss vs reference", res["collision_loss"], g["out_collision_loss"], atol=1e-4, rtol=1e-4)
 
 
-def test_baseline_model_matches_oracle(mano_arrays):
-    """InterHandModel.test(): encoder -> separate right/left MANO -> shift -> projection -> collision metric."""
+def test_mlp_model_batch128_matches_oracle(mano_arrays):
+    """BASELINE.json's IHMR-MLP configuration (batch 128 = 256 hands through the fused forward / collision launches, the
+    Linear layers at M = 128): all six stages of MLPModel.test() against the oracle's MLPRef.test() -- per-stage
+    keep / reject decisions identical, parameters, meshes and penetration depths within the bars."""
+    from helpers import seeded_state_dict
+    from ihmr_amd.mlp_model import MLPModel
+    from ihmr_amd.strategies import make_mlp_strategy
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    from oracle.mlp_ref import MLPRef
+    from oracle.opt_ref import OptimizeRef
+    right, left = mano_arrays
+    B = 128
+    helper = OptimizeRef(right, left, B, [], save_mid_freq=1)
+
+    def fwd(pose, shape, trans):
+        helper.pred_right_orient, helper.pred_left_orient = pose[:, :3], pose[:, 48:51]
+        helper.pred_right_pose_params, helper.pred_left_pose_params = pose[:, 3:48], pose[:, 51:]
+        helper.pred_right_shape_params, helper.pred_left_shape_params = shape[:, :10], shape[:, 10:]
+        helper.pred_hand_trans = trans.view(-1, 1, 3)
+        return helper.get_mano_output()[2]
+
+    batch = synthetic_opt_batch(B, fwd, seed=128128, with_feat=True)
+    batch["init_hand_trans"] = batch["init_hand_trans"][:, 0, :3].contiguous()
+    batch["img"] = torch.zeros(B, 3, 8, 8)
+    batch.pop("init_hand_trans_j")
+    batch["joints_3d"][5, 0, 3] = 0.0
+    batch["hand_type_array"][7] = torch.tensor([1.0, 0.0])
+    strategy = make_mlp_strategy()
+    model = MLPModel(_opt(B))
+    model.set_update_info(strategy, B)
+    orc = MLPRef(right, left, B, strategy, num_data=B)
+    for sid in range(len(strategy)):
+        model.add_new_network(sid)
+        sd = seeded_state_dict(orc.nets[sid], 900 + sid, last_scale=0.02)
+        orc.nets[sid].load_state_dict(sd)
+        model.sub_network_list[sid].load_state_dict(sd)
+    model.eval()
+    model.set_input(batch)
+    model.test()
+    torch.cuda.synchronize()
+    res = model.get_pred_result()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    orc.set_input(batch)
+    orc.test()
+    ref = orc.get_pred_result()
+    kept_ref, kept_got = np.stack(orc.kept_history), torch.stack(model.kept_history).cpu().numpy()
+    print(f"[parity] MLP B=128: kept per stage ref {kept_ref.sum(1).tolist()} got {kept_got.sum(1).tolist()}")
+    assert np.array_equal(kept_ref, kept_got), "per-stage keep/reject decisions differ"
+    assert 0 < kept_ref.sum() < kept_ref.size, "the batch must exercise both decisions"
+    for k in ("pred_cam_params", "pred_pose_params", "pred_shape_params", "pred_hand_trans"):
+        _report(f"mlp128 {k}", res[k], ref[k], atol=2e-5)
+    for k in ("pred_right_hand_verts", "pred_left_hand_verts", "pred_joints_3d", "gt_right_hand_verts", "gt_left_hand_verts"):
+        _report(f"mlp128 {k} [m]", res[k], ref[k], atol=1e-5)
+    _report("mlp128 penetration depth [m]", res["collision_loss_origin_scale"], ref["collision_loss_origin_scale"], atol=1e-5)
+    _report("mlp128 collision_loss", res["collision_loss"], ref["collision_loss"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B", [2, 64])
+def test_baseline_model_matches_oracle(mano_arrays, B):
+    """InterHandModel.test(): encoder -> separate right/left MANO -> shift -> projection -> collision metric.
+    B = 64 is BASELINE.json's IHMR-Baseline configuration: the 128 x 128 tiles without split-K that the measured
+    encoder throughput comes from (at B = 2 nearly every layer takes the split-K path instead)."""
     from helpers import seeded_state_dict
     from ihmr_amd.baseline_model import InterHandModel
     from ihmr_amd.synthetic import synthetic_opt_batch
@@ -72,7 +132,6 @@ def test_baseline_model_matches_oracle(mano_arrays):
     from oracle.mano_ref import ManoRef
     from oracle.sdf_ref import SDFLossRef
     right, left = mano_arrays
-    B = 2
     model = InterHandModel(_opt(B))
     ref_enc = InterHandEncoderRef(model.mean_params.clone())
     sd = seeded_state_dict(ref_enc, 100)
@@ -100,7 +159,7 @@ def test_baseline_model_matches_oracle(mano_arrays):
     model.test()
     torch.cuda.synchronize()
     res = model.get_pred_result()
-    torch.set_num_threads(8)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
     with torch.no_grad():
         fp, hc = ref_enc(batch["img"])
         rv, lv, j3 = two(fp[:, 3:99], fp[:, 99:119], fp[:, 119:122])
@@ -116,6 +175,26 @@ def test_baseline_model_matches_oracle(mano_arrays):
     _report("baseline gt right verts [m]", res["gt_right_hand_verts"], grv, atol=1e-6)
     _report("baseline gt left verts [m]", res["gt_left_hand_verts"], glv, atol=1e-6)
     _report("baseline penetration depth [m]", res["collision_loss_origin_scale"], os_, atol=1e-4)
+    # MPVPE (BASELINE.json): host evaluator on the exported dict, device evaluator on the model's device tensors, and the
+    # plain formula on the ORACLE's meshes -- hands without a MANO annotation do not count
+    from ihmr_amd.evaluator import Evaluator
+    w = batch["mano_params_weight"].clone()
+    w[0, 1] = 0.0
+    res["mano_params_weight"] = w.numpy()
+    host, dev = Evaluator(model.mano_models), Evaluator(model.mano_models)
+    host.update(np.arange(B), res)
+    dev.update_device_verts(model.pred_right_hand_verts, model.pred_left_hand_verts, model.gt_right_hand_verts, model.gt_left_hand_verts, w.cuda())
+    errs = []
+    for h, (pv, gv, arr) in enumerate(((rv, grv, right), (lv, glv, left))):
+        rw = torch.tensor(arr["J_regressor"][0]).double()
+        d = (pv.double() - (rw @ pv.double())[:, None]) - (gv.double() - (rw @ gv.double())[:, None])
+        errs.append(d.norm(dim=2)[w[:, h] > 0].reshape(-1))
+    mpvpe_orc = float(torch.cat(errs).mean())
+    sh, sd = host.metric_sums(), dev.metric_sums()
+    print(f"[parity] MPVPE [m]: oracle meshes {mpvpe_orc:.6e} host {host.mpvpe_3d:.6e} device {dev.mpvpe_3d:.6e} (n = {int(sh[8])})")
+    assert sh[8] == sd[8] == (2 * B - 1) * 778
+    assert abs(host.mpvpe_3d - dev.mpvpe_3d) <= 2e-6 * host.mpvpe_3d
+    assert abs(host.mpvpe_3d - mpvpe_orc) < 1e-4      # BASELINE.json's bar for MPJPE / MPVPE
 
 
 @pytest.mark.gpu

@@ -1,4 +1,5 @@
 """Host-side logic that needs no GPU: prediction-file schema, refinement-batch construction, strategy plumbing."""
+import types
 import numpy as np
 import torch
 
@@ -131,3 +132,53 @@ def test_two_hand_obj_export_face_indexing(tmp_path, mano_arrays):
     assert f.min() == 1 and f.max() == 1556
     np.testing.assert_allclose(v[:778], pred["pred_right_hand_verts"][1], atol=5e-7)
     np.testing.assert_allclose(v[778:], pred["pred_left_hand_verts"][1], atol=5e-7)
+
+
+def test_hand_type_bce_gradient_is_finite_when_the_sigmoid_saturates():
+    """The handedness term of the Baseline training step (loss_utils.py:40-43) against torch's own
+    F.binary_cross_entropy, including probabilities that are exactly 0 and 1 in fp32 (logit beyond +-17)."""
+    import torch.nn.functional as F
+    from ihmr_amd.baseline_train import hand_type_bce, hand_type_bce_grad
+    s = torch.tensor([[1.0, 0.0], [0.0, 1.0], [0.3, 0.999999], [1e-30, 0.5]], requires_grad=True)
+    t = torch.tensor([[1.0, 0.0], [1.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
+    valid = torch.tensor([1.0, 1.0, 1.0, 0.0])
+    loss = (F.binary_cross_entropy(s, t, reduction="none") * valid.reshape(-1, 1)).mean()
+    loss.backward()
+    assert torch.equal(hand_type_bce(s.detach(), t, valid).mean(), loss.detach())
+    got = hand_type_bce_grad(s.detach(), t, valid)
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got, s.grad, rtol=1e-6, atol=0)
+    # what reaches the logit: grad * s (1 - s) -- zero at saturation instead of NaN
+    assert torch.isfinite(got * s.detach() * (1 - s.detach())).all()
+
+
+def test_mpvpe_known_answers():
+    """MPVPE (ihmr_amd.evaluator.get_single_verts_error / Evaluator.mpvpe_3d) on hand-computed cases."""
+    from ihmr_amd.evaluator import Evaluator, get_single_verts_error
+    rng = np.random.RandomState(0)
+    gt = rng.randn(778, 3).astype(np.float32) * 0.05
+    one_hot = np.zeros(778, np.float32); one_hot[0] = 1.0
+    # a rigid offset disappears with the root alignment
+    assert np.allclose(get_single_verts_error(gt + np.float32([0.1, -0.2, 0.3]), gt, one_hot, 1.0), 0.0, atol=1e-7)
+    # one vertex (not the root) moved by a 3-4-5 vector: that vertex alone is off, by 5 mm
+    p = gt.copy(); p[5] += np.float32([0.003, 0.004, 0.0])
+    e = np.array(get_single_verts_error(p, gt, one_hot, 1.0))
+    assert abs(e[5] - 0.005) < 1e-7 and np.allclose(np.delete(e, 5), 0.0, atol=1e-7) and abs(e.mean() - 0.005 / 778) < 1e-9
+    # a root regressed from two vertices: moving one of them by 2 mm moves the root by 1 mm -> every vertex is 1 mm off
+    half = np.zeros(778, np.float32); half[0] = half[1] = 0.5
+    p = gt.copy(); p[0, 0] += 0.002
+    e = np.array(get_single_verts_error(p, gt, half, 1.0))
+    assert np.allclose(e, 0.001, atol=1e-7)
+    assert np.allclose(get_single_verts_error(p, gt, half, 2.0), 0.0005, atol=1e-7)      # scale_factor divides, as in the MPJPE
+    # through the Evaluator: only hands with a MANO annotation count; the mean runs over vertices of all counted hands
+    mano = types.SimpleNamespace(faces=np.zeros((1538, 3), np.int64), J_regressor=np.stack([half] + [one_hot] * 15))
+    ev = Evaluator(dict(right=mano, left=mano))
+    B = 2
+    res = dict(pred_cam_params=np.zeros((B, 3)), pred_shape_params=np.zeros((B, 20)), pred_pose_params=np.zeros((B, 96)), pred_hand_trans=np.zeros((B, 3)),
+               pred_joints_3d=np.zeros((B, 42, 3), np.float32), gt_joints_3d=np.ones((B, 42, 4), np.float32), collision_loss_origin_scale=np.zeros((B, 1556), np.float32),
+               gt_right_hand_verts=np.stack([gt, gt]), gt_left_hand_verts=np.stack([gt, gt]), pred_right_hand_verts=np.stack([p, gt]),
+               pred_left_hand_verts=np.stack([gt, p]), mano_params_weight=np.float32([[1, 1], [1, 0]]))
+    ev.update(np.arange(B), res)
+    # counted hands: sample 0 right (1 mm everywhere), sample 0 left (0), sample 1 right (0); sample 1 left has no annotation
+    assert abs(ev.mpvpe_3d - 0.001 / 3) < 1e-9
+    assert ev.metric_sums()[8] == 3 * 778

@@ -100,19 +100,40 @@ def test_host_select_args_match_reference_filter():
     from ihmr_amd.strategies import make_opt_strategy
     g = gold("select.npz")
     a = stage_to_args(make_opt_strategy(3)[2])
+    assert list(a.use_filter) == [0, 1, 1] and a.select_loss == 1 and a.param_mask == 16 + 32 and a.optimizer == 0 and a.n_iters == 4
     j3d, col = g["j3d"], g["col"]
     S, B = j3d.shape
     idx = np.zeros(B, np.int64)
     for b in range(B):
         best, bv = 0, j3d[0, b]
         for s in range(1, S):
-            ok = (j3d[s, b] <= np.float32(j3d[0, b] * np.float32(a["fac_j3d"]))) and (col[s, b] <= np.float32(col[0, b] * np.float32(a["fac_coll"])))
+            ok = (j3d[s, b] <= np.float32(j3d[0, b] * np.float32(a.filter_factor[1]))) and (col[s, b] <= np.float32(col[0, b] * np.float32(a.filter_factor[2])))
             key = j3d[s, b] if ok else np.float32(1e11)
             if key < bv:
                 best, bv = s, key
         idx[b] = best
     assert np.array_equal(idx, g["a_idx"])
-    assert a["group"] == 2 and a["select_on_collision"] == 0
+
+
+def test_stage_to_args_covers_what_the_reference_accepts():
+    """Any subset of the leaf parameters, the three non-GT per-sample losses as criteria, several criteria on one loss,
+    both optimizers; what the reference itself rejects raises a ValueError that names the strategy field."""
+    from helpers import variant_strategy
+    from ihmr_amd.optimize_model import stage_to_args
+    st = variant_strategy(5)
+    a = stage_to_args(st[0], "sgd", 2)
+    assert list(a.use_filter) == [1, 0, 0] and a.select_loss == 2 and a.optimizer == 1 and a.save_freq == 2 and a.param_mask == 2
+    assert abs(a.filter_factor[0] - 1.051) < 1e-6
+    a = stage_to_args(st[3])
+    assert list(a.use_filter) == [1, 1, 0] and abs(a.filter_factor[1] - 0.991) < 1e-6 and abs(a.filter_factor[0] - 1.201) < 1e-6
+    mixed = dict(st[1], update_params=["pred_cam_params", "pred_left_orient", "pred_hand_trans"])
+    assert stage_to_args(mixed).param_mask == 1 + 8 + 2
+    for bad, field in ((dict(st[1], select_loss="joints_3d_loss"), "select_loss"), (dict(st[1], filter_loss=[("finger_reg_loss", "+0")]), "filter_loss"),
+                       (dict(st[1], update_params=["pred_pose_params"]), "update_params"), (dict(st[1], filter_loss=[]), "filter_loss")):
+        with pytest.raises(ValueError, match=field):
+            stage_to_args(bad)
+    with pytest.raises(ValueError, match="optimizer"):
+        stage_to_args(st[1], "lbfgs")
 
 
 # ------------------------------------------------------------------------------------------ OPT loop
@@ -450,3 +471,49 @@ def test_encoder_train_mode_matches_reference():
         close(gr, g[key], 1e-3 * float(np.abs(g[key]).max()) + 1e-9, what=key)
     close(ref.main_encoder.bn1.running_mean, g["bn1_running_mean"], 1e-6, what="bn1 running mean")
     close(ref.main_encoder.layer4[2].bn3.running_var, g["last_bn_running_var"], 1e-5, what="last bn running var")
+
+
+def _replay_opt_golden(mano_arrays, g, prefix, strategy, optimizer="adam"):
+    from oracle.opt_ref import OptimizeRef
+    epoch, freq = (int(x) for x in g["meta_epoch_freq"])
+    batch = {k[3:]: T(v) for k, v in g.items() if k.startswith("in_")}
+    B = batch["init_cam"].shape[0]
+    right, left = mano_arrays
+    torch.set_num_threads(8)
+    orc = OptimizeRef(right, left, B, strategy(epoch), save_mid_freq=freq, optimizer=optimizer)
+    orc.set_input(batch)
+    orc.init_optimize()
+    orc.optimize()
+    res = orc.get_pred_result()
+    for k, v in res.items():
+        if f"{prefix}out_{k}" in g:
+            close(v, g[f"{prefix}out_{k}"], 1e-6, what=k)
+    close(orc.pred_joints_2d.detach(), g[f"{prefix}out_pred_joints_2d"], 1e-6, what="joints_2d")
+    close(orc.joints_3d_loss_p_batch.detach(), g[f"{prefix}out_joints_3d_loss_p_batch"], 1e-6, what="j3d batch")
+    close(orc.joints_2d_loss_p_batch.detach(), g[f"{prefix}out_joints_2d_loss_p_batch"], 1e-6, what="j2d batch")
+    close(orc.loss.detach(), g[f"{prefix}out_loss"], 1e-5, what="total loss")
+    return orc
+
+
+def test_opt_ragged_trajectory_matches_reference(mano_arrays):
+    """oracle == the reference's OptimizeModel on the RAGGED batch (single-hand samples, missing / half-weight wrists,
+    zero-weight joints, no 3-D target, separated hands; tests/helpers.py:ragged_opt_batch)."""
+    from ihmr_amd.strategies import make_opt_strategy
+    g = gold("opt_traj_ragged.npz")
+    orc = _replay_opt_golden(mano_arrays, g, "", make_opt_strategy)
+    ht = g["in_hand_type_array"]
+    assert (ht.sum(1) < 1.5).sum() == 2 and np.all(g["out_collision_loss"][ht.sum(1) < 1.5] == 0.0)
+    assert g["out_collision_loss"][7] == 0.0 and np.abs(g["out_collision_loss_origin_scale"][7]).max() == 0.0
+    assert np.abs(g["out_collision_loss_origin_scale"][1]).max() > 0  # unmasked per-vertex depths (loss_utils.py:189)
+    assert len({tuple(s) for s in np.stack(orc.selected).T.tolist()}) > 1, "samples must not all select the same snapshots"
+
+
+def test_opt_variant_trajectories_match_reference(mano_arrays):
+    """oracle == the reference's OptimizeModel with (a) non-default filter / select criteria, (b) optimizer = 'sgd'."""
+    from helpers import variant_strategy
+    from ihmr_amd.strategies import make_opt_strategy
+    g = gold("opt_traj_variants.npz")
+    a = _replay_opt_golden(mano_arrays, g, "crit_", variant_strategy)
+    b = _replay_opt_golden(mano_arrays, g, "sgd_", make_opt_strategy, optimizer="sgd")
+    print("selected (criteria):", np.stack(a.selected).tolist(), " (sgd):", np.stack(b.selected).tolist())
+    assert np.stack(a.selected).max() > 0 and np.stack(b.selected).max() > 0
