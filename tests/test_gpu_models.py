@@ -240,8 +240,9 @@ def test_device_evaluator_matches_host_evaluator():
     assert got[1] == ref[1] and got[3] == ref[3] and got[6] == ref[6], "counts differ"
     np.testing.assert_allclose(got[[0, 2, 4, 5]], ref[[0, 2, 4, 5]], rtol=2e-6)
     m_ref, m_got = Evaluator.metrics_from_sums(ref), Evaluator.metrics_from_sums(got)
-    for k in m_ref:
+    for k in ("mpjpe_3d", "inter_mpjpe_3d", "collision_ave", "collision_max"):
         assert abs(m_ref[k] - m_got[k]) <= 2e-6 * abs(m_ref[k]) + 1e-9, (k, m_ref[k], m_got[k])
+    assert got[8] == ref[8] == 0      # no meshes were given: MPVPE has no samples
 
 
 def test_run_optimize_device_and_host_eval_agree():
