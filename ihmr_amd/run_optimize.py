@@ -15,10 +15,6 @@ import os
 import time
 import types
 
-# several model instances run side by side on their own HIP streams (--streams): give them separate hardware queues
-# (read by the HIP runtime when it initialises, i.e. at the first device call below)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import numpy as np
 import torch
 
@@ -36,12 +32,14 @@ def main(argv=None):
     ap.add_argument("--opt_epoch", type=int, default=49, help="iterations per stage - 1 (reference default 300)")
     ap.add_argument("--save_mid_freq", type=int, default=10)
     ap.add_argument("--strategy", type=str, default="opt_default")
+    ap.add_argument("--optimizer", type=str, default="adam", choices=["adam", "sgd"], help="options/opt_options.py: --optimizer")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--host_eval", action="store_true",
                     help="evaluate with the host (numpy) Evaluator on get_pred_result() exports, as the reference does; "
                          "default: metrics on the device (ihmr_eval_metrics), no export")
     ap.add_argument("--streams", type=int, default=1,
-                    help="model instances driven side by side on their own HIP streams (the hardware runs 4 compute queues)")
+                    help="model instances driven side by side on their own HIP streams (2 x --fuse_batches 8 saturates one MI355X; "
+                         "more than 4 need GPU_MAX_HW_QUEUES raised in the environment)")
     ap.add_argument("--fuse_batches", type=int, default=1,
                     help="consecutive batches carried by one launch sequence (per-sample results identical to separate batches)")
     args = ap.parse_args(argv)
@@ -52,7 +50,7 @@ def main(argv=None):
     opt = types.SimpleNamespace(isTrain=False, dist=world > 1, process_rank=rank if world > 1 else -1, batchSize=args.batchSize,
                                 inputSize=224, num_joints=42, total_params_dim=122, cam_params_dim=3, pose_params_dim=96,
                                 shape_params_dim=20, trans_params_dim=3, model_root="", strategy=args.strategy,
-                                save_mid_freq=args.save_mid_freq, optimizer="adam", opt_epoch=args.opt_epoch)
+                                save_mid_freq=args.save_mid_freq, optimizer=args.optimizer, opt_epoch=args.opt_epoch)
     model = OptimizeModel(opt)
     G, S = max(1, args.fuse_batches), max(1, args.streams)
     # one model instance (own buffers, workspace, graphs) per stream; `model` doubles as the first single-batch instance
