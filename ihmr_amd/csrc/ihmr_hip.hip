@@ -255,17 +255,28 @@ __global__ void faces_to_soa_kernel(const int32_t* __restrict__ aos, int32_t* __
     for (int k = 0; k < 3; ++k) soa[k * NFP + f] = aos[s * 3 + k];
 }
 
-extern "C" int ihmr_sdf_collision(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
-                                  float robustifier, float* loss, float* per_vert, float* origin_scale, float* dval,
-                                  void* workspace, void* stream) {
+extern "C" int ihmr_sdf_collision_ex(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
+                                     float robustifier, const ihmr_sdf_options* options, float* loss, float* per_vert,
+                                     float* origin_scale, float* dval, void* workspace, void* stream) {
     if (!workspace || B <= 0) return -1;
     hipStream_t st = (hipStream_t)stream;
     SdfWorkspace ws = sdf_carve(workspace, 2 * B);
+    if (options) {
+        ws.align_corners = options->align_corners ? 1 : 0;
+        if (options->loss_divisor > 0.f) ws.loss_div = options->loss_divisor;
+    }
     int32_t* soa = (int32_t*)((char*)workspace + sdf_ws_bytes(2 * B));
     hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa, ws.inside_count);
     hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP, (int*)nullptr);
     VertLayout vl{hand_verts, (long)2 * NV3, (long)NV3};
     return sdf_launch(vl, soa, soa + 3 * NFP, B, ws, robustifier, loss, per_vert, origin_scale, dval, false, st);
+}
+
+extern "C" int ihmr_sdf_collision(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
+                                  float robustifier, float* loss, float* per_vert, float* origin_scale, float* dval,
+                                  void* workspace, void* stream) {
+    return ihmr_sdf_collision_ex(faces_right, faces_left, hand_verts, B, robustifier, nullptr, loss, per_vert, origin_scale, dval,
+                                 workspace, stream);
 }
 
 extern "C" int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
@@ -298,6 +309,8 @@ static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
     hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m, (const float*)wk.lbs.skel,
                        2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
+    ws.align_corners = io->sdf_align_corners ? 1 : 0;
+    if (io->sdf_loss_divisor > 0.f) ws.loss_div = io->sdf_loss_divisor;
     VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
     int rc = sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, B, ws, 0.f, nullptr, nullptr, nullptr, nullptr, false, st);
     if (rc) return rc;

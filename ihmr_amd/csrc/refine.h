@@ -279,9 +279,9 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void opt_sample_loss_kernel(ihm
     __shared__ float red16[SDF_SAMPLE_THREADS / WAVE];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid >= OPT_SAMPLE_WORKERS) opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS, need_cam);
-    // collision gradient scale: weight * [two-hand sample] / (num_hands^2 * B)   (loss_utils.py:186-188)
+    // collision gradient scale: weight * [two-hand sample] / (loss divisor [num_hands^2] * B)   (loss_utils.py:186-188)
     const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
-    const float gs = w.collision * mask / (4.0f * (float)(io.norm_batch > 0 ? io.norm_batch : B));
+    const float gs = w.collision * mask / (ws.loss_div * (float)(io.norm_batch > 0 ? io.norm_batch : B));
     sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, io.coll_per_vert, io.coll_origin_scale, nullptr, wk.g_verts, B, gs,
                      io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
 }

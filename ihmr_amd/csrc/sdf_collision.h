@@ -48,6 +48,9 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     int* inside_count;         // [8] (slot 0 in use)
     unsigned long long* stats; // [8] optional work counters
     int xcd_cap;
+    // conventions of the upstream module that nothing in the reference pins (ihmr_sdf_options; defaults = DESIGN.md section 4)
+    int align_corners;         // grid_sample(align_corners): 0 = False (the default of the reference's pinned torch 1.6.0)
+    float loss_div;            // loss[b] = sum of the 1556 sampled values / loss_div (4 = num_hands^2 of the parent project)
 };
 
 __host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)H * (SDF_NVOX + SDF_ITEM); }   // one batch-wide list
@@ -75,6 +78,8 @@ static inline SdfWorkspace sdf_carve(void* ws, int H) {
     w.inside_count = (int*)p; p += 64;
     w.xcd_cap = (int)sdf_xcd_cap(H);
     w.inside_list = (unsigned*)p;
+    w.align_corners = 0;
+    w.loss_div = 4.0f;
     return w;
 }
 
@@ -85,8 +90,10 @@ struct VertLayout {
     __device__ __forceinline__ const float* hand(int b, int hnd) const { return base + b * stride_b + hnd * stride_h; }
 };
 
-// grid_sample un-normalisation, align_corners = False: ((x + 1) * G - 1) / 2
-__device__ __forceinline__ float sdf_unnorm(float x) { return ((x + 1.0f) * (float)SDF_G - 1.0f) / 2.0f; }
+// grid_sample un-normalisation: align_corners = False: ((x + 1) * G - 1) / 2;  True: (x + 1) / 2 * (G - 1)   (torch's expressions)
+__device__ __forceinline__ float sdf_unnorm(float x, int align_corners) {
+    return align_corners ? ((x + 1.0f) / 2.0f) * (float)(SDF_G - 1) : ((x + 1.0f) * (float)SDF_G - 1.0f) / 2.0f;
+}
 
 // exclusive prefix sum of data[0..1023] (LDS) by SDF_PREP_THREADS threads, thread t owning the SDF_PREP_CPT adjacent
 // elements from SDF_PREP_CPT * t; returns the total.
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         vn[3 * v + 2] = (vn[3 * v + 2] - cz) / sc;
         if (!DENSE) {
             const float qx = (oq[rep][0] - cx) / sc, qy = (oq[rep][1] - cy) / sc, qz = (oq[rep][2] - cz) / sc;
-            const float ix = sdf_unnorm(qx), iy = sdf_unnorm(qy), iz = sdf_unnorm(qz);
+            const float ix = sdf_unnorm(qx, ws.align_corners), iy = sdf_unnorm(qy, ws.align_corners), iz = sdf_unnorm(qz, ws.align_corners);
             const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
             // completely outside the grid (or non-finite): contributes nothing
             if (fx >= -1.0f && fx <= (float)(SDF_G - 1) && fy >= -1.0f && fy <= (float)(SDF_G - 1) && fz >= -1.0f &&
@@ -589,7 +596,8 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
         const float4 bx = *reinterpret_cast<const float4*>(ws.box + H * 4);
         const float cx = bx.x, cy = bx.y, cz = bx.z, sc = bx.w;
         const float* q = vl.hand(b, 1 - hnd) + 3 * v;
-        const float ix = sdf_unnorm((q[0] - cx) / sc), iy = sdf_unnorm((q[1] - cy) / sc), iz = sdf_unnorm((q[2] - cz) / sc);
+        const float ix = sdf_unnorm((q[0] - cx) / sc, ws.align_corners), iy = sdf_unnorm((q[1] - cy) / sc, ws.align_corners),
+                    iz = sdf_unnorm((q[2] - cz) / sc, ws.align_corners);
         const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
         float val = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
         if (x0 >= -1.0f && x0 <= (float)(SDF_G - 1) && y0 >= -1.0f && y0 <= (float)(SDF_G - 1) && z0 >= -1.0f &&
@@ -619,8 +627,8 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
                 }
             }
         }
-        // chain: ix = ((x+1)*G - 1)/2, x = (q - c)/s  =>  d ix / d q = G / (2 s)
-        const float chain = (0.5f * (float)SDF_G) / sc;
+        // chain: ix = ((x+1)*G - 1)/2 (or (x+1)/2*(G-1)), x = (q - c)/s  =>  d ix / d q = G / (2 s)  (or (G-1) / (2 s))
+        const float chain = (0.5f * (float)(ws.align_corners ? SDF_G - 1 : SDF_G)) / sc;
         gx *= chain; gy *= chain; gz *= chain;
         if (robustifier > 0.f) {
             const float r = val / robustifier, fr = r * r;
@@ -650,7 +658,7 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
         for (int wv = 0; wv < SDF_SAMPLE_THREADS / WAVE; ++wv) tot += red16[wv];
         float mask = 1.0f;
         if (hand_type) mask = (hand_type[b * 2] + hand_type[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
-        loss[b] = tot / 4.0f * mask;  // parent project: sum / num_hands^2
+        loss[b] = tot / ws.loss_div * mask;  // parent project: sum / num_hands^2
     }
 }
 

@@ -32,7 +32,7 @@ OPTIMIZERS = dict(adam=0, sgd=1)
 EXPORTED_SYMBOLS = [
     "ihmr_mano_create", "ihmr_mano_destroy", "ihmr_mano_update_shapedirs", "ihmr_mano_workspace_bytes", "ihmr_mano_lbs_fwd",
     "ihmr_mano_lbs_bwd",
-    "ihmr_sdf_workspace_bytes", "ihmr_sdf_collision", "ihmr_sdf_dense_grid", "ihmr_opt_workspace_bytes",
+    "ihmr_sdf_workspace_bytes", "ihmr_sdf_collision", "ihmr_sdf_collision_ex", "ihmr_sdf_dense_grid", "ihmr_opt_workspace_bytes",
     "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_opt_sdf_stats", "ihmr_opt_stage_graph_create",
     "ihmr_opt_forward_graph_create", "ihmr_graph_launch", "ihmr_graph_destroy", "ihmr_opt_set_params", "ihmr_eval_metrics", "ihmr_eval_mpvpe", "ihmr_conv_igemm", "ihmr_maxpool3x3s2",
     "ihmr_avgpool_relu", "ihmr_preprocess_images", "ihmr_mlp_train_grad", "ihmr_transpose", "ihmr_relu_backward", "ihmr_colsum",
@@ -52,7 +52,12 @@ class OptIO(C.Structure):
         "init_joints_2d", "init_joints_3d", "init_hand_trans_j", "gt_joints_2d", "gt_joints_3d", "gt_hand_trans",
         "hand_type_array",
         "verts", "joints_3d", "joints_2d", "loss_batch", "coll_per_vert", "coll_origin_scale",
-        "snap_params", "snap_loss", "selected", "adam_m", "adam_v", "workspace")] + [("norm_batch", C.c_int)]
+        "snap_params", "snap_loss", "selected", "adam_m", "adam_v", "workspace")] + [
+        ("norm_batch", C.c_int), ("sdf_align_corners", C.c_int), ("sdf_loss_divisor", C.c_float)]
+
+
+class SdfOptions(C.Structure):
+    _fields_ = [("align_corners", C.c_int), ("loss_divisor", C.c_float)]
 
 
 class OptStage(C.Structure):
@@ -124,6 +129,7 @@ def lib():
         L.ihmr_sdf_workspace_bytes.argtypes = [i]
         L.ihmr_sdf_workspace_bytes.restype = C.c_size_t
         L.ihmr_sdf_collision.argtypes = [vp, vp, vp, i, f, vp, vp, vp, vp, vp, vp]
+        L.ihmr_sdf_collision_ex.argtypes = [vp, vp, vp, i, f, C.POINTER(SdfOptions), vp, vp, vp, vp, vp, vp]
         L.ihmr_sdf_dense_grid.argtypes = [vp, vp, vp, i, vp, vp, vp]
         L.ihmr_opt_workspace_bytes.argtypes = [i]
         L.ihmr_opt_workspace_bytes.restype = C.c_size_t

@@ -149,7 +149,10 @@ class OptimizeModel:
             selected=torch.zeros(B, device=dev, dtype=torch.int32), adam_m=z(B, hip.OPT_NPARAM), adam_v=z(B, hip.OPT_NPARAM),
             workspace=torch.empty(hip.lib().ihmr_opt_workspace_bytes(B), device=dev, dtype=torch.uint8),
         )
-        self.io = hip.OptIO(**{k: v.data_ptr() for k, v in self.buf.items()}, norm_batch=self.norm_batch)
+        # conventions of the collision module (include/ihmr_hip.h: ihmr_sdf_options): opt.sdf_align_corners / opt.sdf_loss_divisor
+        self.io = hip.OptIO(**{k: v.data_ptr() for k, v in self.buf.items()}, norm_batch=self.norm_batch,
+                            sdf_align_corners=int(bool(getattr(self.opt, "sdf_align_corners", False))),
+                            sdf_loss_divisor=float(getattr(self.opt, "sdf_loss_divisor", 0.0) or 0.0))
         self.mano_params_weight = z(B, 2)
         self.init = {}
 

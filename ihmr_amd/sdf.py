@@ -29,10 +29,13 @@ class _SdfFunction(torch.autograd.Function):
         origin = torch.empty(B, 1556, device=dev)
         dval = torch.empty(B, 1556, 3, device=dev)
         ws = module._workspace(B, dev)
-        hip.check(hip.lib().ihmr_sdf_collision(hip.ptr(module.faces_right), hip.ptr(module.faces_left), hip.ptr(hv), B,
-                                               float(module.robustifier or 0.0), hip.ptr(loss), hip.ptr(per_vert),
-                                               hip.ptr(origin), hip.ptr(dval), hip.ptr(ws), hip.stream_ptr()),
-                  "ihmr_sdf_collision")
+        import ctypes as C
+        options = hip.SdfOptions(int(bool(module.align_corners)), float(module.loss_divisor))
+        hip.check(hip.lib().ihmr_sdf_collision_ex(hip.ptr(module.faces_right), hip.ptr(module.faces_left), hip.ptr(hv), B,
+                                                  float(module.robustifier or 0.0), C.byref(options), hip.ptr(loss), hip.ptr(per_vert),
+                                                  hip.ptr(origin), hip.ptr(dval), hip.ptr(ws), hip.stream_ptr()),
+                  "ihmr_sdf_collision_ex")
+        ctx.loss_divisor = float(module.loss_divisor)
         # box scale per entry (origin = per_vert * scale): recover it for the backward of `origin`
         ctx.save_for_backward(dval, per_vert, origin)
         return loss, per_vert, origin
@@ -43,7 +46,7 @@ class _SdfFunction(torch.autograd.Function):
         B = dval.shape[0]
         coef = torch.zeros(B, 1556, device=dval.device)
         if g_loss is not None:
-            coef = coef + g_loss.reshape(B, 1) / 4.0
+            coef = coef + g_loss.reshape(B, 1) / ctx.loss_divisor
         if g_per_vert is not None:
             coef = coef + g_per_vert
         if g_origin is not None:
@@ -56,9 +59,12 @@ class _SdfFunction(torch.autograd.Function):
 
 
 class SDFLoss(nn.Module):
-    def __init__(self, faces_right, faces_left, robustifier=None, grid_size=32):
+    def __init__(self, faces_right, faces_left, robustifier=None, grid_size=32, align_corners=False, loss_divisor=4.0):
+        """``align_corners`` / ``loss_divisor``: the two conventions of the (absent, unpinned) upstream module that a maintainer
+        holding the real package can switch to pin this seam (``include/ihmr_hip.h: ihmr_sdf_options``)."""
         super().__init__()
         assert grid_size == 32, "the kernels are built for the 32^3 grid of the upstream module"
+        self.align_corners, self.loss_divisor = bool(align_corners), float(loss_divisor)
         self.register_buffer("faces_right", torch.tensor(np.asarray(faces_right).astype(np.int32)))
         self.register_buffer("faces_left", torch.tensor(np.asarray(faces_left).astype(np.int32)))
         self.robustifier = robustifier

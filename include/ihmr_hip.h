@@ -76,6 +76,18 @@ size_t ihmr_sdf_workspace_bytes(int B);
 int ihmr_sdf_collision(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
                        float robustifier, float* loss, float* per_vert, float* origin_scale, float* dval,
                        void* workspace, void* stream);
+/* The upstream module (github.com/penincillin/SDF_ihmr, unpinned commit) is absent, and the reference pins neither of these
+ * two conventions; both default to what DESIGN.md section 4 decides and can be switched by a maintainer who holds the real
+ * package (INTEGRATION.md "Pinning seam B"):
+ *   align_corners  the `align_corners` of the trilinear grid_sample of phi (0 = False, the default of torch 1.6.0)
+ *   loss_divisor   loss[b] = sum of the 1556 sampled values / loss_divisor (4 = num_hands^2, the parent project's normalisation;
+ *                  1 = plain sum); <= 0 = default.
+ * (The position of the voxel centres -- cell-centred, p = -1 + (2i+1)/32 -- is NOT switchable: the exact inside / outside
+ * arithmetic of the ray test is derived for it.) */
+typedef struct ihmr_sdf_options { int align_corners; float loss_divisor; } ihmr_sdf_options;
+int ihmr_sdf_collision_ex(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
+                          float robustifier, const ihmr_sdf_options* options, float* loss, float* per_vert, float* origin_scale,
+                          float* dval, void* workspace, void* stream);
 /* diagnostic: dense phi grid (B,2,32,32,32) built with the product kernels (every voxel evaluated);
  * compared bit-for-bit with the oracle's grid in tests. */
 int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
@@ -120,6 +132,9 @@ typedef struct ihmr_opt_io {
        With norm_batch = 64 and B = k * 64 one launch carries k independent batches of 64, each with exactly the
        arithmetic of a B = 64 call (samples never interact except through these 1/batch factors). */
     int norm_batch;
+    /* conventions of the collision module (ihmr_sdf_options above): 0 / 0 = defaults */
+    int sdf_align_corners;
+    float sdf_loss_divisor;
 } ihmr_opt_io;
 
 typedef struct ihmr_opt_weights { /* strategies/opt_default.py loss_weights */

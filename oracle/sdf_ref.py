@@ -88,8 +88,11 @@ def hand_boxes(hand_verts: torch.Tensor, scale_factor: float = SCALE_FACTOR):
 
 
 class SDFLossRef(nn.Module):
-    def __init__(self, faces_right, faces_left, robustifier=None, grid_size=GRID):
+    def __init__(self, faces_right, faces_left, robustifier=None, grid_size=GRID, align_corners=False, loss_divisor=float(NUM_HANDS ** 2)):
+        """``align_corners`` / ``loss_divisor``: the conventions nothing in the reference pins (defaults: torch 1.6.0's
+        grid_sample default; the parent project's ``/ valid_people ** 2``); switchable to mirror ``ihmr_sdf_options``."""
         super().__init__()
+        self.align_corners, self.loss_divisor = bool(align_corners), float(loss_divisor)
         self.register_buffer("faces_right", torch.tensor(np.asarray(faces_right).astype(np.int32)))
         self.register_buffer("faces_left", torch.tensor(np.asarray(faces_left).astype(np.int32)))
         self.grid_size = grid_size
@@ -108,7 +111,7 @@ class SDFLossRef(nn.Module):
         for h in (0, 1):
             q = (hand_verts[:, 1 - h] - centre[:, h]) / scale[:, h]  # (B,778,3)
             val = F.grid_sample(phi[h][:, None].to(hand_verts.dtype), q.view(B, -1, 1, 1, 3), mode="bilinear",
-                                padding_mode="zeros", align_corners=False).view(B, -1)
+                                padding_mode="zeros", align_corners=self.align_corners).view(B, -1)
             if self.robustifier:
                 frac = (val / self.robustifier) ** 2
                 val = frac / (frac + 1)
@@ -116,7 +119,7 @@ class SDFLossRef(nn.Module):
             origin.append(val * scale[:, h, 0])
         per_vert = torch.cat(per_vert, dim=1)
         origin = torch.cat(origin, dim=1)
-        losses = per_vert.sum(dim=1) / float(NUM_HANDS ** 2)
+        losses = per_vert.sum(dim=1) / self.loss_divisor
         if return_per_vert_loss and return_origin_scale_loss:
             return losses, per_vert, origin
         if return_per_vert_loss:

@@ -642,3 +642,92 @@ def test_reference_shaped_loop_over_the_hip_seams_matches_cpu_oracle(mano_arrays
     _report("seams joints [m]", g["pred_joints_3d"], r["pred_joints_3d"], atol=1e-4)
     _report("seams penetration depth [m]", g["collision_loss_origin_scale"], r["collision_loss_origin_scale"], atol=1e-4)
     _report("seams collision_loss", g["collision_loss"], r["collision_loss"], atol=2e-4, rtol=1e-3)
+
+
+# ----------------------------------------------------------------------------------- the reference's own batch size: 512
+def test_opt_batch512_matches_oracle_and_is_permutation_equivariant(mano_arrays):
+    """bash/optimize.sh:11,33 runs IHMR-OPT at batchSize 512 per process.  One launch sequence over 512 samples (1024
+    hands): (a) against the oracle (2 iterations per stage + final forward); (b) size-independent properties on the
+    4 x 10-iteration schedule: no sample depends on where it sits in the batch (a permuted batch gives the permuted result,
+    bit for bit) nor on its neighbours (duplicated samples give duplicated results)."""
+    from ihmr_amd.optimize_model import OptimizeModel
+    B = 512
+    orc, model, batch = _oracle_and_model(mano_arrays, B, 1, 1, seed=512512, record=False)
+    torch.set_num_threads(max(1, min(32, (__import__("os").cpu_count() or 8))))
+    orc.set_input(batch); orc.init_optimize(); orc.optimize()
+    model.set_input(batch); model.init_optimize(); model.optimize()
+    torch.cuda.synchronize()
+    r, g = orc.get_pred_result(), model.get_pred_result()
+    assert np.array_equal(np.stack(orc.selected), torch.stack(model.selected_history).cpu().numpy())
+    _report("B=512 pose", g["pred_pose_params"], r["pred_pose_params"], atol=1e-4)
+    _report("B=512 shape", g["pred_shape_params"], r["pred_shape_params"], atol=1e-4)
+    _report("B=512 trans", g["pred_hand_trans"], r["pred_hand_trans"], atol=2e-5)
+    _report("B=512 right verts [m]", g["pred_right_hand_verts"], r["pred_right_hand_verts"], atol=1e-4)
+    _report("B=512 left verts [m]", g["pred_left_hand_verts"], r["pred_left_hand_verts"], atol=1e-4)
+    _report("B=512 joints [m]", g["pred_joints_3d"], r["pred_joints_3d"], atol=1e-4)
+    _report("B=512 penetration depth [m]", g["collision_loss_origin_scale"], r["collision_loss_origin_scale"], atol=1e-4)
+    # (b) properties, 40 iterations
+    long = OptimizeModel(_make_opt(B, epoch=9, save_mid_freq=5))
+    dup = {k: torch.cat([v[:256], v[:256]], dim=0) for k, v in batch.items()}
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(7))
+    outs = []
+    for inp in (dup, {k: v[perm] for k, v in dup.items()}):
+        long.set_input(inp); long.init_optimize(); long.optimize()
+        torch.cuda.synchronize()
+        outs.append((long.get_pred_result(), torch.stack(long.selected_history).cpu().numpy()))
+    (a, sel_a), (p, sel_p) = outs
+    keys = ("pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "pred_left_hand_verts",
+            "pred_joints_3d", "collision_loss", "collision_loss_origin_scale")
+    for k in keys:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k][:256], a[k][256:]), f"{k}: duplicated samples differ"
+        assert np.array_equal(p[k], a[k][perm.numpy()]), f"{k}: the result depends on the position in the batch"
+    assert np.array_equal(sel_p, sel_a[:, perm.numpy()])
+    assert len(np.unique(sel_a)) > 1
+
+
+# ----------------------------------------------------------------------------------- seam B conventions (ihmr_sdf_options)
+@pytest.mark.parametrize("align_corners,loss_divisor", [(False, 4.0), (True, 4.0), (False, 1.0), (True, 1.0)])
+def test_sdf_convention_switches_match_oracle(mano_arrays, align_corners, loss_divisor):
+    """The two conventions of the absent upstream collision module that nothing in the reference pins -- grid_sample's
+    `align_corners` and the normalisation of the per-sample loss -- are explicit parameters on both sides (oracle:
+    SDFLossRef(align_corners=, loss_divisor=); product: SDFLoss(...) -> ihmr_sdf_collision_ex, and opt.sdf_* ->
+    ihmr_opt_io for the fused loop); every combination is compared: values, loss and gradient through seam B, and the
+    fused loop's collision term + one Adam step of every stage."""
+    import functools
+    from ihmr_amd.sdf import SDFLoss
+    from ihmr_amd.optimize_model import OptimizeModel
+    from ihmr_amd.strategies import make_opt_strategy
+    from oracle.opt_ref import OptimizeRef
+    from oracle.sdf_ref import SDFLossRef
+    right, left = mano_arrays
+    B = 4
+    hv, batch = _two_hand_verts(mano_arrays, B, 5)
+    ref_mod = SDFLossRef(right["faces"], left["faces"], align_corners=align_corners, loss_divisor=loss_divisor)
+    hv_ref = hv.clone().requires_grad_(True)
+    l_ref, pv_ref, os_ref = ref_mod(hv_ref, return_per_vert_loss=True, return_origin_scale_loss=True)
+    w = torch.linspace(0.5, 1.5, B)
+    (l_ref * w).sum().backward()
+    mod = SDFLoss(right["faces"], left["faces"], align_corners=align_corners, loss_divisor=loss_divisor).to(_dev())
+    hv_g = hv.clone().to(_dev()).requires_grad_(True)
+    l, pv, os_ = mod(hv_g, return_per_vert_loss=True, return_origin_scale_loss=True)
+    (l * w.to(_dev())).sum().backward()
+    assert int((pv_ref > 0).sum()) > 50
+    _report("conv per_vert", pv.detach().cpu(), pv_ref.detach(), atol=1e-6)
+    _report("conv origin_scale [m]", os_.detach().cpu(), os_ref.detach(), atol=1e-7)
+    _report("conv loss", l.detach().cpu(), l_ref.detach(), atol=1e-5, rtol=1e-6)
+    _report("conv d/dverts", hv_g.grad.cpu(), hv_ref.grad, atol=1e-4 * float(hv_ref.grad.abs().max()))
+    # fused loop
+    opt = _make_opt(B, epoch=1, save_mid_freq=1)
+    opt.sdf_align_corners, opt.sdf_loss_divisor = align_corners, loss_divisor
+    model = OptimizeModel(opt)
+    orc = OptimizeRef(right, left, B, make_opt_strategy(1), save_mid_freq=1,
+                      sdf_loss_cls=functools.partial(SDFLossRef, align_corners=align_corners, loss_divisor=loss_divisor))
+    orc.set_input(batch); orc.init_optimize(); orc.optimize()
+    model.set_input(batch); model.init_optimize(); model.optimize()
+    torch.cuda.synchronize()
+    r, g = orc.get_pred_result(), model.get_pred_result()
+    assert np.array_equal(np.stack(orc.selected), torch.stack(model.selected_history).cpu().numpy())
+    _report("conv fused collision_loss", g["collision_loss"], r["collision_loss"], atol=1e-5, rtol=1e-5)
+    _report("conv fused pose", g["pred_pose_params"], r["pred_pose_params"], atol=1e-4)
+    _report("conv fused penetration depth [m]", g["collision_loss_origin_scale"], r["collision_loss_origin_scale"], atol=1e-6)

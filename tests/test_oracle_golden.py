@@ -517,3 +517,20 @@ def test_opt_variant_trajectories_match_reference(mano_arrays):
     b = _replay_opt_golden(mano_arrays, g, "sgd_", make_opt_strategy, optimizer="sgd")
     print("selected (criteria):", np.stack(a.selected).tolist(), " (sgd):", np.stack(b.selected).tolist())
     assert np.stack(a.selected).max() > 0 and np.stack(b.selected).max() > 0
+
+
+def test_sdf_oracle_convention_switches(mano_arrays):
+    """SDFLossRef(align_corners=, loss_divisor=): the divisor only rescales the per-sample loss; align_corners=True
+    samples the same grid on the corner-aligned lattice (a query on a voxel centre of THAT lattice returns the voxel)."""
+    from oracle import sdf_ref
+    right, left = mano_arrays
+    v = torch.tensor(right["v_template"])
+    other = v.clone(); other[:, 0] = -other[:, 0] + 0.03
+    hv = torch.stack([v, other])[None]
+    a = sdf_ref.SDFLossRef(right["faces"], left["faces"])(hv, return_per_vert_loss=True, return_origin_scale_loss=True)
+    b = sdf_ref.SDFLossRef(right["faces"], left["faces"], loss_divisor=1.0)(hv, return_per_vert_loss=True, return_origin_scale_loss=True)
+    c = sdf_ref.SDFLossRef(right["faces"], left["faces"], align_corners=True)(hv, return_per_vert_loss=True, return_origin_scale_loss=True)
+    assert float(a[0]) > 0
+    close(b[0], 4.0 * a[0], 1e-6, what="divisor")
+    close(b[1], a[1], 0, what="per-vertex values do not depend on the divisor")
+    assert float((c[1] - a[1]).abs().max()) > 1e-4, "align_corners must change the sampled values"
