@@ -165,6 +165,31 @@ def test_whole_encoder_train_forward_backward_matches_oracle_autograd():
     for k, rel in rels.items():
         assert rel < (4e-2 if "main_encoder" in k and "fc1" not in k else 1e-4), f"{k}: relative gradient error {rel:.3e}"
     print(f"[parity] whole-encoder gradients: worst relative L2 error over {len(ref_grads)} parameters = {worst:.3e}")
+    # Is the 1e-2 in the trunk a property of fp32 (ReLU masks flipping on pre-activations within rounding of zero) or of this
+    # implementation?  The same network in float64 is the arbiter: torch's own fp32 gradients are compared with it exactly
+    # as the HIP gradients are.  If the deviation were a defect of the HIP backward pass it would show up as an error
+    # against fp64 well above torch-fp32's own; it does not -- both fp32 implementations sit at the same distance from the
+    # float64 gradients, parameter by parameter.
+    ref64 = InterHandEncoderRef(mean_params.repeat(B, 1).double()).double()
+    ref64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in sd.items()})
+    ref64.train()
+    p64, h64 = ref64(img.double())
+    (p64 * A.double()).sum().add((h64 * Bm.double()).sum()).backward()
+    g64 = {k: v.grad for k, v in ref64.named_parameters()}
+    e_hip, e_t32 = {}, {}
+    for k in ref_grads:
+        n = float(g64[k].norm()) + 1e-300
+        e_hip[k] = float((grads[k].cpu().double() - g64[k]).norm()) / n
+        e_t32[k] = float((ref_grads[k].double() - g64[k]).norm()) / n
+    trunk = [k for k in ref_grads if "main_encoder" in k and "fc1" not in k]
+    med = lambda d, ks: float(np.median([d[k] for k in ks]))
+    print(f"[parity] gradients vs float64: trunk median HIP {med(e_hip, trunk):.3e} torch-fp32 {med(e_t32, trunk):.3e}; "
+          f"worst HIP {max(e_hip.values()):.3e} torch-fp32 {max(e_t32.values()):.3e}")
+    _close("train-mode params vs float64", p, p64.float(), 2e-4)
+    for k in ref_grads:
+        # parameter by parameter no worse than 3x torch-fp32's own distance from float64 (+ 1e-4: the head, where both are ~1e-6)
+        assert e_hip[k] <= 3.0 * e_t32[k] + 1e-4, f"{k}: HIP vs float64 {e_hip[k]:.3e}, torch fp32 vs float64 {e_t32[k]:.3e}"
+    assert med(e_hip, trunk) <= 1.5 * med(e_t32, trunk) + 1e-5
     # the same quantities as the REFERENCE's own encoder produced them (tests/golden/encoder_train.npz, same seeds)
     import os
     gold = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "encoder_train.npz")))
