@@ -91,7 +91,8 @@ def pmc_traffic(kernel):
     produced by ``scripts/profile_round.sh`` = two separate ``--pmc`` passes of this very command, FETCH_SIZE doubled
     per the gfx950 correction).  Counters cannot be read from inside the process, so this is the profile's figure."""
     import csv, glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.csv")))
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9]*_v[0-9]*_pmc_traffic.csv")),
+                   key=lambda f: [int(x) for x in __import__("re").findall(r"\d+", os.path.basename(f))[:2]])
     if not files:
         return None, None
     with open(files[-1], newline="") as fh:
@@ -423,12 +424,14 @@ def main():
             if avg_ms > 0:
                 tot_flops += flops * sizes_run[g]
                 tot_ms += avg_ms * sizes_run[g]
-        traffic, traffic_src = pmc_traffic("sdf_dist_kernel") if (B == 64 and args.epoch == 49) else (None, None)
+        # the committed PMC summary is of EIGHT-batch launches (FUSE=8 scripts/profile_round.sh): quoted only when that is the
+        # launch size the timed region ran
+        traffic, traffic_src = pmc_traffic("sdf_dist_kernel") if (B == 64 and args.epoch == 49 and set(sizes_run) == {8}) else (None, None)
         ach = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None
         roofline = dict(bound="valu", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=(ach / FP32_PEAK_TFLOPS) if ach else None,
                         traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
-                        traffic_note="HBM bytes of a FOUR-batch launch from the committed rocprofv3 PMC summary (counters cannot be read "
-                                     "from inside the process), not of this run",
+                        traffic_note="HBM bytes of an eight-batch launch from the committed rocprofv3 PMC summary of this command at "
+                                     "--streams 1 (counters cannot be read from inside the process), not of this run",
                         kernel="sdf_dist_kernel", by_launch_size=per_size,
                         note="largest share of GPU time in the rocprofv3 kernel summary (profiles/).  Pure fp32 VALU kernel (compares, "
                              "selects, FMAs; no GEMM shape): priced against the 157.3 TFLOP/s fp32 vector peak.  `achieved` = "

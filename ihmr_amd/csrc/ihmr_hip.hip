@@ -303,11 +303,16 @@ extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
 
 // `prev` = the Adam step of the previous iteration (group < 0: none), applied at the head of the skeleton kernel
 static const ParamStep kNoStep{0, 0.f, 0.f, 1.f, -1, 0, 0};
+// reuse_v_posed: the workspace holds v_posed of the current pose and shape parameters (see lbs_skin_kernel)
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
-                       const ihmr_opt_weights& w, const ParamStep& prev, hipStream_t st, int need_cam = 0) {
+                       const ihmr_opt_weights& w, const ParamStep& prev, hipStream_t st, int need_cam = 0, bool reuse_v_posed = false) {
     hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B).inside_count);
-    hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m, (const float*)wk.lbs.skel,
-                       2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
+    if (reuse_v_posed)
+        hipLaunchKernelGGL((lbs_skin_kernel<true, true>), dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m,
+                           (const float*)wk.lbs.skel, 2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
+    else
+        hipLaunchKernelGGL((lbs_skin_kernel<true, false>), dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m,
+                           (const float*)wk.lbs.skel, 2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
     ws.align_corners = io->sdf_align_corners ? 1 : 0;
     if (io->sdf_loss_divisor > 0.f) ws.loss_div = io->sdf_loss_divisor;
@@ -343,8 +348,10 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     const int need_cam = (pm & IHMR_PB_CAM) ? 1 : 0, sgd = sg->optimizer == IHMR_OPTIM_SGD;
     int S = 0;
     ParamStep step{0, 0.f, 0.f, 1.f, -1, 1, 0};   // iteration 0: no step yet, zero the optimizer state
+    // a stage that moves neither the finger pose nor the shape keeps v_posed: computed in its first iteration, reused after
+    const bool vposed_fixed = (pm & (IHMR_PB_POSE_R | IHMR_PB_POSE_L | IHMR_PB_SHAPE_R | IHMR_PB_SHAPE_L)) == 0;
     for (int it = 0; it < sg->n_iters; ++it) {
-        int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam);   // applies the step of iteration it - 1 first
+        int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, vposed_fixed && it > 0);   // applies the step of iteration it - 1 first
         if (rc) return rc;
         if (need_mask)
             lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,

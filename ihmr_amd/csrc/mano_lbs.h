@@ -228,7 +228,11 @@ __device__ __forceinline__ int lbs_group_hand(int x, int s, int i) { return x + 
 
 // ------------------------------------------------------------------------------------- skin
 // grid = (8, 4 vertex tiles x ceil(N/64) groups), block = 256 (195 active lanes = vertices).
-template <bool TWO_HAND>
+// REUSE: v_posed_ws already holds v_posed of exactly these pose and shape parameters (a refinement stage that updates
+// neither -- translation, global orientation: optimize_model.py:393-407 -- after its first iteration): both blends are
+// skipped and the stored values (the bits a recomputation would give) are skinned with the new joint transforms.  The two
+// blends are 2/3 of the kernel's arithmetic and all of its L2 traffic (1.8 MB of basis rows per 8 hands and vertex tile).
+template <bool TWO_HAND, bool REUSE = false>
 __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, const float* __restrict__ skel, int N, int B,
                                                                float* __restrict__ verts, float* __restrict__ joints,
                                                                float* __restrict__ v_posed_ws) {
@@ -237,16 +241,17 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
     __shared__ float beta_s[10][LBS_HG];  // [l][hand]
     __shared__ float shift_s[LBS_HG][4];
     const int tid = threadIdx.x, gx = blockIdx.x, tile = blockIdx.y % 4, gs = blockIdx.y / 4;
-    for (int idx = tid; idx < LBS_HG * 136; idx += LBS_THREADS) {
-        const int hh = idx / 136, e = idx % 136, hid = lbs_group_hand(gx, gs, hh);
-        const float v = (hid < N && e < NPF) ? skel[(size_t)hid * SK_STRIDE + SK_PF + e] : 0.f;
-        reinterpret_cast<float*>(&pfT[e][0])[hh] = v;
-    }
+    if (!REUSE)
+        for (int idx = tid; idx < LBS_HG * 136; idx += LBS_THREADS) {
+            const int hh = idx / 136, e = idx % 136, hid = lbs_group_hand(gx, gs, hh);
+            const float v = (hid < N && e < NPF) ? skel[(size_t)hid * SK_STRIDE + SK_PF + e] : 0.f;
+            reinterpret_cast<float*>(&pfT[e][0])[hh] = v;
+        }
     for (int idx = tid; idx < LBS_HG * 192; idx += LBS_THREADS) {
         const int hh = idx / 192, e = idx % 192, hid = lbs_group_hand(gx, gs, hh);
         A_s[hh / 2][e][hh % 2] = hid < N ? skel[(size_t)hid * SK_STRIDE + SK_A + e] : 0.f;
     }
-    if (tid < LBS_HG * 10) {
+    if (!REUSE && tid < LBS_HG * 10) {
         const int hh = tid / 10, l = tid % 10, hid = lbs_group_hand(gx, gs, hh);
         beta_s[l][hh] = hid < N ? skel[(size_t)hid * SK_STRIDE + SK_BETA + l] : 0.f;
     }
@@ -261,7 +266,16 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
     // shape blend: v_shaped = v_template + shapedirs . beta   (8 hands at once, as 4 hand PAIRS: packed fp32 FMAs
     // do two hands per instruction and give the same IEEE results as scalar ones)
     lbs_v2f vq[LBS_HG / 2][3];
-    {
+    if (REUSE) {
+#pragma unroll
+        for (int q = 0; q < LBS_HG / 2; ++q) {
+            const int h0 = lbs_group_hand(gx, gs, 2 * q), h1 = lbs_group_hand(gx, gs, 2 * q + 1);
+            const float* s0 = v_posed_ws + ((size_t)min(h0, N - 1) * NV + v) * 3;
+            const float* s1 = v_posed_ws + ((size_t)min(h1, N - 1) * NV + v) * 3;
+            vq[q][0] = lbs_v2f{s0[0], s1[0]}; vq[q][1] = lbs_v2f{s0[1], s1[1]}; vq[q][2] = lbs_v2f{s0[2], s1[2]};
+        }
+    }
+    if (!REUSE) {
         const float4 t = m.vt4[v];
         float4 sd[10];
 #pragma unroll
@@ -282,7 +296,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
     // pose blend: v_posed = v_shaped + pose_feature . posedirs.  The basis rows are fetched 9 at a time into two
     // register batches, the next batch in flight while the current one is consumed (explicit batches +
     // scheduling barriers: left alone, hipcc issues one load per use and waits vmcnt(0) on each).
-    {
+    if (!REUSE) {
         // a basis row is fetched as two aligned float pairs (x,y) (z,pad): packed FMAs take their broadcast operand
         // straight from either half of such a pair, no register shuffling between the load and its use
         struct Row { lbs_v2f xy, zw; };
@@ -361,8 +375,10 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
             const int hh = 2 * q + i, h = lbs_group_hand(gx, gs, hh);
             if (h >= N) continue;
             float out[3] = {i ? o2[0].y : o2[0].x, i ? o2[1].y : o2[1].x, i ? o2[2].y : o2[2].x};
-            float* ws = v_posed_ws + ((size_t)h * NV + v) * 3;
-            ws[0] = i ? vq[q][0].y : vq[q][0].x; ws[1] = i ? vq[q][1].y : vq[q][1].x; ws[2] = i ? vq[q][2].y : vq[q][2].x;
+            if (!REUSE) {
+                float* ws = v_posed_ws + ((size_t)h * NV + v) * 3;
+                ws[0] = i ? vq[q][0].y : vq[q][0].x; ws[1] = i ? vq[q][1].y : vq[q][1].x; ws[2] = i ? vq[q][2].y : vq[q][2].x;
+            }
             const bool left = TWO_HAND && h >= B;
             if (left) {  // optimize_model.py:210-211, 222-228
                 out[0] = -out[0] + shift_s[hh][0];
@@ -387,7 +403,6 @@ struct LbsBwdShared {
     __attribute__((aligned(16))) float sk[SK_STRIDE];
     float g[NV3];         // d L / d verts (raw hand frame)
     float vp[NV3];        // v_posed (saved by the forward)
-    float dvp[NV3];       // d L / d v_posed
     float dA[NJ][12];
     float dG[NJ][12];
     float dR[NJ][9];
@@ -401,9 +416,10 @@ struct LbsBwdShared {
 };
 
 // dynamic LDS: float part[nseg][12] -- per-segment partial sums of dA (nseg is a property of the weight matrix:
-// 248 for 4 bones per vertex, up to LBS_SEG_CAP if dense); with it the workgroup needs ~49 KB, three fit a CU
+// 248 for 4 bones per vertex, up to LBS_SEG_CAP if dense); with it the workgroup needs ~38 KB: four fit a CU (1024 hands
+// = one round of the 256 CUs); d v_posed goes through the workspace (L2) instead of LDS for that
 template <bool TWO_HAND>
-__global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, LbsWork wk, int B,
+__global__ __launch_bounds__(LBS_THREADS, 4) void lbs_bwd1_kernel(ihmr_mano m, LbsWork wk, int B,
                                                                const float* __restrict__ d_verts,
                                                                const float* __restrict__ d_joints,
                                                                float* __restrict__ d_orient, float* __restrict__ d_betas,
@@ -415,17 +431,8 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
     const int b = TWO_HAND ? (left ? h - B : h) : 0;
     const bool need_orient = need_mask & 1, need_pose = need_mask & 2, need_betas = need_mask & 4, need_trans = need_mask & 8;
 
-    // constants this workgroup reads later, requested first so their latency hides behind the phases in between:
-    // the skinning weights of this thread's (up to 4) vertices and the kinematic tree
+    // the kinematic tree, requested first (read several phases later)
     constexpr int VR = (NV + LBS_THREADS - 1) / LBS_THREADS;
-    float4 wreg[VR][4];
-#pragma unroll
-    for (int r = 0; r < VR; ++r) {
-        const int v = min(tid + r * LBS_THREADS, NV - 1);
-        const float4* w4 = reinterpret_cast<const float4*>(m.weights + v * NJ);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wreg[r][q] = w4[q];
-    }
     if (tid < NJ) { bw.par[tid] = m.parents[tid]; bw.dep[tid] = m.depth[tid]; }
     // every other global input of the workgroup in the same batch: the left hand's output gradients (for d L / d shift),
     // this hand's output gradients, v_posed and skeleton record, the joint gradients
@@ -512,7 +519,19 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
     }
 
     // ---- per vertex: d v_posed = T.R^T g, T.R = sum_j w_j A_j.R over all 16 joints (no branches: a zero weight adds
-    //      an exact zero), the matrices read from LDS as broadcast rows
+    //      an exact zero), the matrices read from LDS as broadcast rows.  Only the finger-pose and shape gradients need it.
+    if (need_pose || need_betas) {
+    // the skinning weights of this thread's (up to 4) vertices, all 16 loads in flight together (L2 hits; the other three
+    // resident workgroups of the CU cover the round trip)
+    float4 wreg[VR][4];
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+        const int v = min(tid + r * LBS_THREADS, NV - 1);
+        const float4* w4 = reinterpret_cast<const float4*>(m.weights + v * NJ);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wreg[r][q] = w4[q];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
         const int v = tid + r * LBS_THREADS;
@@ -536,10 +555,9 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
         const float g0 = bw.g[3 * v], g1 = bw.g[3 * v + 1], g2 = bw.g[3 * v + 2];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float d = T[c] * g0 + T[4 + c] * g1 + T[8 + c] * g2;
-            bw.dvp[3 * v + c] = d;
-            if (need_pose) wk.dvp[(size_t)h * NV3 + 3 * v + c] = d;
+            wk.dvp[(size_t)h * NV3 + 3 * v + c] = T[c] * g0 + T[4 + c] * g1 + T[8 + c] * g2;
         }
+    }
     }
     // ---- dA[j][e] = sum_v W[v][j] * [g (x) v_posed | g][e].  The CSR-by-joint list is cut into single-joint
     //      segments of <= 13 entries, one lane each (balanced: the wrist alone owns ~600 entries), then the
@@ -675,19 +693,31 @@ __global__ __launch_bounds__(LBS_THREADS, 3) void lbs_bwd1_kernel(ihmr_mano m, L
             __syncthreads();
         }
         const int wave = tid / WAVE, lane = tid % WAVE;
+        // d v_posed of this hand comes back from the workspace (written by this workgroup's per-vertex phase several
+        // barriers ago: visible to the whole workgroup); rows and gradients are fetched in two batches of 7 / 6 vertices
+        // per lane so that the loads of a batch are in flight together without exceeding the 128-register budget
+        const float* dvp_h = wk.dvp + (size_t)h * NV3;
         for (int l = wave; l < 10; l += LBS_THREADS / WAVE) {
-            float4 srow[NVP / WAVE];
-#pragma unroll
-            for (int t = 0; t < NVP / WAVE; ++t) srow[t] = m.sd4[l * NVP + lane + WAVE * t];  // padding rows are zero
-            __builtin_amdgcn_sched_barrier(0);
             float acc = 0.f;
 #pragma unroll
-            for (int t = 0; t < NVP / WAVE; ++t) {
-                const int v = lane + WAVE * t;
-                if (v < NV) {
-                    acc = __builtin_fmaf(srow[t].x, bw.dvp[3 * v], acc);
-                    acc = __builtin_fmaf(srow[t].y, bw.dvp[3 * v + 1], acc);
-                    acc = __builtin_fmaf(srow[t].z, bw.dvp[3 * v + 2], acc);
+            for (int half = 0; half < 2; ++half) {
+                constexpr int T0[2] = {0, 7}, T1[2] = {7, NVP / WAVE};
+                float4 srow[7];
+                float dv[7][3];
+#pragma unroll
+                for (int t = T0[half]; t < T1[half]; ++t) {
+                    const int v = min(lane + WAVE * t, NV - 1);
+                    srow[t - T0[half]] = m.sd4[l * NVP + lane + WAVE * t];  // padding rows are zero
+                    dv[t - T0[half]][0] = dvp_h[3 * v]; dv[t - T0[half]][1] = dvp_h[3 * v + 1]; dv[t - T0[half]][2] = dvp_h[3 * v + 2];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = T0[half]; t < T1[half]; ++t) {
+                    if (lane + WAVE * t < NV) {
+                        acc = __builtin_fmaf(srow[t - T0[half]].x, dv[t - T0[half]][0], acc);
+                        acc = __builtin_fmaf(srow[t - T0[half]].y, dv[t - T0[half]][1], acc);
+                        acc = __builtin_fmaf(srow[t - T0[half]].z, dv[t - T0[half]][2], acc);
+                    }
                 }
             }
             if (lane < 48) acc = __builtin_fmaf(m.J_shapedirs[lane * 10 + l], bw.dJ[lane / 3][lane % 3], acc);

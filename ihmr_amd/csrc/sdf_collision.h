@@ -607,11 +607,22 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
             const float wx1 = fx, wx0 = (x0 + 1.0f) - ix, wy1 = fy, wy0 = (y0 + 1.0f) - iy, wz1 = fz, wz0 = (z0 + 1.0f) - iz;
             const float* phi = ws.phi + (size_t)H * SDF_NVOX;
             float pv[8];
+            // the two x-neighbours of a cell are adjacent in memory: one load for the pair when both are inside the grid
+            // (4-byte aligned 8-byte load: the hardware takes dword-aligned global accesses of any width), single loads at
+            // the border of the grid
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) {
-                const int i = i0 + (c8 & 1), j = j0 + ((c8 >> 1) & 1), k = k0 + (c8 >> 2);
-                const bool in = i >= 0 && i < SDF_G && j >= 0 && j < SDF_G && k >= 0 && k < SDF_G;
-                pv[c8] = in ? phi[(k * SDF_G + j) * SDF_G + i] : 0.f;
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int j = j0 + (c4 & 1), k = k0 + (c4 >> 1);
+                const bool row_in = j >= 0 && j < SDF_G && k >= 0 && k < SDF_G;
+                const float* row = phi + (k * SDF_G + j) * SDF_G;
+                if (row_in && i0 >= 0 && i0 + 1 < SDF_G) {
+                    typedef float sdf_f2u __attribute__((ext_vector_type(2), aligned(4)));
+                    const sdf_f2u two = *reinterpret_cast<const sdf_f2u*>(row + i0);
+                    pv[2 * c4] = two.x; pv[2 * c4 + 1] = two.y;
+                } else {
+                    pv[2 * c4] = (row_in && i0 >= 0) ? row[i0] : 0.f;
+                    pv[2 * c4 + 1] = (row_in && i0 + 1 < SDF_G) ? row[i0 + 1] : 0.f;
+                }
             }
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) {
