@@ -95,18 +95,23 @@ __device__ __forceinline__ float sdf_unnorm(float x, int align_corners) {
     return align_corners ? ((x + 1.0f) / 2.0f) * (float)(SDF_G - 1) : ((x + 1.0f) * (float)SDF_G - 1.0f) / 2.0f;
 }
 
+// Workgroup barrier for phases that hand over LDS data only: waits for this wave's LDS operations, NOT for its global
+// stores (a __syncthreads() carries a workgroup-scope release fence, i.e. s_waitcnt vmcnt(0): every barrier of the prep
+// kernel would wait a full L2 round trip for the triangle records / phi stores issued before it)
+#define SDF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 // exclusive prefix sum of data[0..1023] (LDS) by SDF_PREP_THREADS threads, thread t owning the SDF_PREP_CPT adjacent
 // elements from SDF_PREP_CPT * t; returns the total.
 __device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >= SDF_PREP_THREADS / 64 ints, LDS */) {
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
-    __syncthreads();
+    SDF_LDS_BARRIER();
     int m[SDF_PREP_CPT], mine = 0;
 #pragma unroll
     for (int c = 0; c < SDF_PREP_CPT; ++c) { m[c] = data[SDF_PREP_CPT * tid + c]; mine += m[c]; }
     int wtot;
     const int inc = wave_incl_scan(mine, wtot);
     if (lane == WAVE - 1) scratch[wave] = wtot;
-    __syncthreads();
+    SDF_LDS_BARRIER();
     int base = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < SDF_PREP_THREADS / WAVE; ++w) {
@@ -114,11 +119,11 @@ __device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >
         if (w < wave) base += x;
         total += x;
     }
-    __syncthreads();
+    SDF_LDS_BARRIER();
     int run = base + inc - mine;
 #pragma unroll
     for (int c = 0; c < SDF_PREP_CPT; ++c) { data[SDF_PREP_CPT * tid + c] = run; run += m[c]; }
-    __syncthreads();
+    SDF_LDS_BARRIER();
     return total;
 }
 
@@ -203,6 +208,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
                                                                     int collect_stats) {
     __shared__ float vn[NV3];
     __shared__ unsigned needed[SDF_NCOL];
+    __shared__ unsigned rowany[SDF_G];      // bit j of word k: column (k,j) has a needed voxel
     __shared__ unsigned parity[SDF_NCOL];
     __shared__ int cur[SDF_NCOL];
     __shared__ float red[6][SDF_PREP_THREADS / WAVE];
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         needed[tid + rep * SDF_PREP_THREADS] = DENSE ? 0xffffffffu : 0u;
         parity[tid + rep * SDF_PREP_THREADS] = 0u;
     }
-    __syncthreads();
+    SDF_LDS_BARRIER();
     if (tid == 0) {
         float lo[3], hi[3];
 #pragma unroll
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         box[2] = (lo[2] + hi[2]) * 0.5f;
         box[3] = 0.6f * fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));  // (1 + 0.2) * 0.5 * max extent
     }
-    __syncthreads();
+    SDF_LDS_BARRIER();
     const float cx = box[0], cy = box[1], cz = box[2], sc = box[3];
     if (tid < 4) ws.box[H * 4 + tid] = box[tid];
     // ---- normalise own vertices into [-1,1]^3; which voxels will the other hand's vertices read?
@@ -294,7 +300,14 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             }
         }
     }
-    __syncthreads();
+    SDF_LDS_BARRIER();
+    // which columns of a row hold a needed voxel at all: a wave covers two rows per pass, one ballot gives both words
+#pragma unroll
+    for (int rep = 0; rep < SDF_PREP_CPT; ++rep) {
+        const unsigned long long any = __ballot(needed[tid + rep * SDF_PREP_THREADS] != 0u);
+        if (lane == 0) { rowany[2 * wave + 16 * rep] = (unsigned)any; rowany[2 * wave + 16 * rep + 1] = (unsigned)(any >> 32); }
+    }
+    SDF_LDS_BARRIER();
     // ---- lane = triangle: records for the distance kernel + ray parity of the needed voxels it can hit
     float4* sph = ws.sph + (size_t)H * NFP;
     float* rad = ws.rad + (size_t)H * NFP;
@@ -335,17 +348,24 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         const bool tri_safe = sdf_ray_tri_safe(e1x, e1y, e1z, e2x, e2y, e2z, inv);
         int j0, j1, k0, k1;
         tri_col_range(a[1], bb[1], c[1], a[2], bb[2], c[2], j0, j1, k0, k1);
-        // one flat loop over the bounding box's columns: a wave then iterates max(ncol) times, not
-        // max(k range) * max(j range) as two nested divergent loops would
-        const int ncol = (j1 >= j0 && k1 >= k0) ? (k1 - k0 + 1) * (j1 - j0 + 1) : 0;
-        int j = j0, k = k0;
-        for (int cidx = 0; cidx < ncol; ++cidx) {
+        // one flat loop over the NEEDED columns of the bounding box (row masks: no LDS round trip for a column nobody
+        // reads): a wave iterates max(rows + needed columns) times, not max(k range) * max(j range)
+        if (j1 < j0 || k1 < k0) continue;
+        const unsigned jmask = (j1 - j0 == 31 ? 0xffffffffu : ((1u << (j1 - j0 + 1)) - 1u)) << j0;
+        int k = k0;
+        unsigned cols = rowany[k0] & jmask;
+        for (;;) {
+            if (cols == 0u) {
+                if (++k > k1) break;
+                cols = rowany[k] & jmask;
+                continue;
+            }
+            const int j = __ffs((int)cols) - 1;
+            cols &= cols - 1u;
             const int col = k * SDF_G + j;
             const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
             const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
-            if (++j > j1) { j = j0; ++k; }
             const unsigned need = needed[col];
-            if (!need) continue;
             const float sy = py - a[1], sz = pz - a[2];
             const float uu = __builtin_fmaf(sz, e2y, -(sy * e2z)) * inv;
             const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y));
@@ -357,7 +377,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             if (hits) atomicXor(&parity[col], hits);
         }
     }
-    __syncthreads();
+    SDF_LDS_BARRIER();
     // ---- publish: a thread owns SDF_PREP_CPT adjacent columns; phi = 0 for the outside voxels, inside voxels
     //      into the batch-wide list
     float* phi = ws.phi + (size_t)H * SDF_NVOX;
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     // so every work item of the distance kernel belongs to exactly one hand
     const int blk_padded = (blk_total + SDF_ITEM - 1) & ~(SDF_ITEM - 1);
     if (tid == 0) { blk_inside = blk_total; blk_base = blk_total > 0 ? atomicAdd(&ws.inside_count[xcd], blk_padded) : 0; }
-    __syncthreads();
+    SDF_LDS_BARRIER();
     if (tid < blk_padded - blk_total) ws.inside_list[(size_t)xcd * ws.xcd_cap + blk_base + blk_total + tid] = 0xffffffffu;
 #pragma unroll
     for (int rep = 0; rep < SDF_PREP_CPT; ++rep) {
