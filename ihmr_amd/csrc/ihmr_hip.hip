@@ -233,8 +233,12 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
     }
     // timed pass: the kernel is idempotent (same inputs -> same phi), so it is launched IHMR_TIMED_REPEAT times between
     // ONE pair of events: the cost of the event records (measured by the empty pair) is spread over the repeats
+    // work items (16 inside voxels of one hand) are dealt to the workgroups with a stride; ~1800 items per 128 samples:
+    // 2048 workgroups up to there (one item each, no second table staging), 4096 beyond (measured at 512 samples:
+    // 1024 / 2048 / 3072 / 4096 workgroups 67.3 / 66.0 / 64.2 / 64.1 us)
+    const int dist_blocks = std::min(4096, std::max(SDF_DIST_BLOCKS, 32 * B));
     for (int rep = 0; rep < (timed ? IHMR_TIMED_REPEAT : 1); ++rep)
-        hipLaunchKernelGGL(sdf_dist_kernel, dim3(SDF_DIST_BLOCKS), dim3(SDF_THREADS), 0, st, ws, g_collect_stats);
+        hipLaunchKernelGGL(sdf_dist_kernel, dim3(dist_blocks), dim3(SDF_THREADS), 0, st, ws, g_collect_stats);
     if (timed) {
         HIP_TRY(hipEventRecord(tp.b, st));
         tp.flops = 0.0;

@@ -487,12 +487,14 @@ typedef float sdf_v2f __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace ws, int collect_stats) {
     __shared__ float4 sph_s[NFP];
     __shared__ float rad_s[NFP];
-    __shared__ unsigned short surv[SDF_THREADS / WAVE][SDF_SURV_CAP];
+    __shared__ unsigned pairs_s[SDF_THREADS / WAVE][SDF_SURV_CAP];   // (voxel slot << 16) | triangle: survivors of the wave's 4 voxels
+    __shared__ unsigned best_s[SDF_THREADS / WAVE][4];               // running min of the squared distance (float bits, >= 0: uint order)
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
     const int slot = blockIdx.x, nslot = gridDim.x;
     const int total = ws.inside_count[0];
     const unsigned* glist = ws.inside_list;
-    unsigned short* mylist = surv[wave];
+    unsigned* mypairs = pairs_s[wave];
+    unsigned* mybest = best_s[wave];
     int curH = -1;
     unsigned long long st_dist = 0;
     for (int item = slot; item * SDF_ITEM < total; item += nslot) {
@@ -507,6 +509,40 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
             curH = H;
         }
         const float4* abc = ws.abc + (size_t)H * NFP * 3;
+        // The survivors of the wave's (up to) four voxels are evaluated together, one (voxel, triangle) pair per lane: ~38 per
+        // voxel fill 59 % of a 64-lane round, the ~150 of four voxels fill three rounds of four.  Minimum per voxel through LDS
+        // atomics on the float bits (squared distances are >= +0, so unsigned order = float order; a NaN sorts above +inf
+        // and is ignored, as fminf does).
+        if (lane < 4) mybest[lane] = 0x7f800000u;
+        unsigned ent4[4];             // this wave's four list entries (uniform)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ent4[q] = (unsigned)__builtin_amdgcn_readlane((int)ent_l, wave * (SDF_ITEM / 4) + q);
+        int npair = 0;
+        auto flush = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (int base = 0; base < npair; base += WAVE) {
+                const int idx = base + lane;
+                if (idx < npair) {
+                    const unsigned pr = mypairs[idx];
+                    const int f = (int)(pr & 0xffffu), vs = (int)(pr >> 16);
+                    const int id = (int)((vs == 0 ? ent4[0] : (vs == 1 ? ent4[1] : (vs == 2 ? ent4[2] : ent4[3]))) & 0xffffu);
+                    const float qx = (float)(2 * (id & 31) + 1) / (float)SDF_G - 1.0f;
+                    const float qy = (float)(2 * ((id >> 5) & 31) + 1) / (float)SDF_G - 1.0f;
+                    const float qz = (float)(2 * (id >> 10) + 1) / (float)SDF_G - 1.0f;
+                    const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
+                    const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
+                    atomicMin(&mybest[vs], __float_as_uint(sdf_point_tri_dist2(a, b, c, qx, qy, qz)));
+                }
+            }
+            st_dist += (unsigned long long)(lane == 0 ? npair : 0);
+            npair = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        int nmine = 0;    // voxels of this wave
         // two voxels at a time through the sphere passes: the table is read once for both and the arithmetic
         // is on float pairs (packed fp32 instructions issue two lanes' worth per cycle)
         for (int e = wave * (SDF_ITEM / 4); e < (wave + 1) * (SDF_ITEM / 4); e += 2) {
@@ -549,29 +585,22 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
             }
             for (int v = 0; v < nvox; ++v) {
                 unsigned keepmask = v ? keep_b : keep_a;
-                const int id = v ? id1 : id0;
-                const float px = v ? PX.y : PX.x, py = v ? PY.y : PY.x, pz = v ? PZ.y : PZ.x;
+                const int vs = e - wave * (SDF_ITEM / 4) + v;
                 int cnt;
                 const int mine = __popc(keepmask);
                 int off = wave_incl_scan(mine, cnt) - mine;
-                float best = INFINITY;
                 if (cnt <= SDF_SURV_CAP) {
+                    if (npair + cnt > SDF_SURV_CAP) flush();
+                    off += npair;
                     while (keepmask) {
                         const int t = __ffs((int)keepmask) - 1;
                         keepmask &= keepmask - 1;
-                        mylist[off++] = (unsigned short)(lane + WAVE * t);
+                        mypairs[off++] = ((unsigned)vs << 16) | (unsigned)(lane + WAVE * t);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    for (int sidx = lane; sidx < cnt; sidx += WAVE) {
-                        const int f = mylist[sidx];
-                        const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
-                        const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
-                        best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
-                        st_dist += 1;
-                    }
+                    npair += cnt;
                 } else {   // (degenerate geometry) more survivors than list slots: every lane walks its own triangles
+                    const float px = v ? PX.y : PX.x, py = v ? PY.y : PY.x, pz = v ? PZ.y : PZ.x;
+                    float best = INFINITY;
                     while (keepmask) {
                         const int t = __ffs((int)keepmask) - 1;
                         keepmask &= keepmask - 1;
@@ -581,12 +610,18 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
                         best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
                         st_dist += 1;
                     }
+                    best = wave_reduce_min(best);
+                    if (lane == 0) atomicMin(&mybest[vs], __float_as_uint(best));
                 }
-                best = wave_reduce_min(best);
-                if (lane == 0) ws.phi[(size_t)H * SDF_NVOX + id] = sqrtf(best);
-                __builtin_amdgcn_wave_barrier();
+                ++nmine;
             }
         }
+        flush();
+        if (lane < nmine) {
+            const unsigned ent = lane == 0 ? ent4[0] : (lane == 1 ? ent4[1] : (lane == 2 ? ent4[2] : ent4[3]));
+            ws.phi[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = sqrtf(__uint_as_float(mybest[lane]));
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     if (collect_stats) {
         unsigned long long d = st_dist;
