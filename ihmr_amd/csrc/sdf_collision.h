@@ -29,6 +29,9 @@
 #define SDF_DIST_BLOCKS 2048          // >= the work items of two fused 64-sample batches (~1800): one item per workgroup, no second table staging; 4 workgroups (30 KB LDS, <= 128 VGPRs) per CU
 #endif
 #define SDF_SURV_CAP 512             // LDS slots per wave for the triangles surviving the sphere cull (typically ~40)
+#ifndef SDF_ITEM_RUN
+#define SDF_ITEM_RUN 2
+#endif
 #define SDF_ITEM 16                // inside voxels per work item of the distance kernel (one hand per item); power of two
 
 // Per-hand, per-iteration triangle tables:
@@ -497,7 +500,10 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
     unsigned* mybest = best_s[wave];
     int curH = -1;
     unsigned long long st_dist = 0;
-    for (int item = slot; item * SDF_ITEM < total; item += nslot) {
+    // a workgroup takes SDF_ITEM_RUN consecutive items at a time: consecutive items mostly belong to one hand, whose table is then
+    // staged once for the run
+    for (int item0 = slot * SDF_ITEM_RUN; item0 * SDF_ITEM < total; item0 += nslot * SDF_ITEM_RUN)
+    for (int item = item0; item < item0 + SDF_ITEM_RUN && item * SDF_ITEM < total; ++item) {
         const unsigned ent_l = lane < SDF_ITEM ? glist[item * SDF_ITEM + lane] : 0xffffffffu;
         const int H = (int)((unsigned)__builtin_amdgcn_readlane((int)ent_l, 0) >> 16);   // entry 0 of an item is always valid
         if (H != curH) {             // uniform over the workgroup (same item for all waves)
