@@ -82,14 +82,49 @@ def sources():
         osp.join(osp.dirname(_HERE), "include", "ihmr_hip.h")]
 
 
+HASH_PATH = osp.join(_HERE, "libihmr_hip.srchash")
+
+
+def _source_hash() -> str:
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for f in sources():
+        h.update(osp.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def is_stale() -> bool:
+    """The library is current iff the hash of its sources (+ flags) recorded at build time matches -- content, not mtimes:
+    the tree is copied to the GPU box, and several ranks may import at once."""
+    if not osp.isfile(LIB_PATH) or not osp.isfile(HASH_PATH):
+        return True
+    with open(HASH_PATH) as fh:
+        return fh.read().strip() != _source_hash()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc cross-compiles for gfx950 without a GPU (seconds)."""
-    if not force and osp.isfile(LIB_PATH) and all(osp.getmtime(LIB_PATH) >= osp.getmtime(s) for s in sources()):
+    """hipcc cross-compiles for gfx950 without a GPU (seconds).  Safe against concurrent callers (one rank per GPU): built
+    under a lock file into a temporary name, then renamed into place."""
+    if not force and not is_stale():
         return LIB_PATH
-    cmd = ["hipcc"] + HIPCC_FLAGS + [osp.join(SRC_DIR, "ihmr_hip.hip"), "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or is_stale():             # another process may have built it while this one waited
+                tmp = f"{LIB_PATH}.tmp{os.getpid()}"
+                cmd = ["hipcc"] + HIPCC_FLAGS + [osp.join(SRC_DIR, "ihmr_hip.hip"), "-o", tmp]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB_PATH)
+                with open(HASH_PATH + ".tmp", "w") as fh:
+                    fh.write(_source_hash())
+                os.replace(HASH_PATH + ".tmp", HASH_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
