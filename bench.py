@@ -86,13 +86,15 @@ def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=32, iters_per_stage=8):
                 ms_per_refine_iter=runs[best]["ms_per_refine_iter"])
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of ``kernel`` from the newest committed rocprofv3 PMC summary (``profiles/*_pmc_traffic.csv``,
-    produced by ``scripts/profile_round.sh`` = two separate ``--pmc`` passes of this very command, FETCH_SIZE doubled
-    per the gfx950 correction).  Counters cannot be read from inside the process, so this is the profile's figure."""
-    import csv, glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9]*_v[0-9]*_pmc_traffic.csv")),
-                   key=lambda f: [int(x) for x in __import__("re").findall(r"\d+", os.path.basename(f))[:2]])
+def pmc_traffic(kernel, batches_per_launch):
+    """HBM bytes per launch of ``kernel`` from the newest committed rocprofv3 PMC summary taken at THIS launch size
+    (``profiles/r<round>_v<n>_f<batches per launch>_pmc_traffic.csv``, produced by ``FUSE=<g> scripts/profile_round.sh`` = two
+    separate ``--pmc`` passes of this very command at ``--streams 1``, FETCH_SIZE doubled per the gfx950 correction).  Counters
+    cannot be read from inside the process, so this is the profile's figure; None when no profile of that launch size exists."""
+    import csv, glob, re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                          f"r[0-9]*_v[0-9]*_f{batches_per_launch}_pmc_traffic.csv")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))[:2]])
     if not files:
         return None, None
     with open(files[-1], newline="") as fh:
@@ -245,7 +247,7 @@ def main():
                     help="skip the untimed-by-the-driver extras of the line: single-batch latency, H2D-inclusive rate, batch-512 run, "
                          "secondary configs (profiling runs: keeps the kernel summary to the main workload)")
     ap.add_argument("--no-single-batch-roofline", action="store_true", help="(kept for old scripts; implied by --no-extras)")
-    ap.add_argument("--fuse", type=int, default=8,
+    ap.add_argument("--fuse", type=int, default=10,
                     help="batches of --batch samples carried by ONE launch sequence (opt.fuse_batches; per-sample arithmetic "
                          "identical to separate batches); batches in flight = streams x fuse")
     ap.add_argument("--streams", type=int, default=2,
@@ -285,9 +287,10 @@ def main():
     S, G = max(1, args.streams), max(1, args.fuse)
     n_iters = 4 * (args.epoch + 1)
     # Batches in flight = S x G.  The kernels of one 64-sample batch are latency-bound and fill at most half of the
-    # 256 CUs, so the work is made large first: one launch sequence carries G = 8 batches (512 samples, the reference's
-    # own per-process batch, bash/optimize.sh:11,33; opt.fuse_batches keeps every sample's arithmetic that of a
-    # 64-sample batch, tests/test_gpu_parity.py), and two such sequences run on two HIP streams so that one's small
+    # 256 CUs, so the work is made large first: one launch sequence carries up to G = 10 batches (the default 64 steps run as
+    # 2 x 4 sequences of 8 batches = 512 samples, the reference's own per-process batch, bash/optimize.sh:11,33; 20 steps as
+    # 2 sequences of 10; opt.fuse_batches keeps every sample's arithmetic that of a 64-sample batch,
+    # tests/test_gpu_parity.py), and two such sequences run on two HIP streams so that one's small
     # per-sample kernels overlap the other's collision kernels.  No runtime knobs (hardware-queue counts etc.) involved.
     # --batch 512 --streams 1 --fuse 1 is the reference's recipe verbatim: ONE sequence over a real batch of 512.
     def make_model(fuse, batch=B):
@@ -442,14 +445,15 @@ def main():
             if avg_ms > 0:
                 tot_flops += flops * sizes_run[g]
                 tot_ms += avg_ms * sizes_run[g]
-        # the committed PMC summary is of EIGHT-batch launches (FUSE=8 scripts/profile_round.sh): quoted only when that is the
-        # launch size the timed region ran
-        traffic, traffic_src = pmc_traffic("sdf_dist_kernel") if (B == 64 and args.epoch == 49 and set(sizes_run) == {8}) else (None, None)
+        # HBM traffic: the committed PMC summary of the launch size that carried most of the timed region's work
+        g_main = max(sizes_run, key=lambda g: g * sizes_run[g])
+        traffic, traffic_src = pmc_traffic("sdf_dist_kernel", g_main) if (B == 64 and args.epoch == 49) else (None, None)
         ach = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None
         roofline = dict(bound="valu", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=(ach / FP32_PEAK_TFLOPS) if ach else None,
                         traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
-                        traffic_note="HBM bytes of an eight-batch launch from the committed rocprofv3 PMC summary of this command at "
-                                     "--streams 1 (counters cannot be read from inside the process), not of this run",
+                        traffic_batches_per_launch=g_main,
+                        traffic_note="HBM bytes per launch from the committed rocprofv3 PMC summary of this command at --streams 1 and "
+                                     "the same launch size (counters cannot be read from inside the process), not of this run",
                         kernel="sdf_dist_kernel", by_launch_size=per_size,
                         note="largest share of GPU time in the rocprofv3 kernel summary (profiles/).  Pure fp32 VALU kernel (compares, "
                              "selects, FMAs; no GEMM shape): priced against the 157.3 TFLOP/s fp32 vector peak.  `achieved` = "

@@ -502,8 +502,10 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
     unsigned long long st_dist = 0;
     // a workgroup takes SDF_ITEM_RUN consecutive items at a time: consecutive items mostly belong to one hand, whose table is then
     // staged once for the run
-    for (int item0 = slot * SDF_ITEM_RUN; item0 * SDF_ITEM < total; item0 += nslot * SDF_ITEM_RUN)
-    for (int item = item0; item < item0 + SDF_ITEM_RUN && item * SDF_ITEM < total; ++item) {
+    // (only when there are more items than workgroups: a single 64-sample batch has ~900 items for 2048 workgroups, one each)
+    const int run = (total + SDF_ITEM - 1) / SDF_ITEM > nslot ? SDF_ITEM_RUN : 1;
+    for (int item0 = slot * run; item0 * SDF_ITEM < total; item0 += nslot * run)
+    for (int item = item0; item < item0 + run && item * SDF_ITEM < total; ++item) {
         const unsigned ent_l = lane < SDF_ITEM ? glist[item * SDF_ITEM + lane] : 0xffffffffu;
         const int H = (int)((unsigned)__builtin_amdgcn_readlane((int)ent_l, 0) >> 16);   // entry 0 of an item is always valid
         if (H != curH) {             // uniform over the workgroup (same item for all waves)

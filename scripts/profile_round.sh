@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel trace (+stats) and the two HBM-traffic PMC passes of the SAME bench command.
-# usage: scripts/profile_round.sh <tag>      -> gpurun_out/<tag>_kernel_stats.csv, <tag>_pmc_{fetch,write}.csv
+# usage: FUSE=<batches per launch> STEPS=<n> scripts/profile_round.sh <tag>   -> gpurun_out/<tag>_f<FUSE>_kernel_stats.csv, _pmc_traffic.csv, _pmc_sq.csv
 # (rocprofv3 gets the program itself after `--`; counters run separately from the trace, one TCC counter per pass.)
-tag=${1:-rX}
+tag=${1:-rX}_f${FUSE:-8}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 CMD="python3 bench.py --steps ${STEPS:-2} --warmup 1 --streams 1 --fuse ${FUSE:-8} --no-cpu-baseline --no-extras"
