@@ -184,7 +184,7 @@ class Evaluator:
     def metrics_from_sums(s):
         d = lambda a, b: float(a / b) if b > 0 else float("nan")
         out = dict(mpjpe_3d=d(s[0], s[1]), inter_mpjpe_3d=d(s[2], s[3]), collision_ave=d(s[4], s[6]), collision_max=d(s[5], s[6]))
-        if len(s) > 8:
+        if len(s) > 8 and s[8] > 0:        # only the models that export GT meshes (IHMR-Baseline / IHMR-MLP) have it
             out["mpvpe_3d"] = d(s[7], s[8])
         return out
 
@@ -197,4 +197,4 @@ class Evaluator:
     @property
     def collision_max(self): return self.metrics_from_sums(self.metric_sums())["collision_max"]
     @property
-    def mpvpe_3d(self): return self.metrics_from_sums(self.metric_sums())["mpvpe_3d"]
+    def mpvpe_3d(self): return self.metrics_from_sums(self.metric_sums()).get("mpvpe_3d", float("nan"))

@@ -95,13 +95,21 @@ def _source_hash() -> str:
     return h.hexdigest()
 
 
+def _file_hash(path: str) -> str:
+    import hashlib
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
 def is_stale() -> bool:
-    """The library is current iff the hash of its sources (+ flags) recorded at build time matches -- content, not mtimes:
-    the tree is copied to the GPU box, and several ranks may import at once."""
+    """The library is current iff the record written at build time matches BOTH the hash of the sources (+ flags) and the hash
+    of the shared object itself -- content, not mtimes: the tree is copied to the GPU box, several ranks may import at once,
+    and a library written by anything but :func:`build` (an experiment's hipcc line) must not pass for the product."""
     if not osp.isfile(LIB_PATH) or not osp.isfile(HASH_PATH):
         return True
     with open(HASH_PATH) as fh:
-        return fh.read().strip() != _source_hash()
+        rec = fh.read().split()
+    return len(rec) != 2 or rec[0] != _source_hash() or rec[1] != _file_hash(LIB_PATH)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -121,7 +129,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 subprocess.check_call(cmd)
                 os.replace(tmp, LIB_PATH)
                 with open(HASH_PATH + ".tmp", "w") as fh:
-                    fh.write(_source_hash())
+                    fh.write(_source_hash() + " " + _file_hash(LIB_PATH))
                 os.replace(HASH_PATH + ".tmp", HASH_PATH)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

@@ -245,6 +245,16 @@ def test_device_evaluator_matches_host_evaluator():
     assert got[8] == ref[8] == 0      # no meshes were given: MPVPE has no samples
 
 
+def test_run_optimize_sgd_option():
+    """`--optimizer sgd` (options/opt_options.py) reaches the fused step: finite metrics that differ from Adam's."""
+    from ihmr_amd import run_optimize
+    base = ["--num_samples", "8", "--batchSize", "8", "--opt_epoch", "3", "--save_mid_freq", "1"]
+    m_adam = run_optimize.main(base)
+    m_sgd = run_optimize.main(base + ["--optimizer", "sgd"])
+    assert all(np.isfinite(v) for v in m_sgd.values())
+    assert m_sgd["mpjpe_3d"] != m_adam["mpjpe_3d"]
+
+
 def test_run_optimize_device_and_host_eval_agree():
     from ihmr_amd import run_optimize
     base = ["--num_samples", "20", "--batchSize", "8", "--opt_epoch", "2", "--save_mid_freq", "1"]   # 20 -> padded to 24
