@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 vector == FP32 (f32-input) MFMA dense peak
+TIMED_REPEAT = 8          # IHMR_TIMED_REPEAT of csrc/ihmr_hip.hip: launches of sdf_dist_kernel per event bracket of a timed pass
 
 
 def make_opt(B, epoch, freq, rank):
@@ -247,6 +248,9 @@ def main():
                     help="skip the untimed-by-the-driver extras of the line: single-batch latency, H2D-inclusive rate, batch-512 run, "
                          "secondary configs (profiling runs: keeps the kernel summary to the main workload)")
     ap.add_argument("--no-single-batch-roofline", action="store_true", help="(kept for old scripts; implied by --no-extras)")
+    ap.add_argument("--no-work-counters", action="store_true",
+                    help="skip the untimed pass that reads the collision kernels' work counters (global atomics: they would distort a "
+                         "rocprofv3 profile of this command); roofline.achieved is then null, the launch times stay")
     ap.add_argument("--fuse", type=int, default=10,
                     help="batches of --batch samples carried by ONE launch sequence (opt.fuse_batches; per-sample arithmetic "
                          "identical to separate batches); batches in flight = streams x fuse")
@@ -424,25 +428,35 @@ def main():
             torch.cuda.synchronize()
             hip.lib().ihmr_flush_kernel_timer()
             hip.lib().ihmr_set_kernel_timer(None)
-            # counters at the end state and at the initial state of the refinement, averaged (one launch = g batches)
-            st_end = mdl.collect_sdf_stats()
-            mdl.set_input(inputs[g]); mdl.init_optimize()
-            st_ini = mdl.collect_sdf_stats()
+            # work EXECUTED per launch, from the kernels' own counters (DESIGN.md "Measurement"): the same refinement once more,
+            # untimed (the counters are global atomics), one sdf_prep_kernel + one sdf_dist_kernel launch per iteration
+            stats, flops = None, None
+            if not args.no_work_counters:
+                mdl.set_input(inputs[g]); mdl.init_optimize()
+                mdl.sdf_counters_start()
+                mdl.optimize(0, 1)
+                cnt = mdl.sdf_counters_stop()
+                n_launch = n_iter = max(int(timer.n_sdf_eval) // TIMED_REPEAT, 1)
+                stats = dict(sphere_tests=cnt["sphere_tests"] / n_launch, dist_evals=cnt["dist_evals"] / n_launch,
+                             voxels_from_lists=cnt["voxels_from_lists"] / n_launch,
+                             voxels_full_search=(cnt["voxels_without_list"] + cnt["voxels_rebuilt"]) / n_launch,
+                             inside_voxels=cnt["inside_voxels"] / n_iter, needed_voxels=cnt["needed_voxels"] / n_iter,
+                             ray_tests=cnt["ray_tests"] / n_iter)
+                # flops of ONE launch: 11 per bounding-sphere test (|p - centroid|^2: 8, cull test: 3) and 75 per exact
+                # point-triangle distance -- what the kernel executed; a full search of every inside voxel (the kernel without its
+                # candidate lists, round 1's model) would execute 1538 sphere tests per inside voxel
+                flops = 11.0 * stats["sphere_tests"] + 75.0 * stats["dist_evals"]
             mdl.use_graphs = graphs
-            stats = {k: 0.5 * (st_ini[k] + st_end[k]) for k in st_ini}
-            # algorithmic flops of ONE launch (DESIGN.md "Measurement"): per inside voxel the sphere pass over all 1538
-            # triangles (8 flops: |p - centroid|^2) and the cull test (3 flops), plus 75 flops per exact point-triangle
-            # distance that survives the cull
-            flops = 1538 * 11.0 * stats["inside_voxels"] + 75.0 * stats["dist_evals"]
             # launch duration = event-bracketed time minus the cost of an (empty) event pair recorded right before it
             avg_ms = (timer.ms_sdf_eval - timer.ms_event_pair) / max(timer.n_sdf_eval, 1)
-            ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else None
+            ach = flops / (avg_ms * 1e-3) / 1e12 if (avg_ms > 0 and flops) else None
             per_size.append(dict(batches_per_launch=g, launch_sequences_in_timed_region=sizes_run[g], avg_launch_ms=avg_ms,
                                  avg_event_bracket_ms=timer.ms_sdf_eval / max(timer.n_sdf_eval, 1), launches_timed=int(timer.n_sdf_eval),
                                  algorithmic_flops_per_launch=flops, work_per_launch=stats, achieved=ach,
+                                 full_search_flops_per_launch=(1538 * 11.0 * stats["inside_voxels"] + 75.0 * stats["dist_evals"]) if stats else None,
                                  frac=(ach / FP32_PEAK_TFLOPS) if ach else None,
-                                 brute_force_equivalent_tflops=stats["inside_voxels"] * 1538 * 100.0 / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else None))
-            if avg_ms > 0:
+                                 brute_force_equivalent_tflops=stats["inside_voxels"] * 1538 * 100.0 / (avg_ms * 1e-3) / 1e12 if (avg_ms > 0 and stats) else None))
+            if avg_ms > 0 and flops:
                 tot_flops += flops * sizes_run[g]
                 tot_ms += avg_ms * sizes_run[g]
         # HBM traffic: the committed PMC summary of the launch size that carried most of the timed region's work
@@ -457,8 +471,11 @@ def main():
                         kernel="sdf_dist_kernel", by_launch_size=per_size,
                         note="largest share of GPU time in the rocprofv3 kernel summary (profiles/).  Pure fp32 VALU kernel (compares, "
                              "selects, FMAs; no GEMM shape): priced against the 157.3 TFLOP/s fp32 vector peak.  `achieved` = "
-                             "algorithmic flops / HIP-event launch time, aggregated over the launch sizes the timed region ran "
-                             "(by_launch_size), each timed in a single-stream pass")
+                             "flops the kernel executed (its own counters: 11 per bounding-sphere test, 75 per exact point-triangle "
+                             "distance) / HIP-event launch time, aggregated over the launch sizes the timed region ran "
+                             "(by_launch_size), each timed in a single-stream pass.  The candidate lists remove work (see "
+                             "full_search_flops_per_launch for the same voxels without them), so this fraction is not comparable "
+                             "with round 1's; compare launch times (by_launch_size[].avg_launch_ms)")
 
     # ---- single-batch latency: ONE batch of --batch samples, one stream, nothing else in flight.
     #      ms/refine-iter = stage-loop wall time / iterations (excludes set_input and the export); images/s = batch /

@@ -20,7 +20,7 @@
 
 static ihmr_kernel_timer* g_timer = nullptr;
 #define IHMR_TIMED_REPEAT 8
-struct TimedPair { hipEvent_t e0, e1, a, b; double flops; };   // (e0,e1): an empty pair right before, the cost of the events themselves
+struct TimedPair { hipEvent_t e0, e1, a, b; double flops; int reps; };   // (e0,e1): an empty pair right before, the cost of the events themselves
 static std::vector<TimedPair> g_pending;
 
 // ------------------------------------------------------------------------------------------ model
@@ -242,6 +242,7 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
     if (timed) {
         HIP_TRY(hipEventRecord(tp.b, st));
         tp.flops = 0.0;
+        tp.reps = IHMR_TIMED_REPEAT;
         g_pending.push_back(tp);
     }
     if (loss)
@@ -308,16 +309,20 @@ extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
 // `prev` = the Adam step of the previous iteration (group < 0: none), applied at the head of the skeleton kernel
 static const ParamStep kNoStep{0, 0.f, 0.f, 1.f, -1, 0, 0};
 // reuse_v_posed: the workspace holds v_posed of the current pose and shape parameters (see lbs_skin_kernel)
+// lists: temporal candidate lists of the collision kernels -- 0 off (single-shot callers), 1 reuse while valid, 2 rebuild now
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
-                       const ihmr_opt_weights& w, const ParamStep& prev, hipStream_t st, int need_cam = 0, bool reuse_v_posed = false) {
-    hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B).inside_count);
+                       const ihmr_opt_weights& w, const ParamStep& prev, hipStream_t st, int need_cam = 0, bool reuse_v_posed = false,
+                       int lists = 0) {
+    hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B, true).inside_count);
     if (reuse_v_posed)
         hipLaunchKernelGGL((lbs_skin_kernel<true, true>), dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m,
                            (const float*)wk.lbs.skel, 2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
     else
         hipLaunchKernelGGL((lbs_skin_kernel<true, false>), dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m,
                            (const float*)wk.lbs.skel, 2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
-    SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
+    SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B, true);
+    ws.list_mode = (lists != 0 && !io->sdf_no_candidate_lists) ? 1 : 0;
+    ws.force_rebuild = lists == 2 ? 1 : 0;
     ws.align_corners = io->sdf_align_corners ? 1 : 0;
     if (io->sdf_loss_divisor > 0.f) ws.loss_div = io->sdf_loss_divisor;
     VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
@@ -355,7 +360,9 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     // a stage that moves neither the finger pose nor the shape keeps v_posed: computed in its first iteration, reused after
     const bool vposed_fixed = (pm & (IHMR_PB_POSE_R | IHMR_PB_POSE_L | IHMR_PB_SHAPE_R | IHMR_PB_SHAPE_L)) == 0;
     for (int it = 0; it < sg->n_iters; ++it) {
-        int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, vposed_fixed && it > 0);   // applies the step of iteration it - 1 first
+        // the first iteration of a stage starts the candidate lists over: the select step of the previous stage may have moved
+        // the parameters by more than one optimizer step
+        int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, vposed_fixed && it > 0, it == 0 ? 2 : 1);   // applies the step of iteration it - 1 first
         if (rc) return rc;
         if (need_mask)
             lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
@@ -440,7 +447,7 @@ extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, c
     if (!m || !io || !w || !out4 || B <= 0) return -1;
     hipStream_t st = (hipStream_t)stream;
     OptWork wk = opt_carve(io->workspace, B);
-    SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B);
+    SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B, true);
     HIP_TRY(hipMemsetAsync(ws.stats, 0, 64, st));
     ihmr_kernel_timer* keep = g_timer;
     g_timer = nullptr;
@@ -451,6 +458,25 @@ extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, c
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(out4, ws.stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// diagnostics of the fused loop: enable = 1 zeroes the SDF work counters and switches them on for every launch recorded or issued
+// afterwards (a stage graph captured while they are on keeps counting); enable = 0 synchronises, copies the eight counters out
+// (ray tests, exact distances, inside voxels, needed voxels, bounding-sphere tests, voxels answered from candidate lists, voxels
+// of such hands handed to the full search, voxels whose lists were rebuilt) and switches them off.
+extern "C" int ihmr_opt_sdf_counters(const ihmr_opt_io* io, int B, unsigned long long* out8, int enable) {
+    if (!io || B <= 0) return -1;
+    SdfWorkspace ws = sdf_carve(opt_carve(io->workspace, B).sdf_ws, 2 * B, true);
+    HIP_TRY(hipDeviceSynchronize());
+    if (enable) {
+        HIP_TRY(hipMemset(ws.stats, 0, 64));
+        g_collect_stats = 1;
+        return 0;
+    }
+    g_collect_stats = 0;
+    if (!out8) return -1;
+    HIP_TRY(hipMemcpy(out8, ws.stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -745,7 +771,7 @@ extern "C" int ihmr_flush_kernel_timer(void) {
         HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
         float ms_empty = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms_empty, p.e0, p.e1));
-        if (g_timer) { g_timer->ms_sdf_eval += ms; g_timer->n_sdf_eval += IHMR_TIMED_REPEAT; g_timer->ms_event_pair += ms_empty; }
+        if (g_timer) { g_timer->ms_sdf_eval += ms; g_timer->n_sdf_eval += p.reps; g_timer->ms_event_pair += ms_empty; }
         (void)hipEventDestroy(p.e0);
         (void)hipEventDestroy(p.e1);
         (void)hipEventDestroy(p.a);

@@ -32,7 +32,7 @@ static inline size_t opt_ws_bytes(int B) {
     n += (size_t)B * (3 + 6 + 90 + 20 + 3 + 3 + 1) * 4;
     n = (n + 255) & ~(size_t)255;
     n += 8192;
-    return n + sdf_ws_bytes(2 * B);
+    return n + sdf_ws_bytes(2 * B, true);
 }
 
 static inline OptWork opt_carve(void* ws, int B) {

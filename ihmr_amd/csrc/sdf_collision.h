@@ -14,7 +14,13 @@
 //     per-iteration triangle table -- and only the surviving candidates are tested per voxel (t > 0);
 //   * the distance of an inside voxel is a wave-level min-reduction: lanes across triangles,
 //     culled by a bounding-sphere lower bound against a wave-wide upper bound (exact: a culled
-//     triangle can never be the minimum).
+//     triangle can never be the minimum);
+//   * inside the fused refinement loop the hands move a little per iteration: every inside voxel
+//     keeps a candidate list (the triangles that can be nearest while the hand stays within a slack
+//     of the pose the list was built at) and its last nearest triangle; while the lists are valid a
+//     voxel is answered from its <= 192 candidates instead of all 1538 triangles (list search), the
+//     full search only sees new voxels and hands that moved beyond the slack.  Same minimum, bit
+//     for bit (tests/test_gpu_parity.py::test_candidate_lists_do_not_change_a_bit).
 #pragma once
 #include "ihmr_common.h"
 
@@ -35,11 +41,10 @@
 #define SDF_ITEM 16                // inside voxels per work item of the distance kernel (one hand per item); power of two
 
 // Per-hand, per-iteration triangle tables:
-//   sph[f] = (-2 cx, -2 cy, -2 cz, |c|^2) of the bounding sphere about the centroid c: the squared distance of a
-//            point p to c is |p|^2 + dot((p,1), sph[f]) -- three FMAs instead of three subtractions and three FMAs
-//            (the distance kernel uses it only for conservative culling, with a margin for the cancellation);
-//            padding triangles are parked at 1e18, so arithmetic alone culls them
-//   rad[f] = bounding radius (conservative)
+//   sph[f] = (cx, cy, cz, r): bounding sphere about the centroid c, conservative radius (the distance kernel uses it only for
+//            conservative culling); padding triangles are parked at 1e18, so arithmetic alone culls them.  Goes to LDS as it
+//            is (direct global -> LDS loads)
+//   rad[f] = r again, as a plain array (conflict-free LDS reads for the lanes-across-triangles pass)
 //   abc[f] = {a,0} {b,0} {c,0}                                                           (exact distance)
 struct SdfWorkspace {          // carved from the caller's workspace; H = 2B hands, hand id = hnd*B + b
     float* box;                // [H][4]  centre xyz, scale
@@ -51,6 +56,16 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     int* inside_count;         // [8] (slot 0 in use)
     unsigned long long* stats; // [8] optional work counters
     int xcd_cap;
+    // candidate lists of the fused refinement loop (list_mode 0 = off: single-shot callers)
+    float* vn_ref;             // [H][2334]  normalised vertices of the hand when its lists were built
+    int* hmode;                // [H]        this iteration: 0 = lists are being (re)built, 1 = lists are valid (written by the prep kernel)
+    int* run_start;            // [H]        first entry of the hand's run in its list (this iteration)
+    unsigned* lbits;           // [H][1024]  bit i of word (k,j): voxel (k,j,i) has a candidate list (cleared when the hand starts over)
+    unsigned* lmap;            // [H][32768] voxel -> its list | (the triangle that was nearest the last time it was evaluated) << 16
+                               //            (defined where lbits is set)
+    unsigned short* lists;     // [H][SDF_LCAP_V][SDF_LCAP_L] triangle ids
+    unsigned* inside_list_a;   // [xcd_cap] inside voxels of the hands whose lists are valid (unpadded run per hand; inside_count[1])
+    int list_mode, force_rebuild;
     // conventions of the upstream module that nothing in the reference pins (ihmr_sdf_options; defaults = DESIGN.md section 4)
     int align_corners;         // grid_sample(align_corners): 0 = False (the default of the reference's pinned torch 1.6.0)
     float loss_div;            // loss[b] = sum of the 1556 sampled values / loss_div (4 = num_hands^2 of the parent project)
@@ -58,8 +73,17 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
 
 __host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)H * (SDF_NVOX + SDF_ITEM); }   // one batch-wide list
 
-__host__ __device__ inline size_t sdf_ws_bytes(int H) {
-    size_t n = 0;
+#define SDF_LCAP_V 1024              // candidate lists per hand (one per inside voxel, in the order of the hand's run at build time)
+#define SDF_LCAP_L 192               // triangles per list (three 64-lane chunks; a voxel whose list would be longer gets none)
+#define SDF_LIST_K 8                 // lanes that share one voxel's list in sdf_list_search; list element i is stored at (i % K) * (L / K) + i / K
+#define SDF_LIST_ITEM (4 * (WAVE / SDF_LIST_K))   // voxels per work item of sdf_list_search (4 waves)
+#define SDF_LIST_SLACK 0.04f         // lists stay valid while no vertex of the hand has moved further than this (normalised frame)
+__host__ __device__ inline size_t sdf_list_bytes(int H) {
+    return (size_t)H * ((size_t)NV3 * 4 + 8 + (size_t)SDF_NCOL * 4 + (size_t)SDF_NVOX * 4 + (size_t)SDF_LCAP_V * SDF_LCAP_L * 2) +
+           sdf_xcd_cap(H) * sizeof(unsigned) + 1024;
+}
+__host__ __device__ inline size_t sdf_ws_bytes(int H, bool lists = false) {
+    size_t n = lists ? sdf_list_bytes(H) : 0;
     n += (size_t)H * 4 * sizeof(float);
     n += (size_t)H * NFP * 4 * sizeof(float4);      // sph + abc
     n += (size_t)H * NFP * sizeof(float);           // rad
@@ -69,7 +93,7 @@ __host__ __device__ inline size_t sdf_ws_bytes(int H) {
     return (n + 255) & ~(size_t)255;
 }
 
-static inline SdfWorkspace sdf_carve(void* ws, int H) {
+static inline SdfWorkspace sdf_carve(void* ws, int H, bool lists = false) {
     SdfWorkspace w;
     char* p = (char*)ws;
     w.box = (float*)p; p += (size_t)H * 4 * sizeof(float);
@@ -80,7 +104,22 @@ static inline SdfWorkspace sdf_carve(void* ws, int H) {
     w.stats = (unsigned long long*)p; p += 64;
     w.inside_count = (int*)p; p += 64;
     w.xcd_cap = (int)sdf_xcd_cap(H);
-    w.inside_list = (unsigned*)p;
+    w.inside_list = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
+    w.vn_ref = nullptr; w.hmode = nullptr; w.run_start = nullptr; w.lbits = nullptr; w.lmap = nullptr; w.lists = nullptr;
+    w.inside_list_a = nullptr;
+    w.list_mode = 0; w.force_rebuild = 1;
+    if (lists) {
+        p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+        w.vn_ref = (float*)p; p += (size_t)H * NV3 * 4;
+        w.hmode = (int*)p; p += (size_t)H * 4;
+        w.run_start = (int*)p; p += (size_t)H * 4;
+        p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+        w.lbits = (unsigned*)p; p += (size_t)H * SDF_NCOL * 4;
+        w.inside_list_a = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
+        w.lmap = (unsigned*)p; p += (size_t)H * SDF_NVOX * 4;
+        p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+        w.lists = (unsigned short*)p;
+    }
     w.align_corners = 0;
     w.loss_div = 4.0f;
     return w;
@@ -102,6 +141,18 @@ __device__ __forceinline__ float sdf_unnorm(float x, int align_corners) {
 // stores (a __syncthreads() carries a workgroup-scope release fence, i.e. s_waitcnt vmcnt(0): every barrier of the prep
 // kernel would wait a full L2 round trip for the triangle records / phi stores issued before it)
 #define SDF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// A hand's table, global -> LDS without passing through registers (global_load_lds: the LDS address is wave-uniform base + lane *
+// size, the layout stays linear).  Asynchronous: the caller goes on issuing its other loads and closes with __syncthreads()
+// (which waits for the workgroup's outstanding memory operations).  n16 16-byte units by 256 threads.
+__device__ __forceinline__ void sdf_stage_async(const void* __restrict__ src, char* dst_lds, int n16) {
+    const int tid = threadIdx.x, wave = tid / WAVE;
+    for (int base = wave * WAVE; base < n16; base += SDF_THREADS) {
+        if (base + (tid % WAVE) < n16)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(src) + (size_t)(base + tid % WAVE) * 16,
+                                             (__attribute__((address_space(3))) void*)(dst_lds + (size_t)base * 16), 16, 0, 0);
+    }
+}
 
 // exclusive prefix sum of data[0..1023] (LDS) by SDF_PREP_THREADS threads, thread t owning the SDF_PREP_CPT adjacent
 // elements from SDF_PREP_CPT * t; returns the total.
@@ -206,7 +257,7 @@ __device__ __forceinline__ unsigned sdf_ray_hits(unsigned need, bool tri_safe, f
 }
 
 template <bool DENSE>
-__global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout vl, int B, const int32_t* __restrict__ faces_r,
+__global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayout vl, int B, const int32_t* __restrict__ faces_r,
                                                                     const int32_t* __restrict__ faces_l, SdfWorkspace ws,
                                                                     int collect_stats) {
     __shared__ float vn[NV3];
@@ -217,7 +268,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
     __shared__ float red[6][SDF_PREP_THREADS / WAVE];
     __shared__ float box[4];
     __shared__ int scratch[SDF_PREP_THREADS / WAVE];
-    __shared__ int blk_inside, blk_base;
+    __shared__ int blk_inside, blk_base, blk_base_a;
     const int H = blockIdx.x, hnd = H / B, b = H % B, tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
     const float* own = vl.hand(b, hnd);
     const float* other = vl.hand(b, 1 - hnd);
@@ -248,6 +299,20 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         const int f = min(tid + it * SDF_PREP_THREADS, NFP - 1);
         fidx[it][0] = faces[f]; fidx[it][1] = faces[NFP + f]; fidx[it][2] = faces[2 * NFP + f];
     }
+    // state of the temporal candidate lists, requested now and used much later: the hand's reference pose (this thread's vertices)
+    // and which voxels of this thread's two columns have a list
+    const bool lists_on = !DENSE && ws.list_mode != 0;
+    float rf[SDF_PREP_VPT][3];
+    unsigned lb2[SDF_PREP_CPT];
+#pragma unroll
+    for (int rep = 0; rep < SDF_PREP_VPT; ++rep) {
+        const int v = tid + rep * SDF_PREP_THREADS;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rf[rep][k] = (lists_on && !ws.force_rebuild && v < NV) ? ws.vn_ref[(size_t)H * NV3 + 3 * v + k] : 0.f;
+    }
+#pragma unroll
+    for (int rep = 0; rep < SDF_PREP_CPT; ++rep)
+        lb2[rep] = (lists_on && !ws.force_rebuild) ? ws.lbits[(size_t)H * SDF_NCOL + SDF_PREP_CPT * tid + rep] : 0u;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float a = wave_reduce_min(mn[k]), c = wave_reduce_max(mx[k]);
@@ -311,6 +376,46 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         if (lane == 0) { rowany[2 * wave + 16 * rep] = (unsigned)any; rowany[2 * wave + 16 * rep + 1] = (unsigned)(any >> 32); }
     }
     SDF_LDS_BARRIER();
+    // ---- temporal candidate lists (fused refinement loop): how far has this hand moved, in its own normalised frame, since its
+    //      lists were built?  Within the slack they stay exact (sdf_dist_kernel); beyond it, or when the caller says so (first
+    //      iteration of a stage: the parameters may have jumped), the hand starts over: reference frame := now, map cleared.
+    if (lists_on) {
+        float* ref = ws.vn_ref + (size_t)H * NV3;
+        float dmax = 0.f;
+        if (!ws.force_rebuild) {
+#pragma unroll
+            for (int rep = 0; rep < SDF_PREP_VPT; ++rep) {
+                const int v = tid + rep * SDF_PREP_THREADS;
+                if (v < NV) {
+                    const float dx = vn[3 * v] - rf[rep][0], dy = vn[3 * v + 1] - rf[rep][1], dz = vn[3 * v + 2] - rf[rep][2];
+                    dmax = fmaxf(dmax, sqrtf(dx * dx + dy * dy + dz * dz));
+                }
+            }
+            dmax = wave_reduce_max(dmax);
+            if (lane == 0) red[0][wave] = dmax;       // `red` is free again (the box is in `box`)
+        }
+        SDF_LDS_BARRIER();
+        bool reuse = !ws.force_rebuild;
+        if (reuse) {
+            float m = red[0][0];
+            for (int w = 1; w < SDF_PREP_THREADS / WAVE; ++w) m = fmaxf(m, red[0][w]);
+            reuse = m <= SDF_LIST_SLACK - 1e-4f;        // (a NaN compares false: rebuild)
+        }
+        if (!reuse) {
+#pragma unroll
+            for (int rep = 0; rep < SDF_PREP_VPT; ++rep) {
+                const int v = tid + rep * SDF_PREP_THREADS;
+                if (v < NV) { ref[3 * v] = vn[3 * v]; ref[3 * v + 1] = vn[3 * v + 1]; ref[3 * v + 2] = vn[3 * v + 2]; }
+            }
+#pragma unroll
+            for (int rep = 0; rep < SDF_PREP_CPT; ++rep) ws.lbits[(size_t)H * SDF_NCOL + tid + rep * SDF_PREP_THREADS] = 0u;
+        }
+        if (tid == 0) ws.hmode[H] = reuse ? 1 : 0;
+        if (!reuse) {
+#pragma unroll
+            for (int rep = 0; rep < SDF_PREP_CPT; ++rep) lb2[rep] = 0u;
+        }
+    }
     // ---- lane = triangle: records for the distance kernel + ray parity of the needed voxels it can hit
     float4* sph = ws.sph + (size_t)H * NFP;
     float* rad = ws.rad + (size_t)H * NFP;
@@ -343,8 +448,9 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
         // padding triangles (f >= NF): parked at 1e18 with radius 0, so the distance kernel culls them by arithmetic alone
         {
             const float qx = f < NF ? gx : 1e18f, qy = f < NF ? gy : 1e18f, qz = f < NF ? gz : 1e18f;
-            sph[f] = make_float4(-2.0f * qx, -2.0f * qy, -2.0f * qz, qx * qx + qy * qy + qz * qz);
-            rad[f] = f < NF ? sqrtf(r2) * 1.0001f + 1e-6f : 0.0f;
+            const float r = f < NF ? sqrtf(r2) * 1.0001f + 1e-6f : 0.0f;
+            sph[f] = make_float4(qx, qy, qz, r);
+            rad[f] = r;
         }
         if (!ok) continue;                                   // degenerate in yz: the +x ray never counts it
         const float inv = 1.0f / det;
@@ -396,26 +502,38 @@ __global__ __launch_bounds__(SDF_PREP_THREADS) void sdf_prep_kernel(VertLayout v
             rem &= rem - 1;
             phi[col * SDF_G + i] = 0.0f;
         }
-        cur[col] = __popc(inside2[rep]);
+        // inside voxels with a candidate list (low half) / without (high half): one scan for both
+        cur[col] = __popc(inside2[rep] & lb2[rep]) | (__popc(inside2[rep] & ~lb2[rep]) << 16);
     }
-    const int blk_total = block_excl_scan_1024(cur, scratch);
-    const int xcd = 0;   // one batch-wide list: balanced work items matter more here than L2 affinity
-    // the hand's inside voxels occupy a 16-aligned run of the list (tail padded with an invalid marker),
-    // so every work item of the distance kernel belongs to exactly one hand
-    const int blk_padded = (blk_total + SDF_ITEM - 1) & ~(SDF_ITEM - 1);
-    if (tid == 0) { blk_inside = blk_total; blk_base = blk_total > 0 ? atomicAdd(&ws.inside_count[xcd], blk_padded) : 0; }
+    const unsigned blk_both = (unsigned)block_excl_scan_1024(cur, scratch);
+    // Two batch-wide lists, each with an aligned run per hand (tail padded with an invalid marker) so that a work item belongs to
+    // exactly one hand.  inside_list_a: voxels with a valid candidate list, for sdf_list_search; inside_list: the others (every
+    // inside voxel of a single-shot call or of a hand whose lists are being rebuilt), for the full search of sdf_dist_kernel.
+    const int n_a = (int)(blk_both & 0xffffu), n_b = (int)(blk_both >> 16);
+    const int pad_a = (n_a + SDF_LIST_ITEM - 1) & ~(SDF_LIST_ITEM - 1), pad_b = (n_b + SDF_ITEM - 1) & ~(SDF_ITEM - 1);
+    if (tid == 0) {              // (the two reservations from different waves: their round trips overlap)
+        blk_inside = n_a + n_b;
+        blk_base = n_b > 0 ? atomicAdd(&ws.inside_count[0], pad_b) : 0;
+        if (lists_on) ws.run_start[H] = blk_base;
+    }
+    if (tid == WAVE) blk_base_a = n_a > 0 ? atomicAdd(&ws.inside_count[1], pad_a) : 0;
     SDF_LDS_BARRIER();
-    if (tid < blk_padded - blk_total) ws.inside_list[(size_t)xcd * ws.xcd_cap + blk_base + blk_total + tid] = 0xffffffffu;
+    unsigned* const run_b = ws.inside_list + blk_base;
+    unsigned* const run_a = ws.inside_list_a + blk_base_a;     // (never touched when n_a == 0: null for single-shot callers)
+    if (tid < pad_b - n_b) run_b[n_b + tid] = 0xffffffffu;
+    if (tid < pad_a - n_a) run_a[n_a + tid] = 0xffffffffu;
 #pragma unroll
     for (int rep = 0; rep < SDF_PREP_CPT; ++rep) {
         const int col = SDF_PREP_CPT * tid + rep;
-        unsigned* glist = ws.inside_list + (size_t)xcd * ws.xcd_cap + blk_base + cur[col];
+        const unsigned both = (unsigned)cur[col];
+        int oa = (int)(both & 0xffffu), ob = (int)(both >> 16);
         unsigned rem = inside2[rep];
-        int o = 0;
         while (rem) {
             const int i = __ffs((int)rem) - 1;
             rem &= rem - 1;
-            glist[o++] = ((unsigned)H << 16) | (unsigned)(col * SDF_G + i);
+            const unsigned ent = ((unsigned)H << 16) | (unsigned)(col * SDF_G + i);
+            if ((lb2[rep] >> i) & 1u) run_a[oa++] = ent;
+            else run_b[ob++] = ent;
         }
     }
     if (collect_stats) {
@@ -487,19 +605,20 @@ __device__ __forceinline__ float sdf_point_tri_dist2(const float* a, const float
 // sphere passes (lanes across triangles, packed fp32 on the voxel pair): upper bound = nearest centroid, cull,
 // scan-compacted survivors, exact closest-point distance on dense lanes, DPP min.
 typedef float sdf_v2f __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace ws, int collect_stats) {
-    __shared__ float4 sph_s[NFP];
-    __shared__ float rad_s[NFP];
-    __shared__ unsigned pairs_s[SDF_THREADS / WAVE][SDF_SURV_CAP];   // (voxel slot << 16) | triangle: survivors of the wave's 4 voxels
-    __shared__ unsigned best_s[SDF_THREADS / WAVE][4];               // running min of the squared distance (float bits, >= 0: uint order)
+#define SDF_FULL_LDS (NFP * 20 + (SDF_THREADS / WAVE) * (SDF_SURV_CAP * 4 + 4 * 8))
+__device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int collect_stats, int slot, int nslot, char* smem) {
+    float4* const sph_s = reinterpret_cast<float4*>(smem);                                              // [NFP]
+    float* const rad_s = reinterpret_cast<float*>(smem + NFP * 16);                                     // [NFP]
+    unsigned (*const pairs_s)[SDF_SURV_CAP] = reinterpret_cast<unsigned (*)[SDF_SURV_CAP]>(smem + NFP * 20);   // (voxel slot << 16) | triangle: survivors of the wave's 4 voxels
+    unsigned long long (*const best_s)[4] =                // running min of (squared distance bits << 32) | triangle (bits of a float >= 0: uint order)
+        reinterpret_cast<unsigned long long (*)[4]>(smem + NFP * 20 + (SDF_THREADS / WAVE) * SDF_SURV_CAP * 4);
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
-    const int slot = blockIdx.x, nslot = gridDim.x;
     const int total = ws.inside_count[0];
     const unsigned* glist = ws.inside_list;
     unsigned* mypairs = pairs_s[wave];
-    unsigned* mybest = best_s[wave];
+    unsigned long long* mybest = best_s[wave];
     int curH = -1;
-    unsigned long long st_dist = 0;
+    unsigned long long st_dist = 0, st_full = 0, st_build = 0, st_new = 0;
     // a workgroup takes SDF_ITEM_RUN consecutive items at a time: consecutive items mostly belong to one hand, whose table is then
     // staged once for the run
     // (only when there are more items than workgroups: a single 64-sample batch has ~900 items for 2048 workgroups, one each)
@@ -508,11 +627,14 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
     for (int item = item0; item < item0 + run && item * SDF_ITEM < total; ++item) {
         const unsigned ent_l = lane < SDF_ITEM ? glist[item * SDF_ITEM + lane] : 0xffffffffu;
         const int H = (int)((unsigned)__builtin_amdgcn_readlane((int)ent_l, 0) >> 16);   // entry 0 of an item is always valid
+        // 0: the hand's candidate lists are being (re)built -- by this search; 1: they are valid and these voxels have none; -1: no
+        // candidate lists (single-shot callers)
+        const int mode = ws.list_mode ? ws.hmode[H] : -1;
+        const int run_start = ws.list_mode ? ws.run_start[H] : 0;
         if (H != curH) {             // uniform over the workgroup (same item for all waves)
-            __syncthreads();
-            const float4* sph = ws.sph + (size_t)H * NFP;
-            const float* rad = ws.rad + (size_t)H * NFP;
-            for (int f = tid; f < NFP; f += SDF_THREADS) { sph_s[f] = sph[f]; rad_s[f] = rad[f]; }
+            SDF_LDS_BARRIER();       // (the previous table's readers are done; LDS traffic only)
+            sdf_stage_async(ws.sph + (size_t)H * NFP, reinterpret_cast<char*>(sph_s), NFP);
+            sdf_stage_async(ws.rad + (size_t)H * NFP, reinterpret_cast<char*>(rad_s), NFP / 4);
             __syncthreads();
             curH = H;
         }
@@ -521,7 +643,7 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
         // voxel fill 59 % of a 64-lane round, the ~150 of four voxels fill three rounds of four.  Minimum per voxel through LDS
         // atomics on the float bits (squared distances are >= +0, so unsigned order = float order; a NaN sorts above +inf
         // and is ignored, as fminf does).
-        if (lane < 4) mybest[lane] = 0x7f800000u;
+        if (lane < 4) mybest[lane] = 0x7f800000ull << 32;
         unsigned ent4[4];             // this wave's four list entries (uniform)
 #pragma unroll
         for (int q = 0; q < 4; ++q) ent4[q] = (unsigned)__builtin_amdgcn_readlane((int)ent_l, wave * (SDF_ITEM / 4) + q);
@@ -530,18 +652,27 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // software pipeline: the next round's triangle is requested before this round's distance is computed
+            unsigned pr_n = lane < npair ? mypairs[lane] : 0u;
+            float4 A_n = abc[3 * (int)(pr_n & 0xffffu)], B_n = abc[3 * (int)(pr_n & 0xffffu) + 1], C_n = abc[3 * (int)(pr_n & 0xffffu) + 2];
             for (int base = 0; base < npair; base += WAVE) {
-                const int idx = base + lane;
-                if (idx < npair) {
-                    const unsigned pr = mypairs[idx];
-                    const int f = (int)(pr & 0xffffu), vs = (int)(pr >> 16);
+                const unsigned pr = pr_n;
+                const float4 A = A_n, Bv = B_n, Cv = C_n;
+                const bool live = base + lane < npair;
+                const int nidx = base + WAVE + lane;
+                if (base + WAVE < npair) {
+                    pr_n = nidx < npair ? mypairs[nidx] : 0u;
+                    const int fn = (int)(pr_n & 0xffffu);
+                    A_n = abc[3 * fn], B_n = abc[3 * fn + 1], C_n = abc[3 * fn + 2];
+                }
+                if (live) {
+                    const int vs = (int)(pr >> 16);
                     const int id = (int)((vs == 0 ? ent4[0] : (vs == 1 ? ent4[1] : (vs == 2 ? ent4[2] : ent4[3]))) & 0xffffu);
                     const float qx = (float)(2 * (id & 31) + 1) / (float)SDF_G - 1.0f;
                     const float qy = (float)(2 * ((id >> 5) & 31) + 1) / (float)SDF_G - 1.0f;
                     const float qz = (float)(2 * (id >> 10) + 1) / (float)SDF_G - 1.0f;
-                    const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
                     const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
-                    atomicMin(&mybest[vs], __float_as_uint(sdf_point_tri_dist2(a, b, c, qx, qy, qz)));
+                    atomicMin(&mybest[vs], ((unsigned long long)__float_as_uint(sdf_point_tri_dist2(a, b, c, qx, qy, qz)) << 32) | (pr & 0xffffu));
                 }
             }
             st_dist += (unsigned long long)(lane == 0 ? npair : 0);
@@ -551,49 +682,57 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
         int nmine = 0;    // voxels of this wave
-        // two voxels at a time through the sphere passes: the table is read once for both and the arithmetic
-        // is on float pairs (packed fp32 instructions issue two lanes' worth per cycle)
-        for (int e = wave * (SDF_ITEM / 4); e < (wave + 1) * (SDF_ITEM / 4); e += 2) {
-            const unsigned ent0 = (unsigned)__builtin_amdgcn_readlane((int)ent_l, e);
-            const unsigned ent1r = (unsigned)__builtin_amdgcn_readlane((int)ent_l, e + 1);
-            if (ent0 == 0xffffffffu) break;     // padding (only at the tail of a hand's run)
+        // ---- the full search for a pair of voxels (packed fp32): table read once for both
+        auto pair_pass = [&](unsigned ent0, unsigned ent1r, int vs0, int lidx0) {
             const int nvox = ent1r != 0xffffffffu ? 2 : 1;
             const int id0 = (int)(ent0 & 0xffffu), id1 = (int)((nvox == 2 ? ent1r : ent0) & 0xffffu);
             const sdf_v2f PX = {(float)(2 * (id0 & 31) + 1) / (float)SDF_G - 1.0f, (float)(2 * (id1 & 31) + 1) / (float)SDF_G - 1.0f};
             const sdf_v2f PY = {(float)(2 * ((id0 >> 5) & 31) + 1) / (float)SDF_G - 1.0f,
                                 (float)(2 * ((id1 >> 5) & 31) + 1) / (float)SDF_G - 1.0f};
             const sdf_v2f PZ = {(float)(2 * (id0 >> 10) + 1) / (float)SDF_G - 1.0f, (float)(2 * (id1 >> 10) + 1) / (float)SDF_G - 1.0f};
-            // d2[t] = |p - c|^2 - |p|^2 = dot((p,1), sph): three packed FMAs per triangle and voxel pair.  The
-            // cancellation costs at most ~1e-6 absolute (|p|, |c| <= 2), covered by the margin below: the bound and the
-            // cull stay conservative, the minimum over the survivors is computed exactly afterwards
-            const sdf_v2f P2 = PX * PX + PY * PY + PZ * PZ;
+            // d2[t] = |p - c|^2 (packed fp32 on the voxel pair); used for conservative culling only, the minimum over the survivors
+            // is computed exactly afterwards
             sdf_v2f d2[NFP / WAVE];
             sdf_v2f ub2 = {INFINITY, INFINITY};
 #pragma unroll
             for (int t = 0; t < NFP / WAVE; ++t) {
                 const float4 sp = sph_s[lane + WAVE * t];
-                const sdf_v2f sx = {sp.x, sp.x}, sy = {sp.y, sp.y}, sz = {sp.z, sp.z}, sw = {sp.w, sp.w};
-                d2[t] = __builtin_elementwise_fma(PX, sx, __builtin_elementwise_fma(PY, sy, __builtin_elementwise_fma(PZ, sz, sw)));
+                const sdf_v2f dx = PX - sdf_v2f{sp.x, sp.x}, dy = PY - sdf_v2f{sp.y, sp.y}, dz = PZ - sdf_v2f{sp.z, sp.z};
+                d2[t] = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
                 ub2 = __builtin_elementwise_min(ub2, d2[t]);
             }
-            // the centroid is a point of the triangle: dist <= |p - centroid|   (+ 4e-6 for the cancellation)
-            const float ub_a = sqrtf(fmaxf(wave_reduce_min(ub2.x) + P2.x, 0.0f) + 4e-6f) * 1.0001f + 1e-6f;
-            const float ub_b = sqrtf(fmaxf(wave_reduce_min(ub2.y) + P2.y, 0.0f) + 4e-6f) * 1.0001f + 1e-6f;
+            // the centroid is a point of the triangle: dist <= |p - centroid|
+            const float ub_a = sqrtf(wave_reduce_min(ub2.x)) * 1.0001f + 1e-6f;
+            const float ub_b = sqrtf(wave_reduce_min(ub2.y)) * 1.0001f + 1e-6f;
             const sdf_v2f ub_lim = {ub_a, ub_b};
-            const sdf_v2f shift = sdf_v2f{4e-6f, 4e-6f} - P2;    // compare in the shifted frame: d2 + |p|^2 - 4e-6 > lim^2
-            unsigned keep_a = 0, keep_b = 0;
+            unsigned keep_a = 0, keep_b = 0, list_a = 0, list_b = 0;
+            if (mode == 0) {   // lists are being built: the same cull with the bound widened by twice the motion slack
 #pragma unroll
-            for (int t = 0; t < NFP / WAVE; ++t) {
-                const float r = rad_s[lane + WAVE * t];
-                const sdf_v2f lim = ub_lim + r;
-                const sdf_v2f lim2 = __builtin_elementwise_fma(lim * lim, sdf_v2f{1.00001f, 1.00001f}, shift);
-                // cull iff |p - centroid| - radius > upper bound (exact: such a triangle cannot be the minimum)
-                keep_a |= !(d2[t].x > lim2.x) ? (1u << t) : 0u;
-                keep_b |= !(d2[t].y > lim2.y) ? (1u << t) : 0u;
+                for (int t = 0; t < NFP / WAVE; ++t) {
+                    const float r = rad_s[lane + WAVE * t];
+                    const sdf_v2f lim = ub_lim + r;
+                    const sdf_v2f lim2 = lim * lim * sdf_v2f{1.00001f, 1.00001f};
+                    const sdf_v2f limw = lim + sdf_v2f{2.0f * SDF_LIST_SLACK, 2.0f * SDF_LIST_SLACK};
+                    const sdf_v2f limw2 = limw * limw * sdf_v2f{1.00001f, 1.00001f};
+                    keep_a |= !(d2[t].x > lim2.x) ? (1u << t) : 0u;
+                    keep_b |= !(d2[t].y > lim2.y) ? (1u << t) : 0u;
+                    list_a |= !(d2[t].x > limw2.x) ? (1u << t) : 0u;
+                    list_b |= !(d2[t].y > limw2.y) ? (1u << t) : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NFP / WAVE; ++t) {
+                    const float r = rad_s[lane + WAVE * t];
+                    const sdf_v2f lim = ub_lim + r;
+                    const sdf_v2f lim2 = lim * lim * sdf_v2f{1.00001f, 1.00001f};
+                    // cull iff |p - centroid| - radius > upper bound (exact: such a triangle cannot be the minimum)
+                    keep_a |= !(d2[t].x > lim2.x) ? (1u << t) : 0u;
+                    keep_b |= !(d2[t].y > lim2.y) ? (1u << t) : 0u;
+                }
             }
             for (int v = 0; v < nvox; ++v) {
                 unsigned keepmask = v ? keep_b : keep_a;
-                const int vs = e - wave * (SDF_ITEM / 4) + v;
+                const int vs = vs0 + v;
                 int cnt;
                 const int mine = __popc(keepmask);
                 int off = wave_incl_scan(mine, cnt) - mine;
@@ -608,26 +747,69 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
                     npair += cnt;
                 } else {   // (degenerate geometry) more survivors than list slots: every lane walks its own triangles
                     const float px = v ? PX.y : PX.x, py = v ? PY.y : PY.x, pz = v ? PZ.y : PZ.x;
-                    float best = INFINITY;
                     while (keepmask) {
                         const int t = __ffs((int)keepmask) - 1;
                         keepmask &= keepmask - 1;
                         const int f = lane + WAVE * t;
                         const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
                         const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
-                        best = fminf(best, sdf_point_tri_dist2(a, b, c, px, py, pz));
+                        atomicMin(&mybest[vs], ((unsigned long long)__float_as_uint(sdf_point_tri_dist2(a, b, c, px, py, pz)) << 32) | (unsigned)f);
                         st_dist += 1;
                     }
-                    best = wave_reduce_min(best);
-                    if (lane == 0) atomicMin(&mybest[vs], __float_as_uint(best));
+                }
+                if (mode == 0) {
+                    // the voxel's candidate list: every triangle whose bounding sphere comes within the (widened) bound; its slot =
+                    // the voxel's position in the hand's run (known without atomics).  Too long a list, or too many voxels: none.
+                    unsigned lm = v ? list_b : list_a;
+                    int lcnt;
+                    const int lmine = __popc(lm);
+                    int loff = wave_incl_scan(lmine, lcnt) - lmine;
+                    const int lidx = lidx0 + v;
+                    if (lcnt <= SDF_LCAP_L && lidx < SDF_LCAP_V) {
+                        unsigned short* dst = ws.lists + ((size_t)H * SDF_LCAP_V + lidx) * SDF_LCAP_L;
+                        constexpr int LQ = SDF_LCAP_L / SDF_LIST_K;     // element i at (i % K) * LQ + i / K: each of the K reader lanes gets a contiguous piece
+                        while (lm) {
+                            const int t = __ffs((int)lm) - 1;
+                            lm &= lm - 1;
+                            dst[(loff % SDF_LIST_K) * LQ + loff / SDF_LIST_K] = (unsigned short)(lane + WAVE * t);
+                            ++loff;
+                        }
+                        // the rest of the list is parked padding: a reader needs no length
+                        for (int pos = lcnt + lane; pos < SDF_LCAP_L; pos += WAVE) dst[(pos % SDF_LIST_K) * LQ + pos / SDF_LIST_K] = (unsigned short)(NFP - 1);
+                        if (lane == 0) {       // (the voxel's lmap word is written with the result, at the end of the item)
+                            const int vid = v ? id1 : id0;
+                            atomicOr(&ws.lbits[(size_t)H * SDF_NCOL + (vid >> 5)], 1u << (vid & 31));
+                        }
+                    }
                 }
                 ++nmine;
             }
+        };
+        // the wave's (up to four) voxels as two jobs of the search (ONE call site: the routine is large)
+        const int e0 = wave * (SDF_ITEM / 4);
+        unsigned j_ent0[2], j_ent1[2];
+        int nj = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            j_ent0[k] = (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + 2 * k);
+            j_ent1[k] = (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + 2 * k + 1);
+            if (j_ent0[k] != 0xffffffffu) nj = k + 1;     // padding sits only at the tail of a hand's run
         }
+        const int lidx_base = mode == 0 ? item * SDF_ITEM - run_start + e0 : 0;
+#pragma unroll 1
+        for (int k = 0; k < nj; ++k)
+            pair_pass(k == 0 ? j_ent0[0] : j_ent0[1], k == 0 ? j_ent1[0] : j_ent1[1], 2 * k, lidx_base + 2 * k);
         flush();
+        st_full += (unsigned long long)(lane == 0 ? nmine : 0);
+        st_build += (unsigned long long)(lane == 0 && mode == 0 ? nmine : 0);
+        st_new += (unsigned long long)(lane == 0 && mode == 1 ? nmine : 0);
         if (lane < nmine) {
             const unsigned ent = lane == 0 ? ent4[0] : (lane == 1 ? ent4[1] : (lane == 2 ? ent4[2] : ent4[3]));
-            ws.phi[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = sqrtf(__uint_as_float(mybest[lane]));
+            const unsigned long long bst = mybest[lane];
+            ws.phi[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = sqrtf(__uint_as_float((unsigned)(bst >> 32)));
+            // list of the voxel (if it got one: lbits) and the nearest triangle, which starts its next evaluation (sdf_list_search)
+            if (mode == 0 && lidx_base + lane < SDF_LCAP_V)
+                ws.lmap[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = (unsigned)(lidx_base + lane) | ((unsigned)(bst & 0xffffu) << 16);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -635,8 +817,189 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
         unsigned long long d = st_dist;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-        if (lane == 0) atomicAdd(&ws.stats[1], d);  // exact point-triangle distances
+        if (lane == 0) {
+            atomicAdd(&ws.stats[1], d);                                  // exact point-triangle distances
+            atomicAdd(&ws.stats[4], st_full * (unsigned long long)NF);   // bounding-sphere tests
+            atomicAdd(&ws.stats[6], st_new);                             // voxels of hands with valid lists that have none
+            atomicAdd(&ws.stats[7], st_build);                           // voxels whose lists were (re)built
+        }
     }
+}
+
+// ------------------------------------------------------------------------------------- distance from candidate lists
+// The inside voxels that HAVE a valid candidate list (inside_list_a; item = SDF_LIST_ITEM consecutive entries of one hand).
+// grid-strided over the items, block = 256 (4 waves), 4 workgroups per CU (<= 128 VGPRs, 34 KB LDS): the workgroup stages the
+// hand's CURRENT bounding spheres (LDS, once per run of two items), a wave takes WAVE / K voxels, K lanes per voxel, each lane
+// walking its contiguous piece of the voxel's list (<= 192 triangle ids written when the lists were built: 16 bytes = 8 ids per
+// load, all requested up front).  Upper bound of a voxel = the exact distance to the triangle that was nearest the last time (any
+// triangle gives a valid bound, this one is nearly always the answer): no reduction pass, and only the triangles whose spheres
+// reach inside that bound survive; the survivors of the wave's voxels are queued as dense (voxel, triangle) pairs and evaluated
+// exactly, 64 per round.  Same minimum as the full search, bit for bit: the list holds every triangle that can be nearest while
+// the hand stays within SDF_LIST_SLACK of its reference pose (see pair_pass), and a culled triangle lies farther than a distance
+// some triangle attains.
+#define SDF_LIST_QCAP 512
+#define SDF_LIST_VPW (WAVE / SDF_LIST_K)          // voxels per wave
+#define SDF_LIST_PIECE (SDF_LCAP_L / SDF_LIST_K / 8)   // 16-byte loads per lane
+#define SDF_LIST_LDS (NFP * 16 + (SDF_THREADS / WAVE) * (SDF_LIST_QCAP * 4 + SDF_LIST_VPW * 8 + SDF_LIST_VPW * 2))
+__device__ __forceinline__ void sdf_list_search(const SdfWorkspace& ws, int collect_stats, int slot, int nslot, char* smem) {
+    float4* const tab_s = reinterpret_cast<float4*>(smem);                                              // [NFP] (centroid, radius)
+    unsigned (*const q_s)[SDF_LIST_QCAP] = reinterpret_cast<unsigned (*)[SDF_LIST_QCAP]>(smem + NFP * 16);    // (voxel of the wave << 16) | triangle
+    unsigned long long (*const best_s)[SDF_LIST_VPW] =     // (squared distance bits << 32) | triangle
+        reinterpret_cast<unsigned long long (*)[SDF_LIST_VPW]>(smem + NFP * 16 + (SDF_THREADS / WAVE) * SDF_LIST_QCAP * 4);
+    unsigned short (*const vox_s)[SDF_LIST_VPW] =
+        reinterpret_cast<unsigned short (*)[SDF_LIST_VPW]>(smem + NFP * 16 + (SDF_THREADS / WAVE) * (SDF_LIST_QCAP * 4 + SDF_LIST_VPW * 8));
+    const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
+    const int grp = lane / SDF_LIST_K, sub = lane % SDF_LIST_K;
+    const int total = ws.inside_count[1];
+    const unsigned* glist = ws.inside_list_a;
+    unsigned* q = q_s[wave];
+    unsigned long long* best = best_s[wave];
+    unsigned short* vox_w = vox_s[wave];
+    unsigned long long st_dist = 0, st_sph = 0, st_vox = 0;
+    int curH = -1;
+    const int run = (total + SDF_LIST_ITEM - 1) / SDF_LIST_ITEM > nslot ? 2 : 1;
+    for (int item0 = slot * run; item0 * SDF_LIST_ITEM < total; item0 += nslot * run)
+    for (int item = item0; item < item0 + run && item * SDF_LIST_ITEM < total; ++item) {
+        // the hand (entry 0 of an item is always valid); a new hand's table is requested first (global -> LDS, asynchronous) ...
+        const int H = __builtin_amdgcn_readfirstlane((int)(glist[item * SDF_LIST_ITEM] >> 16));
+        const bool stage = H != curH;          // uniform over the workgroup
+        if (stage) {
+            SDF_LDS_BARRIER();          // (the previous table's readers are done; LDS traffic only)
+            sdf_stage_async(ws.sph + (size_t)H * NFP, reinterpret_cast<char*>(tab_s), NFP);
+        }
+        // ... then this lane's voxel (the same for the K lanes of a group) and everything it needs from memory: all of it in flight
+        // while the table goes to LDS
+        const unsigned ent = glist[item * SDF_LIST_ITEM + wave * SDF_LIST_VPW + grp];
+        const bool has = ent != 0xffffffffu;
+        const unsigned vox = has ? (ent & 0xffffu) : 0u;
+        unsigned* const lword = ws.lmap + (size_t)H * SDF_NVOX + vox;
+        const unsigned lw = has ? *lword : 0u;
+        const int nr = (int)(lw >> 16);
+        const float4* abc = ws.abc + (size_t)H * NFP * 3;
+        const uint4* piece = reinterpret_cast<const uint4*>(ws.lists + ((size_t)H * SDF_LCAP_V + (lw & 0xffffu)) * SDF_LCAP_L) + sub * SDF_LIST_PIECE;
+        uint4 ids4[SDF_LIST_PIECE];
+        constexpr unsigned PK = (unsigned)(NFP - 1) | ((unsigned)(NFP - 1) << 16);     // parked padding
+#pragma unroll
+        for (int c = 0; c < SDF_LIST_PIECE; ++c) ids4[c] = has ? piece[c] : make_uint4(PK, PK, PK, PK);
+        const float4 A0 = abc[3 * nr], B0 = abc[3 * nr + 1], C0 = abc[3 * nr + 2];
+        if (stage) {
+            __syncthreads();            // the table has landed (waits for this wave's other loads too: they were all in flight)
+            curH = H;
+        }
+        const float px = (float)(2 * (int)(vox & 31u) + 1) / (float)SDF_G - 1.0f, py = (float)(2 * (int)((vox >> 5) & 31u) + 1) / (float)SDF_G - 1.0f,
+                    pz = (float)(2 * (int)(vox >> 10) + 1) / (float)SDF_G - 1.0f;
+        float ub;
+        {
+            const float a[3] = {A0.x, A0.y, A0.z}, b[3] = {B0.x, B0.y, B0.z}, c[3] = {C0.x, C0.y, C0.z};
+            const float ub2 = sdf_point_tri_dist2(a, b, c, px, py, pz);
+            if (sub == 0) {
+                vox_w[grp] = (unsigned short)vox;
+                best[grp] = ((unsigned long long)__float_as_uint(ub2) << 32) | (unsigned)nr;
+            }
+            ub = sqrtf(ub2) * 1.0001f + 1e-6f;
+        }
+        int npair = 0;
+        auto flush = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // software pipeline: the next round's triangle is requested before this round's distance is computed
+            unsigned pr_n = lane < npair ? q[lane] : 0u;
+            float4 A_n = abc[3 * (int)(pr_n & 0xffffu)], B_n = abc[3 * (int)(pr_n & 0xffffu) + 1], C_n = abc[3 * (int)(pr_n & 0xffffu) + 2];
+            for (int base = 0; base < npair; base += WAVE) {
+                const unsigned pr = pr_n;
+                const float4 A = A_n, Bv = B_n, Cv = C_n;
+                const bool live = base + lane < npair;
+                if (base + WAVE < npair) {
+                    const int nidx = base + WAVE + lane;
+                    pr_n = nidx < npair ? q[nidx] : 0u;
+                    const int fn = (int)(pr_n & 0xffffu);
+                    A_n = abc[3 * fn], B_n = abc[3 * fn + 1], C_n = abc[3 * fn + 2];
+                }
+                if (live) {
+                    const int g = (int)(pr >> 16);
+                    const int id = (int)vox_w[g];
+                    const float qx = (float)(2 * (id & 31) + 1) / (float)SDF_G - 1.0f;
+                    const float qy = (float)(2 * ((id >> 5) & 31) + 1) / (float)SDF_G - 1.0f;
+                    const float qz = (float)(2 * (id >> 10) + 1) / (float)SDF_G - 1.0f;
+                    const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
+                    atomicMin(&best[g], ((unsigned long long)__float_as_uint(sdf_point_tri_dist2(a, b, c, qx, qy, qz)) << 32) | (pr & 0xffffu));
+                }
+            }
+            st_dist += (unsigned long long)(lane == 0 ? npair : 0);
+            npair = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+#pragma unroll
+        for (int c = 0; c < SDF_LIST_PIECE; ++c) {
+            const uint4 cur = ids4[c];
+            // a piece is compact (parked padding only at its tail): done when no lane has a candidate left
+            const unsigned long long more = __ballot((cur.x & 0xffffu) != (unsigned)(NFP - 1));
+            if (!more) break;
+            st_sph += (unsigned long long)(lane == 0 ? 8 * __popcll(more) : 0);
+            const unsigned ids[8] = {cur.x & 0xffffu, cur.x >> 16, cur.y & 0xffffu, cur.y >> 16, cur.z & 0xffffu, cur.z >> 16, cur.w & 0xffffu, cur.w >> 16};
+            float4 sp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sp[k] = tab_s[ids[k]];         // eight gathers in flight
+            unsigned km = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float dx = px - sp[k].x, dy = py - sp[k].y, dz = pz - sp[k].z;
+                const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+                const float lim = ub + sp[k].w;
+                // cull iff |p - centroid| - radius > upper bound (exact: such a triangle cannot be the minimum); parked padding: never kept
+                km |= ((int)ids[k] != nr && !(d2 > lim * lim * 1.00001f)) ? (1u << k) : 0u;
+            }
+            // survivors -> the wave's queue: one scan over the per-lane counts
+            int cnt;
+            const int mine = __popc(km);
+            int off = wave_incl_scan(mine, cnt) - mine;
+            if (cnt) {
+                if (npair + cnt > SDF_LIST_QCAP) flush();
+                off += npair;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((km >> k) & 1u) q[off++] = ((unsigned)grp << 16) | ids[k];
+                npair += cnt;
+            }
+        }
+        flush();
+        if (has && sub == 0) {
+            const unsigned long long bst = best[grp];
+            ws.phi[(size_t)H * SDF_NVOX + vox] = sqrtf(__uint_as_float((unsigned)(bst >> 32)));
+            reinterpret_cast<unsigned short*>(lword)[1] = (unsigned short)(bst & 0xffffu);
+        }
+        {
+            const unsigned long long mh = __ballot(has && sub == 0);
+            st_vox += (unsigned long long)(lane == 0 ? __popcll(mh) : 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (collect_stats && lane == 0) {
+        atomicAdd(&ws.stats[1], st_dist + st_vox);   // exact point-triangle distances (one per voxel for the bound)
+        atomicAdd(&ws.stats[4], st_sph);             // bounding-sphere tests
+        atomicAdd(&ws.stats[5], st_vox);             // voxels answered from their lists
+    }
+}
+
+// ------------------------------------------------------------------------------------- distance: the launch
+// grid = SDF_DIST_BLOCKS.. (a multiple of 16), block = 256, 4 workgroups per CU.  Single-shot callers: every workgroup runs the full
+// search.  Fused loop: the two searches read disjoint lists and write disjoint voxels, so they share the launch -- alternate groups
+// of eight workgroups (one per XCD) take the full search and the list search, each grid-strided over its own items; both are bound
+// by memory / LDS round trips more than by issue slots, and fill each other's gaps on a CU.
+#define SDF_DIST_LDS (SDF_FULL_LDS > SDF_LIST_LDS ? SDF_FULL_LDS : SDF_LIST_LDS)
+__global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace ws, int collect_stats) {
+    __shared__ __attribute__((aligned(16))) char smem[SDF_DIST_LDS];
+    if (!ws.list_mode) {
+        sdf_full_search(ws, collect_stats, (int)blockIdx.x, (int)gridDim.x, smem);
+        return;
+    }
+    const int idx = (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7u)), half = (int)(gridDim.x >> 1);
+    if (((blockIdx.x >> 3) & 1u) == 0u) sdf_full_search(ws, collect_stats, idx, half, smem);
+    else sdf_list_search(ws, collect_stats, idx, half, smem);
 }
 
 // ------------------------------------------------------------------------------------- sample

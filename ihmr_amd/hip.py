@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "ihmr_mano_create", "ihmr_mano_destroy", "ihmr_mano_update_shapedirs", "ihmr_mano_workspace_bytes", "ihmr_mano_lbs_fwd",
     "ihmr_mano_lbs_bwd",
     "ihmr_sdf_workspace_bytes", "ihmr_sdf_collision", "ihmr_sdf_collision_ex", "ihmr_sdf_dense_grid", "ihmr_opt_workspace_bytes",
-    "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_opt_sdf_stats", "ihmr_opt_stage_graph_create",
+    "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_opt_sdf_stats", "ihmr_opt_sdf_counters", "ihmr_opt_stage_graph_create",
     "ihmr_opt_forward_graph_create", "ihmr_graph_launch", "ihmr_graph_destroy", "ihmr_opt_set_params", "ihmr_eval_metrics", "ihmr_eval_mpvpe", "ihmr_conv_igemm", "ihmr_maxpool3x3s2",
     "ihmr_avgpool_relu", "ihmr_preprocess_images", "ihmr_mlp_train_grad", "ihmr_transpose", "ihmr_relu_backward", "ihmr_colsum",
     "ihmr_adam_step", "ihmr_bn_workspace_bytes", "ihmr_bn_train_forward", "ihmr_bn_train_backward", "ihmr_conv_wgrad",
@@ -53,7 +53,7 @@ class OptIO(C.Structure):
         "hand_type_array",
         "verts", "joints_3d", "joints_2d", "loss_batch", "coll_per_vert", "coll_origin_scale",
         "snap_params", "snap_loss", "selected", "adam_m", "adam_v", "workspace")] + [
-        ("norm_batch", C.c_int), ("sdf_align_corners", C.c_int), ("sdf_loss_divisor", C.c_float)]
+        ("norm_batch", C.c_int), ("sdf_align_corners", C.c_int), ("sdf_loss_divisor", C.c_float), ("sdf_no_candidate_lists", C.c_int)]
 
 
 class SdfOptions(C.Structure):
@@ -205,6 +205,7 @@ def lib():
         L.ihmr_avgpool_relu_backward.argtypes = [vp, vp, vp, i, i, i, i, vp]
         L.ihmr_preprocess_images.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp]
         L.ihmr_opt_sdf_stats.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), vp, vp]
+        L.ihmr_opt_sdf_counters.argtypes = [C.POINTER(OptIO), i, vp, i]
         L.ihmr_set_kernel_timer.argtypes = [C.POINTER(KernelTimer)]
         L.ihmr_flush_kernel_timer.argtypes = []
         L.ihmr_version.restype = C.c_char_p

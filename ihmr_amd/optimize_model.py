@@ -152,7 +152,8 @@ class OptimizeModel:
         # conventions of the collision module (include/ihmr_hip.h: ihmr_sdf_options): opt.sdf_align_corners / opt.sdf_loss_divisor
         self.io = hip.OptIO(**{k: v.data_ptr() for k, v in self.buf.items()}, norm_batch=self.norm_batch,
                             sdf_align_corners=int(bool(getattr(self.opt, "sdf_align_corners", False))),
-                            sdf_loss_divisor=float(getattr(self.opt, "sdf_loss_divisor", 0.0) or 0.0))
+                            sdf_loss_divisor=float(getattr(self.opt, "sdf_loss_divisor", 0.0) or 0.0),
+                            sdf_no_candidate_lists=int(bool(getattr(self.opt, "sdf_no_candidate_lists", False))))
         self.mano_params_weight = z(B, 2)
         self.init = {}
 
@@ -215,6 +216,19 @@ class OptimizeModel:
         hip.check(hip.lib().ihmr_opt_sdf_stats(mr, ml, C.byref(self.io), self.batch_size, C.byref(w), out, hip.stream_ptr()),
                   "ihmr_opt_sdf_stats")
         return dict(ray_tests=int(out[0]), dist_evals=int(out[1]), inside_voxels=int(out[2]), needed_voxels=int(out[3]))
+
+    SDF_COUNTERS = ("ray_tests", "dist_evals", "inside_voxels", "needed_voxels", "sphere_tests", "voxels_from_lists",
+                    "voxels_without_list", "voxels_rebuilt")
+
+    def sdf_counters_start(self):
+        """Zero the collision kernels' work counters and switch them on for everything launched (or captured) from now on."""
+        hip.check(hip.lib().ihmr_opt_sdf_counters(C.byref(self.io), self.batch_size, None, 1), "ihmr_opt_sdf_counters")
+
+    def sdf_counters_stop(self):
+        """Synchronise, switch the counters off and return their totals since :meth:`sdf_counters_start` (diagnostics)."""
+        out = (C.c_ulonglong * 8)()
+        hip.check(hip.lib().ihmr_opt_sdf_counters(C.byref(self.io), self.batch_size, out, 0), "ihmr_opt_sdf_counters")
+        return {k: int(out[i]) for i, k in enumerate(self.SDF_COUNTERS)}
 
     def run_stage(self, stage):
         sg = stage_to_args(stage, self.optimizer, self.save_mid_freq)

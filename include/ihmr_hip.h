@@ -135,6 +135,9 @@ typedef struct ihmr_opt_io {
     /* conventions of the collision module (ihmr_sdf_options above): 0 / 0 = defaults */
     int sdf_align_corners;
     float sdf_loss_divisor;
+    /* 1 = every iteration searches all 1538 triangles per voxel (the per-voxel candidate lists that ihmr_opt_run_stage carries from
+       iteration to iteration are an exact acceleration; this switch exists to test exactly that) */
+    int sdf_no_candidate_lists;
 } ihmr_opt_io;
 
 typedef struct ihmr_opt_weights { /* strategies/opt_default.py loss_weights */
@@ -199,6 +202,12 @@ int ihmr_opt_set_params(const ihmr_opt_io* io, const float* final_params, int B,
  * sdf_prep_kernel + sdf_dist_kernel launch pair -- the algorithmic work bench.py prices the roofline with. */
 int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                        const ihmr_opt_weights* w, unsigned long long* out4, void* stream);
+
+/* diagnostics of the fused loop.  enable = 1: zero the eight SDF work counters and switch them on for every launch issued or
+ * recorded afterwards (a stage graph captured while they are on keeps counting); enable = 0: synchronise, copy them to out8 (host)
+ * and switch them off: {ray tests, exact distances, inside voxels, needed voxels, bounding-sphere tests, voxels answered from
+ * their candidate lists, voxels of such hands handed to the full search, voxels whose lists were rebuilt}. */
+int ihmr_opt_sdf_counters(const ihmr_opt_io* io, int B, unsigned long long* out8, int enable);
 
 /* ------------------------------------------------------------------ image encoder (ResNet-50 + heads) */
 /* One Conv2d / Linear of `InterHandEncoder.forward` (models/networks.py:66-80, models/resnet.py:138-156) as an

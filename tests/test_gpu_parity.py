@@ -731,3 +731,58 @@ def test_sdf_convention_switches_match_oracle(mano_arrays, align_corners, loss_d
     _report("conv fused collision_loss", g["collision_loss"], r["collision_loss"], atol=1e-5, rtol=1e-5)
     _report("conv fused pose", g["pred_pose_params"], r["pred_pose_params"], atol=1e-4)
     _report("conv fused penetration depth [m]", g["collision_loss_origin_scale"], r["collision_loss_origin_scale"], atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------- candidate lists are exact
+@pytest.mark.parametrize("B,epoch", [(16, 29), (64, 9)])
+def test_candidate_lists_do_not_change_a_bit(mano_arrays, B, epoch):
+    """Inside a stage the distance kernel searches, per voxel, only the candidate triangles recorded when the hand's lists were
+    last built (valid while no vertex has moved by more than the slack in the hand's normalised frame; rebuilt otherwise and at
+    every stage start).  A conservative acceleration: with `opt.sdf_no_candidate_lists` every iteration searches all 1538
+    triangles -- both runs must agree bit for bit, on the regular and on the ragged batch, through all four stages (the
+    translation / shape stages reuse the lists for many iterations, the orientation / pose stages rebuild every few)."""
+    from helpers import ragged_opt_batch
+    from ihmr_amd.optimize_model import OptimizeModel
+    _, batch = _two_hand_verts(mano_arrays, B, 900 + B)
+    if B == 16:
+        batch = ragged_opt_batch(batch)
+    outs = []
+    for off in (False, True):
+        opt = _make_opt(B, epoch=epoch, save_mid_freq=5)
+        opt.sdf_no_candidate_lists = off
+        m = OptimizeModel(opt)
+        for rep in range(2):            # the second pass replays the captured graphs over the previous pass's (stale) lists
+            m.set_input(batch); m.init_optimize(); m.optimize()
+            torch.cuda.synchronize()
+        outs.append((m.get_pred_result(), torch.stack(m.selected_history).cpu().numpy()))
+    (a, sa), (b, sb) = outs
+    assert np.array_equal(sa, sb)
+    for k in ("pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "pred_left_hand_verts",
+              "pred_joints_3d", "collision_loss", "collision_loss_origin_scale"):
+        assert np.array_equal(a[k], b[k]), f"{k}: the candidate lists changed the result"
+    assert float(a["collision_loss_origin_scale"].max()) > 0
+
+
+def test_candidate_lists_are_used_and_accounted_for(mano_arrays):
+    """The work counters of the fused loop: inside a stage most inside voxels are answered from their candidate lists, every inside
+    voxel is evaluated exactly once per iteration (list search + full search = inside voxels), the list search tests far fewer
+    spheres than the 1538 of a full search, and with the lists switched off nothing goes through them."""
+    from ihmr_amd.optimize_model import OptimizeModel
+    B = 16
+    _, batch = _two_hand_verts(mano_arrays, B, 77)
+    for off in (False, True):
+        opt = _make_opt(B, epoch=19, save_mid_freq=5)
+        opt.sdf_no_candidate_lists = off
+        m = OptimizeModel(opt)
+        m.set_input(batch); m.init_optimize()
+        m.sdf_counters_start()
+        m.run_stage(m.strategy[0])
+        c = m.sdf_counters_stop()
+        assert c["inside_voxels"] > 0
+        if off:
+            assert c["voxels_from_lists"] == 0 and c["voxels_without_list"] == 0 and c["voxels_rebuilt"] == 0
+            assert c["sphere_tests"] == 1538 * c["inside_voxels"]
+        else:
+            assert c["voxels_from_lists"] + c["voxels_without_list"] + c["voxels_rebuilt"] == c["inside_voxels"]
+            assert c["voxels_from_lists"] > c["inside_voxels"] // 2
+            assert c["sphere_tests"] < 1538 * c["inside_voxels"] // 2
