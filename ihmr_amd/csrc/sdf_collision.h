@@ -622,11 +622,18 @@ __device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int coll
     // a workgroup takes SDF_ITEM_RUN consecutive items at a time: consecutive items mostly belong to one hand, whose table is then
     // staged once for the run
     // (only when there are more items than workgroups: a single 64-sample batch has ~900 items for 2048 workgroups, one each)
-    const int run = (total + SDF_ITEM - 1) / SDF_ITEM > nslot ? SDF_ITEM_RUN : 1;
-    for (int item0 = slot * run; item0 * SDF_ITEM < total; item0 += nslot * run)
-    for (int item = item0; item < item0 + run && item * SDF_ITEM < total; ++item) {
+    // With few items (one batch of 64: ~200 items for 1024 workgroups) two workgroups share an item, a wave takes two voxels = ONE
+    // pass instead of two: the launch is as long as its longest item.
+    const int nitems = (total + SDF_ITEM - 1) / SDF_ITEM;
+    const int run = nitems > nslot ? SDF_ITEM_RUN : 1;
+    const int split = 2 * nitems <= nslot ? 2 : 1;
+    const int vpw = SDF_ITEM / 4 / split;                  // voxels per wave
+    for (int item0 = (slot / split) * run; item0 < nitems; item0 += (nslot / split) * run)
+    for (int item = item0; item < item0 + run && item < nitems; ++item) {
         const unsigned ent_l = lane < SDF_ITEM ? glist[item * SDF_ITEM + lane] : 0xffffffffu;
         const int H = (int)((unsigned)__builtin_amdgcn_readlane((int)ent_l, 0) >> 16);   // entry 0 of an item is always valid
+        const int e0 = (split == 2 ? (slot & 1) * (SDF_ITEM / 2) : 0) + wave * vpw;     // this wave's first entry of the item
+        if (split == 2 && (slot & 1) && (unsigned)__builtin_amdgcn_readlane((int)ent_l, SDF_ITEM / 2) == 0xffffffffu) continue;   // (padding)
         // 0: the hand's candidate lists are being (re)built -- by this search; 1: they are valid and these voxels have none; -1: no
         // candidate lists (single-shot callers)
         const int mode = ws.list_mode ? ws.hmode[H] : -1;
@@ -646,7 +653,7 @@ __device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int coll
         if (lane < 4) mybest[lane] = 0x7f800000ull << 32;
         unsigned ent4[4];             // this wave's four list entries (uniform)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ent4[q] = (unsigned)__builtin_amdgcn_readlane((int)ent_l, wave * (SDF_ITEM / 4) + q);
+        for (int q = 0; q < 4; ++q) ent4[q] = q < vpw ? (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + q) : 0xffffffffu;
         int npair = 0;
         auto flush = [&]() {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -786,13 +793,12 @@ __device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int coll
             }
         };
         // the wave's (up to four) voxels as two jobs of the search (ONE call site: the routine is large)
-        const int e0 = wave * (SDF_ITEM / 4);
         unsigned j_ent0[2], j_ent1[2];
         int nj = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            j_ent0[k] = (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + 2 * k);
-            j_ent1[k] = (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + 2 * k + 1);
+            j_ent0[k] = 2 * k < vpw ? (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + 2 * k) : 0xffffffffu;
+            j_ent1[k] = 2 * k < vpw ? (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + 2 * k + 1) : 0xffffffffu;
             if (j_ent0[k] != 0xffffffffu) nj = k + 1;     // padding sits only at the tail of a hand's run
         }
         const int lidx_base = mode == 0 ? item * SDF_ITEM - run_start + e0 : 0;
@@ -857,9 +863,12 @@ __device__ __forceinline__ void sdf_list_search(const SdfWorkspace& ws, int coll
     unsigned short* vox_w = vox_s[wave];
     unsigned long long st_dist = 0, st_sph = 0, st_vox = 0;
     int curH = -1;
-    const int run = (total + SDF_LIST_ITEM - 1) / SDF_LIST_ITEM > nslot ? 2 : 1;
-    for (int item0 = slot * run; item0 * SDF_LIST_ITEM < total; item0 += nslot * run)
-    for (int item = item0; item < item0 + run && item * SDF_LIST_ITEM < total; ++item) {
+    // (sharing an item between two workgroups when there are few, as the full search does, is SLOWER here: 17.6 instead of 16.7 us
+    // for the launch of one batch of 64 -- half-empty waves, the same chain of loads)
+    const int nitems = (total + SDF_LIST_ITEM - 1) / SDF_LIST_ITEM;
+    const int run = nitems > nslot ? 2 : 1;
+    for (int item0 = slot * run; item0 < nitems; item0 += nslot * run)
+    for (int item = item0; item < item0 + run && item < nitems; ++item) {
         // the hand (entry 0 of an item is always valid); a new hand's table is requested first (global -> LDS, asynchronous) ...
         const int H = __builtin_amdgcn_readfirstlane((int)(glist[item * SDF_LIST_ITEM] >> 16));
         const bool stage = H != curH;          // uniform over the workgroup
