@@ -214,12 +214,17 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
                       float robustifier, float* loss, float* per_vert, float* origin, float* dval, bool dense, hipStream_t st) {
     // the inside-voxel counter is zero on entry (faces_to_soa_kernel on seam B, the skeleton kernel of the iteration
     // on seam C); the prep kernel appends to it
+    // small launches: the 1024-thread form (half the chain per thread), see sdf_collision.h
+    const bool small = 2 * B <= SDF_PREP_SMALL_MAX_HANDS;
     if (dense)
-        hipLaunchKernelGGL(sdf_prep_kernel<true>, dim3(2 * B), dim3(SDF_PREP_THREADS), 0, st, vl, B, faces_r_soa, faces_l_soa, ws,
-                           g_collect_stats);
+        hipLaunchKernelGGL((sdf_prep_kernel<true, SDF_PREP_THREADS_LARGE>), dim3(2 * B), dim3(SDF_PREP_THREADS_LARGE), 0, st, vl, B, faces_r_soa,
+                           faces_l_soa, ws, g_collect_stats);
+    else if (small)
+        hipLaunchKernelGGL((sdf_prep_kernel<false, SDF_PREP_THREADS_SMALL>), dim3(2 * B), dim3(SDF_PREP_THREADS_SMALL), 0, st, vl, B, faces_r_soa,
+                           faces_l_soa, ws, g_collect_stats);
     else
-        hipLaunchKernelGGL(sdf_prep_kernel<false>, dim3(2 * B), dim3(SDF_PREP_THREADS), 0, st, vl, B, faces_r_soa, faces_l_soa, ws,
-                           g_collect_stats);
+        hipLaunchKernelGGL((sdf_prep_kernel<false, SDF_PREP_THREADS_LARGE>), dim3(2 * B), dim3(SDF_PREP_THREADS_LARGE), 0, st, vl, B, faces_r_soa,
+                           faces_l_soa, ws, g_collect_stats);
     TimedPair tp;
     const bool timed = g_timer != nullptr;
     if (timed) {

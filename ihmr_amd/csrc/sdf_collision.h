@@ -25,9 +25,13 @@
 #include "ihmr_common.h"
 
 #define SDF_THREADS 256
-#define SDF_PREP_THREADS 512
-#define SDF_PREP_CPT (SDF_NCOL / SDF_PREP_THREADS)                         // adjacent grid columns owned by a thread
-#define SDF_PREP_VPT ((NV + SDF_PREP_THREADS - 1) / SDF_PREP_THREADS)   // vertices owned by a thread
+// sdf_prep_kernel<DENSE, PT>: PT threads per workgroup (one hand).  512: a thread owns two vertices, four triangles, two adjacent
+// grid columns -- the form for large launches (two 1024-thread workgroups fill a CU's thread slots while waiting most of their
+// cycles; 512-thread ones leave room for other kernels' workgroups: +4 % images/s with sixteen batches in flight).  1024: half the
+// chain per thread -- the form for small launches, where the kernel is as long as one workgroup (one batch of 64: 29.0 -> 22.1 us).
+#define SDF_PREP_THREADS_LARGE 512
+#define SDF_PREP_THREADS_SMALL 1024
+#define SDF_PREP_SMALL_MAX_HANDS 256     // up to this many hands per launch the 1024-thread form is used
 #define SDF_NCOL (SDF_G * SDF_G)   // 1024 columns (k,j)
 #define SDF_EVAL_CHUNKS 8          // workgroups per hand in the parity kernel
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
@@ -154,21 +158,23 @@ __device__ __forceinline__ void sdf_stage_async(const void* __restrict__ src, ch
     }
 }
 
-// exclusive prefix sum of data[0..1023] (LDS) by SDF_PREP_THREADS threads, thread t owning the SDF_PREP_CPT adjacent
-// elements from SDF_PREP_CPT * t; returns the total.
-__device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >= SDF_PREP_THREADS / 64 ints, LDS */) {
+// exclusive prefix sum of data[0..1023] (LDS) by PT threads, thread t owning the 1024 / PT adjacent elements from (1024 / PT) * t;
+// returns the total.
+template <int PT>
+__device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >= PT / 64 ints, LDS */) {
+    constexpr int CPT = SDF_NCOL / PT;
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
     SDF_LDS_BARRIER();
-    int m[SDF_PREP_CPT], mine = 0;
+    int m[CPT], mine = 0;
 #pragma unroll
-    for (int c = 0; c < SDF_PREP_CPT; ++c) { m[c] = data[SDF_PREP_CPT * tid + c]; mine += m[c]; }
+    for (int c = 0; c < CPT; ++c) { m[c] = data[CPT * tid + c]; mine += m[c]; }
     int wtot;
     const int inc = wave_incl_scan(mine, wtot);
     if (lane == WAVE - 1) scratch[wave] = wtot;
     SDF_LDS_BARRIER();
     int base = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < SDF_PREP_THREADS / WAVE; ++w) {
+    for (int w = 0; w < PT / WAVE; ++w) {
         const int x = scratch[w];
         if (w < wave) base += x;
         total += x;
@@ -176,7 +182,7 @@ __device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >
     SDF_LDS_BARRIER();
     int run = base + inc - mine;
 #pragma unroll
-    for (int c = 0; c < SDF_PREP_CPT; ++c) { data[SDF_PREP_CPT * tid + c] = run; run += m[c]; }
+    for (int c = 0; c < CPT; ++c) { data[CPT * tid + c] = run; run += m[c]; }
     SDF_LDS_BARRIER();
     return total;
 }
@@ -194,7 +200,7 @@ __device__ __forceinline__ void tri_col_range(float y0, float y1, float y2, floa
 
 // ------------------------------------------------------------------------------------- prep + parity
 // grid = 2B (block id = hand id H = hnd*B + b, so both hands of sample b sit on XCD b % 8 when B % 8 == 0),
-// block = SDF_PREP_THREADS (512).  Everything up to the inside/outside decision of a hand happens here, out of LDS:
+// block = PT (512 or 1024, see above).  Everything up to the inside/outside decision of a hand happens here, out of LDS:
 //   box -> normalised vertices -> needed-voxel mask (one 32-bit word per (k,j) column)
 //   -> lane = triangle: sphere + abc records to HBM for the distance kernel; for every needed column whose
 //      centre lies in the triangle's yz bounding box the (u,v) ray test, and for a hit the t > 0 test of the
@@ -256,30 +262,32 @@ __device__ __forceinline__ unsigned sdf_ray_hits(unsigned need, bool tri_safe, f
     return hits;
 }
 
-template <bool DENSE>
-__global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayout vl, int B, const int32_t* __restrict__ faces_r,
+template <bool DENSE, int PT>
+__global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, const int32_t* __restrict__ faces_r,
                                                                     const int32_t* __restrict__ faces_l, SdfWorkspace ws,
                                                                     int collect_stats) {
+    constexpr int CPT = SDF_NCOL / PT;             // adjacent grid columns owned by a thread
+    constexpr int VPT = (NV + PT - 1) / PT;         // vertices owned by a thread
     __shared__ float vn[NV3];
     __shared__ unsigned needed[SDF_NCOL];
     __shared__ unsigned rowany[SDF_G];      // bit j of word k: column (k,j) has a needed voxel
     __shared__ unsigned parity[SDF_NCOL];
     __shared__ int cur[SDF_NCOL];
-    __shared__ float red[6][SDF_PREP_THREADS / WAVE];
+    __shared__ float red[6][PT / WAVE];
     __shared__ float box[4];
-    __shared__ int scratch[SDF_PREP_THREADS / WAVE];
+    __shared__ int scratch[PT / WAVE];
     __shared__ int blk_inside, blk_base, blk_base_a;
     const int H = blockIdx.x, hnd = H / B, b = H % B, tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
     const float* own = vl.hand(b, hnd);
     const float* other = vl.hand(b, 1 - hnd);
     const int32_t* faces = hnd == 0 ? faces_r : faces_l;  // SoA [3][NFP]
-    // ---- bounding box (min / max are exact, any order); a thread owns vertices tid, tid + SDF_PREP_THREADS, ...
+    // ---- bounding box (min / max are exact, any order); a thread owns vertices tid, tid + PT, ...
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    float oq[SDF_PREP_VPT][3];
+    float oq[VPT][3];
 #pragma unroll
-    for (int rep = 0; rep < SDF_PREP_VPT; ++rep) {
+    for (int rep = 0; rep < VPT; ++rep) {
         oq[rep][0] = oq[rep][1] = oq[rep][2] = 0.f;
-        const int v = tid + rep * SDF_PREP_THREADS;
+        const int v = tid + rep * PT;
         if (v < NV) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -292,36 +300,36 @@ __global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayou
         }
     }
     // face indices of this lane's (up to four) triangles: issued early, consumed after the box is known
-    constexpr int TRI_IT = (NFP + SDF_PREP_THREADS - 1) / SDF_PREP_THREADS;
+    constexpr int TRI_IT = (NFP + PT - 1) / PT;
     int fidx[TRI_IT][3];
 #pragma unroll
     for (int it = 0; it < TRI_IT; ++it) {
-        const int f = min(tid + it * SDF_PREP_THREADS, NFP - 1);
+        const int f = min(tid + it * PT, NFP - 1);
         fidx[it][0] = faces[f]; fidx[it][1] = faces[NFP + f]; fidx[it][2] = faces[2 * NFP + f];
     }
     // state of the temporal candidate lists, requested now and used much later: the hand's reference pose (this thread's vertices)
     // and which voxels of this thread's two columns have a list
     const bool lists_on = !DENSE && ws.list_mode != 0;
-    float rf[SDF_PREP_VPT][3];
-    unsigned lb2[SDF_PREP_CPT];
+    float rf[VPT][3];
+    unsigned lb2[CPT];
 #pragma unroll
-    for (int rep = 0; rep < SDF_PREP_VPT; ++rep) {
-        const int v = tid + rep * SDF_PREP_THREADS;
+    for (int rep = 0; rep < VPT; ++rep) {
+        const int v = tid + rep * PT;
 #pragma unroll
         for (int k = 0; k < 3; ++k) rf[rep][k] = (lists_on && !ws.force_rebuild && v < NV) ? ws.vn_ref[(size_t)H * NV3 + 3 * v + k] : 0.f;
     }
 #pragma unroll
-    for (int rep = 0; rep < SDF_PREP_CPT; ++rep)
-        lb2[rep] = (lists_on && !ws.force_rebuild) ? ws.lbits[(size_t)H * SDF_NCOL + SDF_PREP_CPT * tid + rep] : 0u;
+    for (int rep = 0; rep < CPT; ++rep)
+        lb2[rep] = (lists_on && !ws.force_rebuild) ? ws.lbits[(size_t)H * SDF_NCOL + CPT * tid + rep] : 0u;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float a = wave_reduce_min(mn[k]), c = wave_reduce_max(mx[k]);
         if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = c; }
     }
 #pragma unroll
-    for (int rep = 0; rep < SDF_PREP_CPT; ++rep) {
-        needed[tid + rep * SDF_PREP_THREADS] = DENSE ? 0xffffffffu : 0u;
-        parity[tid + rep * SDF_PREP_THREADS] = 0u;
+    for (int rep = 0; rep < CPT; ++rep) {
+        needed[tid + rep * PT] = DENSE ? 0xffffffffu : 0u;
+        parity[tid + rep * PT] = 0u;
     }
     SDF_LDS_BARRIER();
     if (tid == 0) {
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayou
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             lo[k] = red[k][0]; hi[k] = red[3 + k][0];
-            for (int w = 1; w < SDF_PREP_THREADS / WAVE; ++w) { lo[k] = fminf(lo[k], red[k][w]); hi[k] = fmaxf(hi[k], red[3 + k][w]); }
+            for (int w = 1; w < PT / WAVE; ++w) { lo[k] = fminf(lo[k], red[k][w]); hi[k] = fmaxf(hi[k], red[3 + k][w]); }
         }
         box[0] = (lo[0] + hi[0]) * 0.5f;
         box[1] = (lo[1] + hi[1]) * 0.5f;
@@ -341,8 +349,8 @@ __global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayou
     if (tid < 4) ws.box[H * 4 + tid] = box[tid];
     // ---- normalise own vertices into [-1,1]^3; which voxels will the other hand's vertices read?
 #pragma unroll
-    for (int rep = 0; rep < SDF_PREP_VPT; ++rep) {
-        const int v = tid + rep * SDF_PREP_THREADS;
+    for (int rep = 0; rep < VPT; ++rep) {
+        const int v = tid + rep * PT;
         if (v >= NV) break;
         vn[3 * v] = (vn[3 * v] - cx) / sc;
         vn[3 * v + 1] = (vn[3 * v + 1] - cy) / sc;
@@ -371,9 +379,9 @@ __global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayou
     SDF_LDS_BARRIER();
     // which columns of a row hold a needed voxel at all: a wave covers two rows per pass, one ballot gives both words
 #pragma unroll
-    for (int rep = 0; rep < SDF_PREP_CPT; ++rep) {
-        const unsigned long long any = __ballot(needed[tid + rep * SDF_PREP_THREADS] != 0u);
-        if (lane == 0) { rowany[2 * wave + 16 * rep] = (unsigned)any; rowany[2 * wave + 16 * rep + 1] = (unsigned)(any >> 32); }
+    for (int rep = 0; rep < CPT; ++rep) {
+        const unsigned long long any = __ballot(needed[tid + rep * PT] != 0u);
+        if (lane == 0) { rowany[2 * (wave + (PT / WAVE) * rep)] = (unsigned)any; rowany[2 * (wave + (PT / WAVE) * rep) + 1] = (unsigned)(any >> 32); }
     }
     SDF_LDS_BARRIER();
     // ---- temporal candidate lists (fused refinement loop): how far has this hand moved, in its own normalised frame, since its
@@ -384,8 +392,8 @@ __global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayou
         float dmax = 0.f;
         if (!ws.force_rebuild) {
 #pragma unroll
-            for (int rep = 0; rep < SDF_PREP_VPT; ++rep) {
-                const int v = tid + rep * SDF_PREP_THREADS;
+            for (int rep = 0; rep < VPT; ++rep) {
+                const int v = tid + rep * PT;
                 if (v < NV) {
                     const float dx = vn[3 * v] - rf[rep][0], dy = vn[3 * v + 1] - rf[rep][1], dz = vn[3 * v + 2] - rf[rep][2];
                     dmax = fmaxf(dmax, sqrtf(dx * dx + dy * dy + dz * dz));
@@ -398,22 +406,22 @@ __global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayou
         bool reuse = !ws.force_rebuild;
         if (reuse) {
             float m = red[0][0];
-            for (int w = 1; w < SDF_PREP_THREADS / WAVE; ++w) m = fmaxf(m, red[0][w]);
+            for (int w = 1; w < PT / WAVE; ++w) m = fmaxf(m, red[0][w]);
             reuse = m <= SDF_LIST_SLACK - 1e-4f;        // (a NaN compares false: rebuild)
         }
         if (!reuse) {
 #pragma unroll
-            for (int rep = 0; rep < SDF_PREP_VPT; ++rep) {
-                const int v = tid + rep * SDF_PREP_THREADS;
+            for (int rep = 0; rep < VPT; ++rep) {
+                const int v = tid + rep * PT;
                 if (v < NV) { ref[3 * v] = vn[3 * v]; ref[3 * v + 1] = vn[3 * v + 1]; ref[3 * v + 2] = vn[3 * v + 2]; }
             }
 #pragma unroll
-            for (int rep = 0; rep < SDF_PREP_CPT; ++rep) ws.lbits[(size_t)H * SDF_NCOL + tid + rep * SDF_PREP_THREADS] = 0u;
+            for (int rep = 0; rep < CPT; ++rep) ws.lbits[(size_t)H * SDF_NCOL + tid + rep * PT] = 0u;
         }
         if (tid == 0) ws.hmode[H] = reuse ? 1 : 0;
         if (!reuse) {
 #pragma unroll
-            for (int rep = 0; rep < SDF_PREP_CPT; ++rep) lb2[rep] = 0u;
+            for (int rep = 0; rep < CPT; ++rep) lb2[rep] = 0u;
         }
     }
     // ---- lane = triangle: records for the distance kernel + ray parity of the needed voxels it can hit
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayou
     unsigned long long st_tests = 0;
 #pragma unroll
     for (int it = 0; it < TRI_IT; ++it) {
-        const int f = tid + it * SDF_PREP_THREADS;
+        const int f = tid + it * PT;
         if (f >= NFP) break;
         const int fa = fidx[it][0], fb = fidx[it][1], fc = fidx[it][2];
         const float a[3] = {vn[3 * fa], vn[3 * fa + 1], vn[3 * fa + 2]};
@@ -487,13 +495,13 @@ __global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayou
         }
     }
     SDF_LDS_BARRIER();
-    // ---- publish: a thread owns SDF_PREP_CPT adjacent columns; phi = 0 for the outside voxels, inside voxels
+    // ---- publish: a thread owns CPT adjacent columns; phi = 0 for the outside voxels, inside voxels
     //      into the batch-wide list
     float* phi = ws.phi + (size_t)H * SDF_NVOX;
-    unsigned need2[SDF_PREP_CPT], inside2[SDF_PREP_CPT];
+    unsigned need2[CPT], inside2[CPT];
 #pragma unroll
-    for (int rep = 0; rep < SDF_PREP_CPT; ++rep) {
-        const int col = SDF_PREP_CPT * tid + rep;
+    for (int rep = 0; rep < CPT; ++rep) {
+        const int col = CPT * tid + rep;
         need2[rep] = needed[col];
         inside2[rep] = parity[col] & need2[rep];
         unsigned rem = need2[rep] & ~inside2[rep];
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayou
         // inside voxels with a candidate list (low half) / without (high half): one scan for both
         cur[col] = __popc(inside2[rep] & lb2[rep]) | (__popc(inside2[rep] & ~lb2[rep]) << 16);
     }
-    const unsigned blk_both = (unsigned)block_excl_scan_1024(cur, scratch);
+    const unsigned blk_both = (unsigned)block_excl_scan_1024<PT>(cur, scratch);
     // Two batch-wide lists, each with an aligned run per hand (tail padded with an invalid marker) so that a work item belongs to
     // exactly one hand.  inside_list_a: voxels with a valid candidate list, for sdf_list_search; inside_list: the others (every
     // inside voxel of a single-shot call or of a hand whose lists are being rebuilt), for the full search of sdf_dist_kernel.
@@ -523,8 +531,8 @@ __global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayou
     if (tid < pad_b - n_b) run_b[n_b + tid] = 0xffffffffu;
     if (tid < pad_a - n_a) run_a[n_a + tid] = 0xffffffffu;
 #pragma unroll
-    for (int rep = 0; rep < SDF_PREP_CPT; ++rep) {
-        const int col = SDF_PREP_CPT * tid + rep;
+    for (int rep = 0; rep < CPT; ++rep) {
+        const int col = CPT * tid + rep;
         const unsigned both = (unsigned)cur[col];
         int oa = (int)(both & 0xffffu), ob = (int)(both >> 16);
         unsigned rem = inside2[rep];
@@ -542,7 +550,7 @@ __global__ __launch_bounds__(SDF_PREP_THREADS, 8) void sdf_prep_kernel(VertLayou
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
         unsigned long long nv = 0;
 #pragma unroll
-        for (int rep = 0; rep < SDF_PREP_CPT; ++rep) nv += (unsigned long long)__popc(need2[rep]);
+        for (int rep = 0; rep < CPT; ++rep) nv += (unsigned long long)__popc(need2[rep]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nv += __shfl_xor(nv, o);
         if (lane == 0) { atomicAdd(&ws.stats[0], c); atomicAdd(&ws.stats[3], nv); }   // ray tests, needed voxels
