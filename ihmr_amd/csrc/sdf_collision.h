@@ -1026,6 +1026,7 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
 // (x mask[b] = [hand_type_array sum > 1.5] when hand_type != nullptr, loss_utils.py:186-188).
 // If gverts != nullptr: fused-path gradient gverts[(1-hnd), b, v, :] = gs * dval  (layout (2,B,778,3)).
 #define SDF_SAMPLE_THREADS 512
+#define SDF_SAMPLE_NIT 4             // entries per thread: ceil(1556 / 448) with the fused kernel's 448 sampling threads
 __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const SdfWorkspace& ws, float robustifier,
                                                  float* __restrict__ loss, float* __restrict__ per_vert,
                                                  float* __restrict__ origin, float* __restrict__ dval,
@@ -1033,23 +1034,41 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
                                                  const float* __restrict__ hand_type, float* red16, int b, int nworkers) {
     const int tid = threadIdx.x;
     float acc = 0.f;
-    for (int e = tid; e < 2 * NV && tid < nworkers; e += nworkers) {
-        const int hnd = e / NV, v = e % NV;
-        const int H = hnd * B + b;
-        const float4 bx = *reinterpret_cast<const float4*>(ws.box + H * 4);
-        const float cx = bx.x, cy = bx.y, cz = bx.z, sc = bx.w;
-        const float* q = vl.hand(b, 1 - hnd) + 3 * v;
-        const float ix = sdf_unnorm((q[0] - cx) / sc, ws.align_corners), iy = sdf_unnorm((q[1] - cy) / sc, ws.align_corners),
-                    iz = sdf_unnorm((q[2] - cz) / sc, ws.align_corners);
+    // A thread owns the entries tid, tid + nworkers, ... (at most SDF_SAMPLE_NIT).  Three phases over ALL of them, so that the two
+    // dependent round trips (vertex + box, then the eight grid corners) are paid once per thread, not once per entry: as a plain
+    // loop the stores of one entry keep the loads of the next from being issued early.  Arithmetic and summation order per entry
+    // are those of the loop.
+    bool on[SDF_SAMPLE_NIT];
+    int hn[SDF_SAMPLE_NIT], vx[SDF_SAMPLE_NIT];
+    float4 bx[SDF_SAMPLE_NIT];
+    float qv[SDF_SAMPLE_NIT][3];
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        const int e = tid + it * nworkers;
+        on[it] = e < 2 * NV && tid < nworkers;
+        const int ee = on[it] ? e : 0;
+        hn[it] = ee / NV; vx[it] = ee % NV;
+        bx[it] = *reinterpret_cast<const float4*>(ws.box + (hn[it] * B + b) * 4);
+        const float* q = vl.hand(b, 1 - hn[it]) + 3 * vx[it];
+        qv[it][0] = q[0]; qv[it][1] = q[1]; qv[it][2] = q[2];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float pv[SDF_SAMPLE_NIT][8], ixs[SDF_SAMPLE_NIT][3];
+    bool inr[SDF_SAMPLE_NIT];
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        const float cx = bx[it].x, cy = bx[it].y, cz = bx[it].z, sc = bx[it].w;
+        const float ix = sdf_unnorm((qv[it][0] - cx) / sc, ws.align_corners), iy = sdf_unnorm((qv[it][1] - cy) / sc, ws.align_corners),
+                    iz = sdf_unnorm((qv[it][2] - cz) / sc, ws.align_corners);
+        ixs[it][0] = ix; ixs[it][1] = iy; ixs[it][2] = iz;
         const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
-        float val = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-        if (x0 >= -1.0f && x0 <= (float)(SDF_G - 1) && y0 >= -1.0f && y0 <= (float)(SDF_G - 1) && z0 >= -1.0f &&
-            z0 <= (float)(SDF_G - 1)) {
+        inr[it] = on[it] && x0 >= -1.0f && x0 <= (float)(SDF_G - 1) && y0 >= -1.0f && y0 <= (float)(SDF_G - 1) && z0 >= -1.0f &&
+                  z0 <= (float)(SDF_G - 1);
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) pv[it][c8] = 0.f;
+        if (inr[it]) {
             const int i0 = (int)x0, j0 = (int)y0, k0 = (int)z0;
-            const float fx = ix - x0, fy = iy - y0, fz = iz - z0;
-            const float wx1 = fx, wx0 = (x0 + 1.0f) - ix, wy1 = fy, wy0 = (y0 + 1.0f) - iy, wz1 = fz, wz0 = (z0 + 1.0f) - iz;
-            const float* phi = ws.phi + (size_t)H * SDF_NVOX;
-            float pv[8];
+            const float* phi = ws.phi + (size_t)(hn[it] * B + b) * SDF_NVOX;
             // the two x-neighbours of a cell are adjacent in memory: one load for the pair when both are inside the grid
             // (4-byte aligned 8-byte load: the hardware takes dword-aligned global accesses of any width), single loads at
             // the border of the grid
@@ -1061,18 +1080,33 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
                 if (row_in && i0 >= 0 && i0 + 1 < SDF_G) {
                     typedef float sdf_f2u __attribute__((ext_vector_type(2), aligned(4)));
                     const sdf_f2u two = *reinterpret_cast<const sdf_f2u*>(row + i0);
-                    pv[2 * c4] = two.x; pv[2 * c4 + 1] = two.y;
+                    pv[it][2 * c4] = two.x; pv[it][2 * c4 + 1] = two.y;
                 } else {
-                    pv[2 * c4] = (row_in && i0 >= 0) ? row[i0] : 0.f;
-                    pv[2 * c4 + 1] = (row_in && i0 + 1 < SDF_G) ? row[i0 + 1] : 0.f;
+                    pv[it][2 * c4] = (row_in && i0 >= 0) ? row[i0] : 0.f;
+                    pv[it][2 * c4 + 1] = (row_in && i0 + 1 < SDF_G) ? row[i0 + 1] : 0.f;
                 }
             }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        if (!on[it]) continue;
+        const int e = tid + it * nworkers, hnd = hn[it], v = vx[it];
+        const float sc = bx[it].w;
+        const float ix = ixs[it][0], iy = ixs[it][1], iz = ixs[it][2];
+        const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+        float val = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+        if (inr[it]) {
+            const int i0 = (int)x0, j0 = (int)y0, k0 = (int)z0;
+            const float fx = ix - x0, fy = iy - y0, fz = iz - z0;
+            const float wx1 = fx, wx0 = (x0 + 1.0f) - ix, wy1 = fy, wy0 = (y0 + 1.0f) - iy, wz1 = fz, wz0 = (z0 + 1.0f) - iz;
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) {
                 const int di = c8 & 1, dj = (c8 >> 1) & 1, dk = c8 >> 2;
                 const int i = i0 + di, j = j0 + dj, k = k0 + dk;
                 if (i >= 0 && i < SDF_G && j >= 0 && j < SDF_G && k >= 0 && k < SDF_G) {
-                    const float p = pv[c8];
+                    const float p = pv[it][c8];
                     const float wx = di ? wx1 : wx0, wy = dj ? wy1 : wy0, wz = dk ? wz1 : wz0;
                     val += p * (wx * wy * wz);
                     gx += (di ? p : -p) * (wy * wz);
