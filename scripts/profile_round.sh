@@ -5,7 +5,7 @@
 tag=${1:-rX}_f${FUSE:-8}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps ${STEPS:-2} --warmup 1 --streams 1 --fuse ${FUSE:-8} --no-cpu-baseline --no-extras --no-work-counters"
+CMD="python3 bench.py --steps ${STEPS:-${FUSE:-8}} --warmup ${FUSE:-8} --streams 1 --fuse ${FUSE:-8} --no-cpu-baseline --no-extras --no-work-counters"
 mkdir -p gpurun_out
 rm -rf gpurun_out/kt gpurun_out/pmc_f gpurun_out/pmc_w
 timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/kt -o kt -- $CMD > gpurun_out/${tag}_kt.log 2>&1
