@@ -742,15 +742,18 @@ __global__ __launch_bounds__(64) void lbs_bwd2_kernel(ihmr_mano m, LbsWork wk, i
     const float* arow = m.posedirs + (size_t)min(e, NPF - 1) * NV3;
     const float* brow = wk.dvp + (size_t)min(hand, N - 1) * NV3;
     const bool a_ok = e < NPF, b_ok = hand < N;
-    lbs_v2f av[LBS_KC][8], bv[LBS_KC][8];
+    // 16-byte loads (rows are 8-byte aligned only: NV3 * 4 = 9336; the hardware takes dword-aligned global accesses of any width):
+    // half as many address-processing slots as float pairs -- the kernel is bound by those, every lane reads its own cache line
+    typedef float lbs_f4u __attribute__((ext_vector_type(4), aligned(8)));
+    lbs_f4u av[LBS_KC][4], bv[LBS_KC][4];
 #pragma unroll
     for (int c = 0; c < LBS_KC; ++c) {
         const int k0 = (kg * LBS_KC + c) * 32 + 16 * kp;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = min(k0 + 2 * q, NV3 - 2);          // NV3 is even: a float pair never straddles the end
-            av[c][q] = *reinterpret_cast<const lbs_v2f*>(arow + k);
-            bv[c][q] = *reinterpret_cast<const lbs_v2f*>(brow + k);
+        for (int q = 0; q < 4; ++q) {
+            const int k = min(k0 + 4 * q, NV3 - 4);          // (a clamped load only feeds elements that are masked below)
+            av[c][q] = *reinterpret_cast<const lbs_f4u*>(arow + k);
+            bv[c][q] = *reinterpret_cast<const lbs_f4u*>(brow + k);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -761,12 +764,19 @@ __global__ __launch_bounds__(64) void lbs_bwd2_kernel(ihmr_mano m, LbsWork wk, i
     for (int c = 0; c < LBS_KC; ++c) {
         const int k0 = (kg * LBS_KC + c) * 32 + 16 * kp;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool k_ok = k0 + 2 * q < NV3;
-            const float a0 = (a_ok && k_ok) ? av[c][q].x : 0.f, a1 = (a_ok && k_ok) ? av[c][q].y : 0.f;
-            const float b0 = (b_ok && k_ok) ? bv[c][q].x : 0.f, b1 = (b_ok && k_ok) ? bv[c][q].y : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            // NV3 % 4 == 2: the last group of four of a row is half valid; it is loaded from NV3 - 4 (shifted by two), so its
+            // valid elements k0 + 4q, k0 + 4q + 1 sit in .z, .w
+            const int kq = k0 + 4 * q;
+            const bool sh = kq + 4 > NV3 && kq < NV3;
+            const float ax[4] = {sh ? av[c][q].z : av[c][q].x, sh ? av[c][q].w : av[c][q].y, av[c][q].z, av[c][q].w};
+            const float bx[4] = {sh ? bv[c][q].z : bv[c][q].x, sh ? bv[c][q].w : bv[c][q].y, bv[c][q].z, bv[c][q].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool k_ok = kq + t < NV3;
+                const float a0 = (a_ok && k_ok) ? ax[t] : 0.f, b0 = (b_ok && k_ok) ? bx[t] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+            }
         }
     }
     // C/D layout: column (hand) = lane & 31, row (feature) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
