@@ -99,10 +99,12 @@ def pmc_traffic(kernel, batches_per_launch):
     if not files:
         return None, None
     with open(files[-1], newline="") as fh:
-        for r in csv.DictReader(fh):
-            if r["kernel"].startswith(kernel):
-                return float(r["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(files[-1])
-    return None, None
+        rows = [r for r in csv.DictReader(fh) if r["kernel"].startswith(kernel)]
+    if not rows:
+        return None, None
+    # one row per launch shape: the shape launched most often is the profiled size (the others: a one-batch instance's first pass)
+    r = max(rows, key=lambda r: int(r["launches"]))
+    return float(r["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(files[-1])
 
 
 
