@@ -37,6 +37,9 @@ struct ihmr_mano {
     float* J_template;    // [48]   = J_regressor . v_template
     float* J_shapedirs;   // [48][10] = J_regressor . shapedirs
     float* weights;       // [778][16]
+    float4* w4_w;         // [778] the (up to) four non-zero skinning weights of a vertex in joint order, zero padded ...
+    uint32_t* w4_j;       // [778] ... and their joints, one byte each (padding: joint 0 with weight 0)
+    int sparse4;          // every vertex has at most four non-zero weights (MANO's own weights do): the skinning loops run over w4_*
     float* pose_mean;     // [48]
     int32_t* parents;     // [16]
     int32_t* depth;       // [16] depth in the kinematic tree (root = 0)

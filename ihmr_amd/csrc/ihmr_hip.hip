@@ -90,6 +90,20 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
             if (wts[v * NJ + j] != 0.f) { wv.push_back(v); ww.push_back(wts[v * NJ + j]); }
         start[j + 1] = (int32_t)wv.size();
     }
+    // by vertex: the (up to) four non-zero weights in joint order (a zero weight adds an exact zero to the skinning sums, so
+    // leaving the zeros out changes no bit); an asset with a denser vertex keeps the 16-joint loops
+    std::vector<float> w4w((size_t)NV * 4, 0.f);
+    std::vector<uint32_t> w4j(NV, 0u);
+    int sparse4 = 1;
+    for (int v = 0; v < NV; ++v) {
+        int n = 0;
+        for (int j = 0; j < NJ; ++j)
+            if (wts[v * NJ + j] != 0.f) {
+                if (n < 4) { w4w[(size_t)v * 4 + n] = wts[v * NJ + j]; w4j[v] |= (uint32_t)j << (8 * n); }
+                ++n;
+            }
+        if (n > 4) sparse4 = 0;
+    }
     std::vector<int32_t> seg_q, jseg(NJ + 1, 0);
     for (int j = 0; j < NJ; ++j) {
         jseg[j] = (int32_t)seg_q.size();
@@ -113,6 +127,8 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
     rc |= upload_as(&m->pd4, pd4); rc |= upload_as(&m->sd4, sd4); rc |= upload_as(&m->vt4, vt4);
     rc |= upload(&m->v_template, vt); rc |= upload(&m->shapedirs_t, sd_t); rc |= upload(&m->posedirs, pd);
     rc |= upload(&m->J_template, J_t); rc |= upload(&m->J_shapedirs, J_sd); rc |= upload(&m->weights, wts);
+    rc |= upload_as(&m->w4_w, w4w); rc |= upload(&m->w4_j, w4j);
+    m->sparse4 = sparse4;
     rc |= upload(&m->pose_mean, pm); rc |= upload(&m->parents, par); rc |= upload(&m->depth, depth);
     rc |= upload(&m->tip_ids, tips); rc |= upload(&m->wj_start, start); rc |= upload(&m->wj_vert, wv);
     rc |= upload(&m->wj_w, ww); rc |= upload(&m->seg_q, seg_q); rc |= upload(&m->jseg_start, jseg); rc |= upload(&m->faces, fsoa); rc |= upload(&m->J_regressor, jr);
@@ -135,7 +151,8 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
 extern "C" int ihmr_mano_destroy(ihmr_mano* m) {
     if (!m) return 0;
     void* ptrs[] = {m->v_template, m->shapedirs_t, m->posedirs, m->J_template, m->J_shapedirs, m->weights, m->pose_mean,
-                    m->parents, m->depth, m->tip_ids, m->wj_start, m->wj_vert, m->wj_w, m->faces, m->J_regressor, m->pd4, m->sd4, m->vt4, m->seg_q, m->jseg_start};
+                    m->parents, m->depth, m->tip_ids, m->wj_start, m->wj_vert, m->wj_w, m->faces, m->J_regressor, m->pd4, m->sd4, m->vt4, m->seg_q, m->jseg_start,
+                    m->w4_w, m->w4_j};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;

@@ -337,8 +337,14 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
         }
         consume(pa, NPF - 9);
     }
+    // skinning weights: the vertex's (up to) four non-zero ones when the asset has no denser vertex (MANO's own weights), else all 16
     float w[NJ];
-    {
+    float4 ws4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t js4 = 0u;
+    if (m.sparse4) {
+        ws4 = m.w4_w[v];
+        js4 = m.w4_j[v];
+    } else {
         const float4* w4 = reinterpret_cast<const float4*>(m.weights + v * NJ);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { const float4 x = w4[q]; w[4 * q] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w; }
@@ -356,15 +362,33 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
         lbs_v2f T[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = lbs_v2f{0.f, 0.f};
+        if (m.sparse4) {
+            // the same sum without its zero terms (joint order kept; fma(0, a, T) == T): 4 instead of 16 joints, the rows
+            // gathered from LDS per lane instead of broadcast
+            const float wv[4] = {ws4.x, ws4.y, ws4.z, ws4.w};
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const lbs_v2f wj = {w[j], w[j]};
-            const float4* A4 = reinterpret_cast<const float4*>(&A_s[q][12 * j][0]);   // {A[e] h0, A[e] h1, A[e+1] h0, A[e+1] h1}
+            for (int sI = 0; sI < 4; ++sI) {
+                const int j = (int)((js4 >> (8 * sI)) & 0xffu);
+                const lbs_v2f wj = {wv[sI], wv[sI]};
+                const float4* A4 = reinterpret_cast<const float4*>(&A_s[q][12 * j][0]);
 #pragma unroll
-            for (int e2 = 0; e2 < 6; ++e2) {
-                const float4 a = A4[e2];
-                T[2 * e2] = __builtin_elementwise_fma(wj, lbs_v2f{a.x, a.y}, T[2 * e2]);
-                T[2 * e2 + 1] = __builtin_elementwise_fma(wj, lbs_v2f{a.z, a.w}, T[2 * e2 + 1]);
+                for (int e2 = 0; e2 < 6; ++e2) {
+                    const float4 a = A4[e2];
+                    T[2 * e2] = __builtin_elementwise_fma(wj, lbs_v2f{a.x, a.y}, T[2 * e2]);
+                    T[2 * e2 + 1] = __builtin_elementwise_fma(wj, lbs_v2f{a.z, a.w}, T[2 * e2 + 1]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const lbs_v2f wj = {w[j], w[j]};
+                const float4* A4 = reinterpret_cast<const float4*>(&A_s[q][12 * j][0]);   // {A[e] h0, A[e] h1, A[e+1] h0, A[e+1] h1}
+#pragma unroll
+                for (int e2 = 0; e2 < 6; ++e2) {
+                    const float4 a = A4[e2];
+                    T[2 * e2] = __builtin_elementwise_fma(wj, lbs_v2f{a.x, a.y}, T[2 * e2]);
+                    T[2 * e2 + 1] = __builtin_elementwise_fma(wj, lbs_v2f{a.z, a.w}, T[2 * e2 + 1]);
+                }
             }
         }
         lbs_v2f o2[3];
@@ -521,6 +545,41 @@ __global__ __launch_bounds__(LBS_THREADS, 4) void lbs_bwd1_kernel(ihmr_mano m, L
     // ---- per vertex: d v_posed = T.R^T g, T.R = sum_j w_j A_j.R over all 16 joints (no branches: a zero weight adds
     //      an exact zero), the matrices read from LDS as broadcast rows.  Only the finger-pose and shape gradients need it.
     if (need_pose || need_betas) {
+    if (m.sparse4) {
+        // the vertex's (up to) four non-zero weights (see lbs_skin_kernel): the same sums without their zero terms
+        float4 wr[VR];
+        uint32_t jr[VR];
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            const int v = min(tid + r * LBS_THREADS, NV - 1);
+            wr[r] = m.w4_w[v];
+            jr[r] = m.w4_j[v];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            const int v = tid + r * LBS_THREADS;
+            if (v >= NV) break;
+            const float wv[4] = {wr[r].x, wr[r].y, wr[r].z, wr[r].w};
+            float T[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                const float4* A4 = reinterpret_cast<const float4*>(sA + 12 * (int)((jr[r] >> (8 * sI)) & 0xffu));
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float4 a = A4[q];
+                    T[4 * q] = __builtin_fmaf(wv[sI], a.x, T[4 * q]);
+                    T[4 * q + 1] = __builtin_fmaf(wv[sI], a.y, T[4 * q + 1]);
+                    T[4 * q + 2] = __builtin_fmaf(wv[sI], a.z, T[4 * q + 2]);
+                }
+            }
+            const float g0 = bw.g[3 * v], g1 = bw.g[3 * v + 1], g2 = bw.g[3 * v + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wk.dvp[(size_t)h * NV3 + 3 * v + c] = T[c] * g0 + T[4 + c] * g1 + T[8 + c] * g2;
+        }
+    } else {
     // the skinning weights of this thread's (up to 4) vertices, all 16 loads in flight together (L2 hits; the other three
     // resident workgroups of the CU cover the round trip)
     float4 wreg[VR][4];
@@ -557,6 +616,7 @@ __global__ __launch_bounds__(LBS_THREADS, 4) void lbs_bwd1_kernel(ihmr_mano m, L
         for (int c = 0; c < 3; ++c) {
             wk.dvp[(size_t)h * NV3 + 3 * v + c] = T[c] * g0 + T[4 + c] * g1 + T[8 + c] * g2;
         }
+    }
     }
     }
     // ---- dA[j][e] = sum_v W[v][j] * [g (x) v_posed | g][e].  The CSR-by-joint list is cut into single-joint
