@@ -89,6 +89,48 @@ def test_lbs_backward_matches_autograd(mano_arrays, which):
             _report(f"lbs d{k} [{which}]", got[k], ref[k], atol=2e-5 * scale)
 
 
+def _dense_weight_asset(arr, nnz=7, seed=5):
+    """The synthetic asset with up to `nnz` non-zero skinning weights per vertex (rows still sum to 1): MANO's own weights have at
+    most four, which is what the kernels' short skinning loops assume -- a denser asset must take their 16-joint form."""
+    rng = np.random.default_rng(seed)
+    a = dict(arr)
+    w = np.array(arr["lbs_weights"], dtype=np.float64)
+    for v in range(0, w.shape[0], 3):
+        extra = rng.choice(w.shape[1], size=nnz, replace=False)
+        w[v, extra] += rng.uniform(0.02, 0.2, size=nnz)
+    w /= w.sum(axis=1, keepdims=True)
+    a["lbs_weights"] = w.astype(arr["lbs_weights"].dtype)
+    assert int((a["lbs_weights"] != 0).sum(axis=1).max()) > 4
+    return a
+
+
+def test_lbs_dense_weight_asset_matches_oracle(mano_arrays):
+    """Forward and all gradients of the LBS kernels on an asset whose vertices have MORE than four non-zero skinning weights (the
+    16-joint loops) against the oracle; the same inputs on the 4-sparse asset go through the short loops (tests above)."""
+    from ihmr_amd import mano
+    from oracle.mano_ref import ManoRef
+    right, _ = mano_arrays
+    arr = _dense_weight_asset(right)
+    N = 5
+    orient, pose, betas = _rand_mano_inputs(N, 11)
+    g = torch.Generator().manual_seed(12)
+    gv = torch.randn(N, 778, 3, generator=g)
+    gj = torch.randn(N, 16, 3, generator=g)
+
+    def run(module, dev):
+        o, p, b = (t.clone().to(dev).requires_grad_(True) for t in (orient, pose, betas))
+        out = module(global_orient=o, hand_pose=p, betas=b)
+        ((out.vertices * gv.to(dev)).sum() + (out.joints * gj.to(dev)).sum()).backward()
+        return out.vertices.detach().cpu(), out.joints.detach().cpu(), o.grad.cpu(), p.grad.cpu(), b.grad.cpu()
+
+    ref = run(ManoRef(arr), "cpu")
+    got = run(mano.MANO(arr).to(_dev()), _dev())
+    _report("dense-weight lbs verts", got[0], ref[0], atol=2e-6)
+    _report("dense-weight lbs joints", got[1], ref[1], atol=2e-6)
+    for name, a, b in zip(("orient", "pose", "betas"), got[2:], ref[2:]):
+        _report(f"dense-weight lbs d{name}", a, b, atol=2e-5 * float(b.abs().max()))
+
+
 # ----------------------------------------------------------------------------------- seam B (collision)
 def _two_hand_verts(mano_arrays, B, seed):
     """(B,2,778,3) penetrating hand pairs from the oracle forward on the synthetic batch."""
