@@ -419,7 +419,7 @@ def main():
         for q in plan(args.steps):
             for g in q:
                 sizes_run[g] = sizes_run.get(g, 0) + 1
-        per_size, tot_flops, tot_ms = [], 0.0, 0.0
+        per_size, tot_flops, tot_ms, tot_full = [], 0.0, 0.0, 0.0
         for g in sorted(sizes_run):
             mdl = instance(0, g)
             timer = hip.KernelTimer(0.0, 0, 0.0, 0.0)
@@ -461,16 +461,22 @@ def main():
             if avg_ms > 0 and flops:
                 tot_flops += flops * sizes_run[g]
                 tot_ms += avg_ms * sizes_run[g]
+                tot_full += (1538 * 11.0 * stats["inside_voxels"] + 75.0 * stats["dist_evals"]) * sizes_run[g]
         # HBM traffic: the committed PMC summary of the launch size that carried most of the timed region's work
         g_main = max(sizes_run, key=lambda g: g * sizes_run[g])
         traffic, traffic_src = pmc_traffic("sdf_dist_kernel", g_main) if (B == 64 and args.epoch == 49) else (None, None)
         ach = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None
+        ach_full = tot_full / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 and tot_full > 0 else None
         roofline = dict(bound="valu", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=(ach / FP32_PEAK_TFLOPS) if ach else None,
                         traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
                         traffic_batches_per_launch=g_main,
                         traffic_note="HBM bytes per launch from the committed rocprofv3 PMC summary of this command at --streams 1 and "
                                      "the same launch size (counters cannot be read from inside the process), not of this run",
                         kernel="sdf_dist_kernel", by_launch_size=per_size,
+                        full_search_equivalent=dict(achieved=ach_full, frac=(ach_full / FP32_PEAK_TFLOPS) if ach_full else None,
+                                                    note="the same launches priced with the work of searching all 1538 triangles for every "
+                                                         "inside voxel (the kernel without its candidate lists; rounds 1 and early 2 were "
+                                                         "priced this way): comparable across rounds, not what the kernel executes"),
                         note="largest share of GPU time in the rocprofv3 kernel summary (profiles/).  Pure fp32 VALU kernel (compares, "
                              "selects, FMAs; no GEMM shape): priced against the 157.3 TFLOP/s fp32 vector peak.  `achieved` = "
                              "flops the kernel executed (its own counters: 11 per bounding-sphere test, 75 per exact point-triangle "
