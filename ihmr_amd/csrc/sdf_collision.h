@@ -495,8 +495,8 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         }
     }
     SDF_LDS_BARRIER();
-    // ---- publish: a thread owns CPT adjacent columns; phi = 0 for the outside voxels, inside voxels
-    //      into the batch-wide list
+    // ---- publish: a thread owns CPT adjacent columns; phi = 0 for the outside voxels a sample reads, inside voxels
+    //      into the batch-wide lists
     float* phi = ws.phi + (size_t)H * SDF_NVOX;
     unsigned need2[CPT], inside2[CPT];
 #pragma unroll
@@ -504,11 +504,12 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         const int col = CPT * tid + rep;
         need2[rep] = needed[col];
         inside2[rep] = parity[col] & need2[rep];
-        unsigned rem = need2[rep] & ~inside2[rep];
-        while (rem) {
-            const int i = __ffs((int)rem) - 1;
-            rem &= rem - 1;
-            phi[col * SDF_G + i] = 0.0f;
+        // phi = 0 for the outside voxels a sample reads: the column's whole 128-byte row is zeroed (eight 16-byte stores, no loop over
+        // the bits: the inside voxels are overwritten by the distance kernel, which runs after this one, and nobody reads the rest)
+        if (need2[rep] & ~inside2[rep]) {
+            float4* row = reinterpret_cast<float4*>(phi + col * SDF_G);
+#pragma unroll
+            for (int q = 0; q < SDF_G / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // inside voxels with a candidate list (low half) / without (high half): one scan for both
         cur[col] = __popc(inside2[rep] & lb2[rep]) | (__popc(inside2[rep] & ~lb2[rep]) << 16);
