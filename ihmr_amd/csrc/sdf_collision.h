@@ -10,8 +10,8 @@
 //   * only voxels that a sample actually reads are evaluated (<= 8 corners per query vertex,
 //     collected in a 1024 x 32-bit mask per hand);
 //   * all voxels of a (k,j) column share the +x ray, so the (u,v) triangle test is done once per
-//     column -- one wave per column, lanes across the 1538 triangles, coalesced SoA reads of a
-//     per-iteration triangle table -- and only the surviving candidates are tested per voxel (t > 0);
+//     (triangle, column) -- lane = triangle, looping over the needed columns of its yz bounding box --
+//     and the t > 0 test of the column's voxels is a loop-free hit mask (sdf_ray_hits);
 //   * the distance of an inside voxel is a wave-level min-reduction: lanes across triangles,
 //     culled by a bounding-sphere lower bound against a wave-wide upper bound (exact: a culled
 //     triangle can never be the minimum);
@@ -33,10 +33,9 @@
 #define SDF_PREP_THREADS_SMALL 1024
 #define SDF_PREP_SMALL_MAX_HANDS 256     // up to this many hands per launch the 1024-thread form is used
 #define SDF_NCOL (SDF_G * SDF_G)   // 1024 columns (k,j)
-#define SDF_EVAL_CHUNKS 8          // workgroups per hand in the parity kernel
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
 #ifndef SDF_DIST_BLOCKS
-#define SDF_DIST_BLOCKS 2048          // >= the work items of two fused 64-sample batches (~1800): one item per workgroup, no second table staging; 4 workgroups (30 KB LDS, <= 128 VGPRs) per CU
+#define SDF_DIST_BLOCKS 2048          // smallest grid of sdf_dist_kernel (a multiple of 16); 4 workgroups (40 KB LDS, <= 128 VGPRs) per CU
 #endif
 #define SDF_SURV_CAP 512             // LDS slots per wave for the triangles surviving the sphere cull (typically ~40)
 #ifndef SDF_ITEM_RUN
@@ -606,13 +605,14 @@ __device__ __forceinline__ float sdf_point_tri_dist2(const float* a, const float
     return DOT3(dx, dy, dz, dx, dy, dz);
 }
 
-// ------------------------------------------------------------------------------------- distance
-// grid = SDF_DIST_BLOCKS, block = 256 (4 waves), 4 workgroups per CU (<= 128 VGPRs, 36 KB LDS).  The inside voxels of
+// ------------------------------------------------------------------------------------- distance: full search
+// (one of the two searches of sdf_dist_kernel, below; grid-strided over its slots.)  The inside voxels of
 // the whole batch sit in one list (balanced work matters more here than L2 affinity: the per-sample counts vary
 // by 3x).  A work item = SDF_ITEM (16) consecutive list entries = inside voxels of ONE hand: the workgroup stages
 // that hand's 1538 bounding spheres in LDS (32 KB), then each wave takes 4 voxels, two at a time through the
 // sphere passes (lanes across triangles, packed fp32 on the voxel pair): upper bound = nearest centroid, cull,
-// scan-compacted survivors, exact closest-point distance on dense lanes, DPP min.
+// scan-compacted survivors of the wave's four voxels as dense (voxel, triangle) pairs, exact closest-point distance, 64-bit LDS
+// atomic min on (distance bits, triangle).  While a hand's candidate lists are being (re)built it also writes them.
 typedef float sdf_v2f __attribute__((ext_vector_type(2)));
 #define SDF_FULL_LDS (NFP * 20 + (SDF_THREADS / WAVE) * (SDF_SURV_CAP * 4 + 4 * 8))
 __device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int collect_stats, int slot, int nslot, char* smem) {
