@@ -178,15 +178,22 @@ extern "C" size_t ihmr_mano_workspace_bytes(int N) { return lbs_ws_bytes(N); }
 
 static void lbs_forward_launch(const ihmr_mano* m, bool two_hand, const float* orient, const float* pose, const float* betas,
                                const float* trans, int N, int B, float* verts, float* joints, const LbsWork& wk, hipStream_t st) {
-    const dim3 skin_grid(8, 4 * ((N + 63) / 64));
+    // small launches: four instead of eight hands per skin workgroup (half the chain per thread, see lbs_skin_kernel)
+    const bool small = N <= LBS_SMALL_MAX_HANDS;
+    const int hg8 = 8 * (small ? LBS_HG_SMALL : LBS_HG);
+    const dim3 skin_grid(8, 4 * ((N + hg8 - 1) / hg8));
     if (two_hand) {
         hipLaunchKernelGGL(lbs_skel_kernel<true>, dim3(N), dim3(192), 0, st, *m, orient, pose, betas, trans, B, wk.skel, joints);
-        hipLaunchKernelGGL(lbs_skin_kernel<true>, skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
-                           joints, wk.v_posed);
+        if (small) hipLaunchKernelGGL((lbs_skin_kernel<true, false, LBS_HG_SMALL>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B,
+                                      verts, joints, wk.v_posed);
+        else hipLaunchKernelGGL((lbs_skin_kernel<true, false, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
+                                joints, wk.v_posed);
     } else {
         hipLaunchKernelGGL(lbs_skel_kernel<false>, dim3(N), dim3(192), 0, st, *m, orient, pose, betas, trans, B, wk.skel, joints);
-        hipLaunchKernelGGL(lbs_skin_kernel<false>, skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
-                           joints, wk.v_posed);
+        if (small) hipLaunchKernelGGL((lbs_skin_kernel<false, false, LBS_HG_SMALL>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B,
+                                      verts, joints, wk.v_posed);
+        else hipLaunchKernelGGL((lbs_skin_kernel<false, false, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
+                                joints, wk.v_posed);
     }
 }
 
@@ -336,12 +343,21 @@ static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
                        const ihmr_opt_weights& w, const ParamStep& prev, hipStream_t st, int need_cam = 0, bool reuse_v_posed = false,
                        int lists = 0) {
     hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B, true).inside_count);
-    if (reuse_v_posed)
-        hipLaunchKernelGGL((lbs_skin_kernel<true, true>), dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m,
-                           (const float*)wk.lbs.skel, 2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
-    else
-        hipLaunchKernelGGL((lbs_skin_kernel<true, false>), dim3(8, 4 * ((2 * B + 63) / 64)), dim3(LBS_THREADS), 0, st, *m,
-                           (const float*)wk.lbs.skel, 2 * B, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
+    // (small launches: four instead of eight hands per workgroup -- half the chain per thread, see lbs_skin_kernel)
+    const int N2 = 2 * B;
+    const bool small = N2 <= LBS_SMALL_MAX_HANDS;
+    const dim3 skin_grid(8, 4 * ((N2 + 8 * (small ? LBS_HG_SMALL : LBS_HG) - 1) / (8 * (small ? LBS_HG_SMALL : LBS_HG))));
+    if (reuse_v_posed) {
+        if (small) hipLaunchKernelGGL((lbs_skin_kernel<true, true, LBS_HG_SMALL>), skin_grid, dim3(LBS_THREADS), 0, st, *m,
+                                      (const float*)wk.lbs.skel, N2, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
+        else hipLaunchKernelGGL((lbs_skin_kernel<true, true, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m,
+                                (const float*)wk.lbs.skel, N2, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
+    } else {
+        if (small) hipLaunchKernelGGL((lbs_skin_kernel<true, false, LBS_HG_SMALL>), skin_grid, dim3(LBS_THREADS), 0, st, *m,
+                                      (const float*)wk.lbs.skel, N2, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
+        else hipLaunchKernelGGL((lbs_skin_kernel<true, false, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m,
+                                (const float*)wk.lbs.skel, N2, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
+    }
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B, true);
     ws.list_mode = (lists != 0 && !io->sdf_no_candidate_lists) ? 1 : 0;
     ws.force_rebuild = lists == 2 ? 1 : 0;

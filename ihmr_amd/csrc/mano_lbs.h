@@ -22,7 +22,9 @@
 #include "ihmr_common.h"
 
 #define LBS_THREADS 256
-#define LBS_HG 8          // hands per skin / bwd2 workgroup
+#define LBS_HG 8          // hands per skin workgroup (large launches)
+#define LBS_HG_SMALL 4    // ... of launches of up to LBS_SMALL_MAX_HANDS hands
+#define LBS_SMALL_MAX_HANDS 256
 #define LBS_TILE_V 195    // vertices per skin workgroup (4 x 195 = 780 >= 778)
 #define LBS_KG 25         // bwd2: K groups (split-K partial sums, reduced in fixed order by bwd3)
 #define LBS_KC 3          // bwd2: 32-column chunks per K group: 25 x 3 x 32 = 2400 >= 2334 basis columns
@@ -222,41 +224,44 @@ __global__ __launch_bounds__(192) void lbs_skel_kernel(ihmr_mano m, const float*
 
 typedef float lbs_v2f __attribute__((ext_vector_type(2)));
 
-// hand i of group (x, s): x + 8 * (8 s + i) -- all hands of a group share (hand % 8), i.e. the XCD that ran
+// hand i of group (x, s) of HG hands: x + 8 * (HG s + i) -- all hands of a group share (hand % 8), i.e. the XCD that ran
 // their skeleton workgroup and will run their collision / backward workgroups (speed only).
-__device__ __forceinline__ int lbs_group_hand(int x, int s, int i) { return x + 8 * (8 * s + i); }
+template <int HG>
+__device__ __forceinline__ int lbs_group_hand(int x, int s, int i) { return x + 8 * (HG * s + i); }
 
 // ------------------------------------------------------------------------------------- skin
-// grid = (8, 4 vertex tiles x ceil(N/64) groups), block = 256 (195 active lanes = vertices).
+// grid = (8, 4 vertex tiles x ceil(N / (8 HG)) groups), block = 256 (195 active lanes = vertices); HG = hands per workgroup: 8
+// (LBS_HG) for large launches -- the basis rows a workgroup streams from L2 serve eight hands --, 4 for launches of up to
+// LBS_SMALL_MAX_HANDS hands, where the kernel is as long as one thread's chain of FMAs (half as long with half the hands).
 // REUSE: v_posed_ws already holds v_posed of exactly these pose and shape parameters (a refinement stage that updates
 // neither -- translation, global orientation: optimize_model.py:393-407 -- after its first iteration): both blends are
 // skipped and the stored values (the bits a recomputation would give) are skinned with the new joint transforms.  The two
 // blends are 2/3 of the kernel's arithmetic and all of its L2 traffic (1.8 MB of basis rows per 8 hands and vertex tile).
-template <bool TWO_HAND, bool REUSE = false>
+template <bool TWO_HAND, bool REUSE = false, int HG = LBS_HG>
 __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, const float* __restrict__ skel, int N, int B,
                                                                float* __restrict__ verts, float* __restrict__ joints,
                                                                float* __restrict__ v_posed_ws) {
-    __shared__ float4 pfT[136][2];        // [e][hands 0-3 | 4-7]
-    __shared__ float A_s[LBS_HG / 2][192][2];   // skinning matrices, the two hands of a pair interleaved
-    __shared__ float beta_s[10][LBS_HG];  // [l][hand]
-    __shared__ float shift_s[LBS_HG][4];
+    __shared__ float4 pfT[136][HG / 4];   // [e][hands 0-3 | 4-7]
+    __shared__ float A_s[HG / 2][192][2];   // skinning matrices, the two hands of a pair interleaved
+    __shared__ float beta_s[10][HG];  // [l][hand]
+    __shared__ float shift_s[HG][4];
     const int tid = threadIdx.x, gx = blockIdx.x, tile = blockIdx.y % 4, gs = blockIdx.y / 4;
     if (!REUSE)
-        for (int idx = tid; idx < LBS_HG * 136; idx += LBS_THREADS) {
-            const int hh = idx / 136, e = idx % 136, hid = lbs_group_hand(gx, gs, hh);
+        for (int idx = tid; idx < HG * 136; idx += LBS_THREADS) {
+            const int hh = idx / 136, e = idx % 136, hid = lbs_group_hand<HG>(gx, gs, hh);
             const float v = (hid < N && e < NPF) ? skel[(size_t)hid * SK_STRIDE + SK_PF + e] : 0.f;
             reinterpret_cast<float*>(&pfT[e][0])[hh] = v;
         }
-    for (int idx = tid; idx < LBS_HG * 192; idx += LBS_THREADS) {
-        const int hh = idx / 192, e = idx % 192, hid = lbs_group_hand(gx, gs, hh);
+    for (int idx = tid; idx < HG * 192; idx += LBS_THREADS) {
+        const int hh = idx / 192, e = idx % 192, hid = lbs_group_hand<HG>(gx, gs, hh);
         A_s[hh / 2][e][hh % 2] = hid < N ? skel[(size_t)hid * SK_STRIDE + SK_A + e] : 0.f;
     }
-    if (!REUSE && tid < LBS_HG * 10) {
-        const int hh = tid / 10, l = tid % 10, hid = lbs_group_hand(gx, gs, hh);
+    if (!REUSE && tid < HG * 10) {
+        const int hh = tid / 10, l = tid % 10, hid = lbs_group_hand<HG>(gx, gs, hh);
         beta_s[l][hh] = hid < N ? skel[(size_t)hid * SK_STRIDE + SK_BETA + l] : 0.f;
     }
-    if (tid >= 128 && tid < 128 + LBS_HG * 4) {
-        const int hh = (tid - 128) / 4, k = (tid - 128) % 4, hid = lbs_group_hand(gx, gs, hh);
+    if (tid >= 128 && tid < 128 + HG * 4) {
+        const int hh = (tid - 128) / 4, k = (tid - 128) % 4, hid = lbs_group_hand<HG>(gx, gs, hh);
         shift_s[hh][k] = (hid < N && k < 3) ? skel[(size_t)hid * SK_STRIDE + SK_SHIFT + k] : 0.f;
     }
     __syncthreads();
@@ -265,11 +270,11 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
 
     // shape blend: v_shaped = v_template + shapedirs . beta   (8 hands at once, as 4 hand PAIRS: packed fp32 FMAs
     // do two hands per instruction and give the same IEEE results as scalar ones)
-    lbs_v2f vq[LBS_HG / 2][3];
+    lbs_v2f vq[HG / 2][3];
     if (REUSE) {
 #pragma unroll
-        for (int q = 0; q < LBS_HG / 2; ++q) {
-            const int h0 = lbs_group_hand(gx, gs, 2 * q), h1 = lbs_group_hand(gx, gs, 2 * q + 1);
+        for (int q = 0; q < HG / 2; ++q) {
+            const int h0 = lbs_group_hand<HG>(gx, gs, 2 * q), h1 = lbs_group_hand<HG>(gx, gs, 2 * q + 1);
             const float* s0 = v_posed_ws + ((size_t)min(h0, N - 1) * NV + v) * 3;
             const float* s1 = v_posed_ws + ((size_t)min(h1, N - 1) * NV + v) * 3;
             vq[q][0] = lbs_v2f{s0[0], s1[0]}; vq[q][1] = lbs_v2f{s0[1], s1[1]}; vq[q][2] = lbs_v2f{s0[2], s1[2]};
@@ -281,11 +286,11 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
 #pragma unroll
         for (int l = 0; l < 10; ++l) sd[l] = m.sd4[l * NVP + v];
 #pragma unroll
-        for (int q = 0; q < LBS_HG / 2; ++q) { vq[q][0] = lbs_v2f{t.x, t.x}; vq[q][1] = lbs_v2f{t.y, t.y}; vq[q][2] = lbs_v2f{t.z, t.z}; }
+        for (int q = 0; q < HG / 2; ++q) { vq[q][0] = lbs_v2f{t.x, t.x}; vq[q][1] = lbs_v2f{t.y, t.y}; vq[q][2] = lbs_v2f{t.z, t.z}; }
 #pragma unroll
         for (int l = 0; l < 10; ++l) {
 #pragma unroll
-            for (int q = 0; q < LBS_HG / 2; ++q) {
+            for (int q = 0; q < HG / 2; ++q) {
                 const lbs_v2f bl = *reinterpret_cast<const lbs_v2f*>(&beta_s[l][2 * q]);
                 vq[q][0] = __builtin_elementwise_fma(lbs_v2f{sd[l].x, sd[l].x}, bl, vq[q][0]);
                 vq[q][1] = __builtin_elementwise_fma(lbs_v2f{sd[l].y, sd[l].y}, bl, vq[q][1]);
@@ -312,10 +317,14 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
         auto consume = [&](const Row* p, int e0) {
 #pragma unroll
             for (int u = 0; u < 9; ++u) {
-                const float4 f0 = pfT[e0 + u][0], f1 = pfT[e0 + u][1];
-                const lbs_v2f f[LBS_HG / 2] = {lbs_v2f{f0.x, f0.y}, lbs_v2f{f0.z, f0.w}, lbs_v2f{f1.x, f1.y}, lbs_v2f{f1.z, f1.w}};
+                lbs_v2f f[HG / 2];
 #pragma unroll
-                for (int q = 0; q < LBS_HG / 2; ++q) {
+                for (int q4 = 0; q4 < HG / 4; ++q4) {
+                    const float4 fq = pfT[e0 + u][q4];
+                    f[2 * q4] = lbs_v2f{fq.x, fq.y}; f[2 * q4 + 1] = lbs_v2f{fq.z, fq.w};
+                }
+#pragma unroll
+                for (int q = 0; q < HG / 2; ++q) {
                     vq[q][0] = __builtin_elementwise_fma(f[q], __builtin_shufflevector(p[u].xy, p[u].xy, 0, 0), vq[q][0]);
                     vq[q][1] = __builtin_elementwise_fma(f[q], __builtin_shufflevector(p[u].xy, p[u].xy, 1, 1), vq[q][1]);
                     vq[q][2] = __builtin_elementwise_fma(f[q], __builtin_shufflevector(p[u].zw, p[u].zw, 0, 0), vq[q][2]);
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
     // skinning, one hand pair at a time: T = sum_j w_j A_j over all 16 joints without branches (a zero weight adds an
     // exact zero), the pair's matrices read from LDS as broadcast 16-byte rows, packed FMAs
 #pragma unroll
-    for (int q = 0; q < LBS_HG / 2; ++q) {
+    for (int q = 0; q < HG / 2; ++q) {
         lbs_v2f T[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = lbs_v2f{0.f, 0.f};
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
         for (int r = 0; r < 3; ++r) o2[r] = T[4 * r + 0] * vq[q][0] + T[4 * r + 1] * vq[q][1] + T[4 * r + 2] * vq[q][2] + T[4 * r + 3];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int hh = 2 * q + i, h = lbs_group_hand(gx, gs, hh);
+            const int hh = 2 * q + i, h = lbs_group_hand<HG>(gx, gs, hh);
             if (h >= N) continue;
             float out[3] = {i ? o2[0].y : o2[0].x, i ? o2[1].y : o2[1].x, i ? o2[2].y : o2[2].x};
             if (!REUSE) {
