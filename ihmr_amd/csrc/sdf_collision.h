@@ -31,7 +31,7 @@
 // chain per thread -- the form for small launches, where the kernel is as long as one workgroup (one batch of 64: 29.0 -> 22.1 us).
 #define SDF_PREP_THREADS_LARGE 512
 #define SDF_PREP_THREADS_SMALL 1024
-#define SDF_PREP_SMALL_MAX_HANDS 256     // up to this many hands per launch the 1024-thread form is used
+#define SDF_PREP_SMALL_MAX_HANDS 128     // up to this many hands per launch (one batch of 64) the 1024-thread form is used; at 256 hands (IHMR-MLP, batch 128) the 512-thread form is 11 % faster end to end
 #define SDF_NCOL (SDF_G * SDF_G)   // 1024 columns (k,j)
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
 #ifndef SDF_DIST_BLOCKS
