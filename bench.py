@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 vector == FP32 (f32-input) MFMA dense peak
-TIMED_REPEAT = 8          # IHMR_TIMED_REPEAT of csrc/ihmr_hip.hip: launches of sdf_dist_kernel per event bracket of a timed pass
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 
 
 def make_opt(B, epoch, freq, rank):
@@ -63,7 +63,7 @@ def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=32, iters_per_stage=8):
     sub = {k: v[:n_samples].clone() for k, v in batch_cpu.items()}
     n_fwd = 4 * iters_per_stage + 1           # + final forward (no backward; counted as a full iteration: conservative)
     full_iters = 4 * (epoch_full + 1) + 1
-    runs = {}
+    runs, oracle_out = {}, None
     for threads in sorted({min(32, cores), cores}):
         torch.set_num_threads(threads)
         # every core: 256 torch threads on 2.3 KB tensors spend their time in fork / join (~10 s per iteration measured on a
@@ -77,6 +77,9 @@ def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=32, iters_per_stage=8):
         t0 = time.perf_counter()
         orc.optimize()
         t_total = time.perf_counter() - t0
+        if not short:
+            oracle_out = dict(result=orc.get_pred_result(), selected=[np.asarray(x).copy() for x in orc.selected], n_samples=n_samples,
+                              iters_per_stage=iters_per_stage)
         runs[threads] = dict(seconds=t_total, forward_backward_evaluations=evals, images_per_s=n_samples / (t_total / evals * full_iters),
                              ms_per_refine_iter=1000.0 * t_total / evals)
     best = max(runs, key=lambda k: runs[k]["images_per_s"])
@@ -84,31 +87,103 @@ def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=32, iters_per_stage=8):
                 torch_threads=best, by_torch_threads={str(k): v for k, v in runs.items()},
                 sample=f"{n_samples} samples x {4 * iters_per_stage} refine iterations (+1 forward) measured in {runs[best]['seconds']:.1f}s, "
                        f"extrapolated linearly to {full_iters - 1} iterations",
-                ms_per_refine_iter=runs[best]["ms_per_refine_iter"])
+                ms_per_refine_iter=runs[best]["ms_per_refine_iter"]), oracle_out
 
 
-def pmc_traffic(kernel, batches_per_launch):
-    """HBM bytes per launch of ``kernel`` from the newest committed rocprofv3 PMC summary taken at THIS launch size
-    (``profiles/r<round>_v<n>_f<batches per launch>_pmc_traffic.csv``, produced by ``FUSE=<g> scripts/profile_round.sh`` = two
-    separate ``--pmc`` passes of this very command at ``--streams 1``, FETCH_SIZE doubled per the gfx950 correction).  Counters
-    cannot be read from inside the process, so this is the profile's figure; None when no profile of that launch size exists."""
-    import csv, glob, re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                          f"r[0-9]*_v[0-9]*_f{batches_per_launch}_pmc_traffic.csv")),
-                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))[:2]])
-    if not files:
-        return None, None
-    with open(files[-1], newline="") as fh:
-        rows = [r for r in csv.DictReader(fh) if r["kernel"].startswith(kernel)]
+def parity_vs_oracle(batch_cpu, oracle_out, rank):
+    """The HIP path on exactly the sample the `cpu_baseline` leg pushed through the oracle (same `n_samples` samples, same
+    4 x `iters_per_stage` refinement iterations, a snapshot per iteration) -> worst differences, so that the line carries an
+    oracle value beside every parity number (BASELINE.json: MPJPE / penetration depth within 1e-4)."""
+    from ihmr_amd.optimize_model import OptimizeModel
+    n, it = oracle_out["n_samples"], oracle_out["iters_per_stage"]
+    m = OptimizeModel(make_opt(n, it - 1, 1, rank))
+    m.set_input({k: v[:n].cuda() for k, v in batch_cpu.items()})
+    m.init_optimize()
+    m.optimize()
+    torch.cuda.synchronize()
+    got, ref = m.get_pred_result(), oracle_out["result"]
+    sel = [x.cpu().numpy() for x in m.selected_history]
+    agree = float(np.mean([np.mean(a == b) for a, b in zip(sel, oracle_out["selected"])]))
+    err = lambda k: float(np.abs(got[k].astype(np.float64) - ref[k].astype(np.float64)).max())
+    verts = max(err("pred_right_hand_verts"), err("pred_left_hand_verts"))
+    pen_h, pen_o = float(np.mean(got["collision_loss_origin_scale"])), float(np.mean(ref["collision_loss_origin_scale"]))
+    # MPJPE of both sides against the synthetic annotation, the reference's metric (root-aligned joints are what both export)
+    mp = lambda r: float(np.mean(np.linalg.norm(r["pred_joints_3d"] - r["gt_joints_3d"][..., :3], axis=-1)))
+    return dict(sample=f"{n} samples x {4 * it} refine iterations (+ final forward), snapshot every iteration: the cpu_baseline sample",
+                max_abs_joint_m=err("pred_joints_3d"), max_abs_vertex_m=verts, max_abs_pen_depth_m=err("collision_loss_origin_scale"),
+                selection_agreement=agree, mean_penetration_depth_m=dict(hip=pen_h, oracle=pen_o, abs_diff=abs(pen_h - pen_o)),
+                mpjpe_m=dict(hip=mp(got), oracle=mp(ref), abs_diff=abs(mp(got) - mp(ref))), tolerance_m=1e-4,
+                within_tolerance=bool(err("pred_joints_3d") < 1e-4 and verts < 1e-4 and err("collision_loss_origin_scale") < 1e-4 and agree == 1.0))
+
+
+def committed_profile(batches_per_launch=None, tag=None):
+    """Newest committed profile set of THIS code: `profiles/<name>_meta.json` (written by scripts/profile_round.sh and its
+    siblings) records the source hash of the library that was profiled; a set is used only when that hash equals the hash of
+    the library this process loads (ihmr_amd/libihmr_hip.srchash) -- a profile of older code is never quoted.
+    Returns (prefix, meta) or (None, None)."""
+    import glob
+    from ihmr_amd import hip
+    cur = hip.loaded_source_hash()
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_meta.json")):
+        try:
+            with open(f) as fh:
+                meta = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if cur is None or meta.get("srchash") != cur:
+            continue
+        if batches_per_launch is not None and meta.get("batches_per_launch") != batches_per_launch:
+            continue
+        if tag is not None and meta.get("config") != tag:
+            continue
+        if best is None or meta.get("unix_time", 0) > best[1].get("unix_time", 0):
+            best = (f[:-len("_meta.json")], meta)
+    return best if best else (None, None)
+
+
+def profile_rows(prefix, suffix, kernel):
+    """Rows of `<prefix>_<suffix>.csv` whose kernel name starts with `kernel`, most-launched shape first."""
+    import csv
+    try:
+        with open(f"{prefix}_{suffix}.csv", newline="") as fh:
+            rows = [r for r in csv.DictReader(fh) if r["kernel"].startswith(kernel)]
+    except OSError:
+        return []
+    key = "launches" if rows and "launches" in rows[0] else "calls"
+    return sorted(rows, key=lambda r: -int(r[key]))
+
+
+def pmc_traffic(kernel, batches_per_launch, tag="opt"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of the SAME code at THIS launch size (two separate
+    `--pmc` passes, FETCH_SIZE doubled per the gfx950 correction; scripts/profile_round.sh).  Counters cannot be read from inside
+    the process, so this is the profile's figure; (None, None, None) when no profile of the loaded library exists."""
+    prefix, meta = committed_profile(batches_per_launch, tag)
+    if prefix is None:
+        return None, None, None
+    rows = profile_rows(prefix, "pmc_traffic", kernel)
     if not rows:
+        return None, None, None
+    kt = profile_rows(prefix, "kernel_stats", kernel)
+    return float(rows[0]["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(prefix) + "_pmc_traffic.csv", (float(kt[0]["avg_us"]) if kt else None)
+
+
+def encoder_traffic():
+    """HBM bytes of ONE encoder forward (64 images) from the committed PMC profile of `bench.py --config baseline` of the loaded
+    library: sum over the convolution kernels' rows of bytes x launches, divided by the number of forwards in the profiled run
+    (= launches of the stem, the only layer on the generic-gather variant).  (None, None) without such a profile."""
+    prefix, meta = committed_profile(None, "baseline")
+    if prefix is None:
         return None, None
-    # one row per launch shape: the shape launched most often is the profiled size (the others: a one-batch instance's first pass)
-    r = max(rows, key=lambda r: int(r["launches"]))
-    return float(r["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(files[-1])
+    rows = profile_rows(prefix, "pmc_traffic", "conv_")
+    stem = [r for r in rows if r["kernel"].startswith("conv_igemm_kernel") and "false>" in r["kernel"]]
+    if not rows or not stem:
+        return None, None
+    fwd = sum(int(r["launches"]) for r in stem)
+    return sum(float(r["hbm_bytes_per_launch"]) * int(r["launches"]) for r in rows) / fwd, "profiles/" + os.path.basename(prefix) + "_pmc_traffic.csv"
 
 
-
-def secondary(config):
+def secondary(config, with_cpu=True):
     """BASELINE.json configs[1] / configs[2] (parity-test cases, NOT the driver's metric): IHMR-Baseline batch 64 and
     IHMR-MLP batch 128 inference on one MI355X with the CPU oracle timed beside them on a bounded sample (BASELINE.md
     section 3: "reported per config").  Returned as a dict: the default run attaches both to its line under
@@ -173,6 +248,21 @@ def secondary(config):
         torch.cuda.synchronize()
         dt2 = timeit(step2, 12, 3) / 2
         del m2
+        enc_traffic, enc_traffic_src = encoder_traffic()
+        out = dict(metric="images/sec, IHMR-Baseline (ResNet-50 + MANO regress) batch=64 inference", value=B / dt, unit="images/s", n_gpus=1,
+                   ms_per_step=dt * 1e3, dtype="f32", data="synthetic", higher_is_better=True,
+                   config=dict(workload="BASELINE.json configs[1]: InterHandModel.test() + get_pred_result(), batch 64, 224x224"),
+                   two_batches_in_flight=dict(images_per_s=B / dt2, ms_per_batch=dt2 * 1e3, note="two model instances on two HIP streams"),
+                   roofline=dict(bound="mfma", kernel="conv_igemm_kernel (whole encoder)", achieved=8.2e9 * B / enc_dt / 1e12,
+                                 peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=8.2e9 * B / enc_dt / 1e12 / FP32_PEAK_TFLOPS,
+                                 traffic=enc_traffic, traffic_unit="bytes per encoder forward (64 images)", traffic_source=enc_traffic_src,
+                                 hbm=dict(achieved=(enc_traffic / enc_dt / 1e9) if enc_traffic else None, peak=HBM_PEAK_GBS, unit="GB/s",
+                                          frac=(enc_traffic / enc_dt / 1e9 / HBM_PEAK_GBS) if enc_traffic else None,
+                                          note="counter bytes of the profile / this run's encoder time"),
+                                 encoder_ms_per_batch=enc_dt * 1e3),
+                   cpu_baseline=None)
+        if not with_cpu:
+            return out
         # CPU oracle on the first Bc images: encoder + two MANO evaluations (prediction, annotation) + the collision metric
         right, left = synthetic_mano(True), synthetic_mano(False)
         ref = InterHandEncoderRef(m.mean_params[:Bc].clone()); ref.load_state_dict({k: v.cpu() for k, v in m.encoder.state_dict().items()}); ref.eval()
@@ -192,15 +282,8 @@ def secondary(config):
             sdf(torch.stack([rv, lv], 1), return_per_vert_loss=True, return_origin_scale_loss=True)
             two(cpu_batch["mano_pose"][:Bc], cpu_batch["mano_betas"][:Bc], cpu_batch["hand_trans"][:Bc, 0, :3])
         tc = time.perf_counter() - t0
-        out = dict(metric="images/sec, IHMR-Baseline (ResNet-50 + MANO regress) batch=64 inference", value=B / dt, unit="images/s", n_gpus=1,
-                   ms_per_step=dt * 1e3, dtype="f32", data="synthetic", higher_is_better=True,
-                   config=dict(workload="BASELINE.json configs[1]: InterHandModel.test() + get_pred_result(), batch 64, 224x224"),
-                   two_batches_in_flight=dict(images_per_s=B / dt2, ms_per_batch=dt2 * 1e3, note="two model instances on two HIP streams"),
-                   roofline=dict(bound="mfma", kernel="conv_igemm_kernel (whole encoder)", achieved=8.2e9 * B / enc_dt / 1e12,
-                                 peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=8.2e9 * B / enc_dt / 1e12 / FP32_PEAK_TFLOPS, traffic=None,
-                                 encoder_ms_per_batch=enc_dt * 1e3),
-                   cpu_baseline=dict(value=Bc / tc, unit="images/s", cores=cores, kind="port",
-                                     sample=f"{Bc} images through the oracle (encoder + 2 x two-hand MANO + dense voxel SDF) in {tc:.1f}s"))
+        out["cpu_baseline"] = dict(value=Bc / tc, unit="images/s", cores=cores, kind="port",
+                                   sample=f"{Bc} images through the oracle (encoder + 2 x two-hand MANO + dense voxel SDF) in {tc:.1f}s")
     else:
         from ihmr_amd.mlp_model import MLPModel
         from oracle.mlp_ref import MLPRef
@@ -222,17 +305,80 @@ def secondary(config):
             m.set_input(batch); m.test(); pend.append(m.get_pred_result_async())
             if len(pend) > 1:
                 pend.pop(0).wait()
-        dt = timeit(step, 20, 3)
+        runs = [timeit(step, 20, 3) for _ in range(5)]            # spread over five runs of 20 batches
+        dt = float(np.median(runs))
+        # GPU time of test() alone (events on its stream, nothing else in flight) beside the wall time per batch
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        m.set_input(batch); torch.cuda.synchronize()
+        gpu = []
+        for _ in range(10):
+            ev[0].record(); m.test(); ev[1].record(); torch.cuda.synchronize()
+            gpu.append(ev[0].elapsed_time(ev[1]))
+        gpu_ms = float(np.median(gpu))
+        # two batches in flight: a second instance on a second stream (as the Baseline config does)
+        m2 = MLPModel(opt(B)); m2.set_update_info(strat, B)
+        for i in range(len(strat)):
+            m2.add_new_network(i); m2.sub_network_list[i].load_state_dict(m.sub_network_list[i].state_dict())
+        m2.eval()
+        st2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+        pend2 = []
+        def step2():
+            hs = []
+            for mm, st in ((m, st2[0]), (m2, st2[1])):
+                with torch.cuda.stream(st):
+                    mm.set_input(batch); mm.test(); hs.append(mm.get_pred_result_async())
+            while pend2:
+                pend2.pop(0).wait()
+            pend2.extend(hs)
+        torch.cuda.synchronize()
+        runs2 = [timeit(step2, 12, 3) / 2 for _ in range(5)]
+        dt2 = float(np.median(runs2))
+        del m2
+        # dominant kernel of the config (largest share of GPU time in the committed profile: sdf_dist_kernel at 256 hands, the
+        # full search -- a single-shot caller has no candidate lists): HIP-event time of its in-loop launches in a graph-less pass,
+        # work from its own counters in a second pass
+        import ctypes as C
+        from ihmr_amd import hip
+        timer = hip.KernelTimer(0.0, 0, 0.0, 0.0, 0)
+        core_graphs = m._core.use_graphs
+        m._core.use_graphs = False
+        hip.lib().ihmr_set_kernel_timer(C.byref(timer))
+        m.set_input(batch); m._test_eager(); torch.cuda.synchronize()
+        hip.lib().ihmr_flush_kernel_timer(); hip.lib().ihmr_set_kernel_timer(None)
+        m._core.sdf_counters_start(); m.set_input(batch); m._test_eager(); cnt = m._core.sdf_counters_stop()
+        m._core.use_graphs = core_graphs
+        nl = max(int(timer.n_sdf_eval), 1)
+        k_ms = (timer.ms_sdf_eval - timer.ms_event_pair) / nl
+        flops = (11.0 * cnt["sphere_tests"] + 75.0 * cnt["dist_evals"]) / nl
+        abytes = 2.0 * B * 1538 * (16 + 36) + cnt["inside_voxels"] / nl * 8
+        traffic, tsrc, prof_us = pmc_traffic("sdf_dist_kernel", None, "mlp")
+        ach, bw = flops / (k_ms * 1e-3) / 1e12, abytes / (k_ms * 1e-3) / 1e9
+        hbm_binds = bw / HBM_PEAK_GBS > ach / FP32_PEAK_TFLOPS
+        out = dict(metric="images/sec, IHMR-MLP refinement head batch=128 inference", value=B / dt, unit="images/s", n_gpus=1, ms_per_step=dt * 1e3,
+                   dtype="f32", data="synthetic", higher_is_better=True,
+                   config=dict(workload="BASELINE.json configs[2]: MLPModel.test() (6 stages: 8 MANO + SDF evaluations, 6 MLPs) + export, batch 128; "
+                                        "test() replayed as one captured hipGraph per instance"),
+                   runs_images_per_s=[B / r for r in runs], spread_images_per_s=[B / max(runs), B / min(runs)],
+                   gpu_ms_per_batch=gpu_ms, wall_ms_per_batch=dt * 1e3,
+                   two_batches_in_flight=dict(images_per_s=B / dt2, ms_per_batch=dt2 * 1e3, runs_images_per_s=[B / r for r in runs2],
+                                              note="two model instances on two HIP streams"),
+                   roofline=dict(bound="hbm" if hbm_binds else "valu", kernel="sdf_dist_kernel (full search, 256 hands per launch)",
+                                 achieved=bw if hbm_binds else ach, peak=HBM_PEAK_GBS if hbm_binds else FP32_PEAK_TFLOPS,
+                                 unit="GB/s" if hbm_binds else "TFLOP/s", frac=(bw / HBM_PEAK_GBS) if hbm_binds else (ach / FP32_PEAK_TFLOPS),
+                                 valu=dict(achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS),
+                                 hbm=dict(achieved=bw, peak=HBM_PEAK_GBS, unit="GB/s", frac=bw / HBM_PEAK_GBS),
+                                 avg_launch_ms=k_ms, launches_per_batch=nl, kernel_ms_per_batch=k_ms * nl, share_of_gpu_time=k_ms * nl / gpu_ms,
+                                 algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=abytes,
+                                 traffic=traffic, traffic_unit="bytes/launch", traffic_source=tsrc, profile_avg_launch_us=prof_us),
+                   cpu_baseline=None)
+        if not with_cpu:
+            return out
         orc.set_input({k: v[:Bc].clone() for k, v in b.items()})
         t0 = time.perf_counter()
         orc.test()
         tc = time.perf_counter() - t0
-        out = dict(metric="images/sec, IHMR-MLP refinement head batch=128 inference", value=B / dt, unit="images/s", n_gpus=1, ms_per_step=dt * 1e3,
-                   dtype="f32", data="synthetic", higher_is_better=True,
-                   config=dict(workload="BASELINE.json configs[2]: MLPModel.test() (6 stages: 8 MANO + SDF evaluations, 6 MLPs) + export, batch 128"),
-                   roofline=None,
-                   cpu_baseline=dict(value=Bc / tc, unit="images/s", cores=cores, kind="port",
-                                     sample=f"{Bc} samples through the oracle's MLPRef.test() in {tc:.1f}s"))
+        out["cpu_baseline"] = dict(value=Bc / tc, unit="images/s", cores=cores, kind="port",
+                                   sample=f"{Bc} samples through the oracle's MLPRef.test() in {tc:.1f}s")
     out["cpu_baseline"]["cpu_model"] = cpu_model_string()
     out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     return out
@@ -258,18 +404,21 @@ def main():
                          "identical to separate batches); batches in flight = streams x fuse")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent launch sequences in flight per GPU (each step is still one full pass over one batch of --batch samples)")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="under torch.distributed.run: run the package's collectives (metric all-reduce, MAX, all-gather, bucketed gradient "
+                         "all-reduce) on device tensors through the process group's backend and report the checks in the line")
     ap.add_argument("--config", type=str, default="opt", choices=["opt", "baseline", "mlp"],
                     help="opt = the driver's bench line (IHMR-OPT); baseline / mlp = one of the secondary BASELINE.json configs alone")
     args = ap.parse_args()
     if args.config != "opt":
         assert torch.cuda.is_available(), "bench.py needs an MI355X: the hot path has no CPU fallback"
-        print(json.dumps(secondary(args.config)))
+        print(json.dumps(secondary(args.config, with_cpu=not args.no_cpu_baseline)))
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or ("TORCHELASTIC_RUN_ID" in os.environ and "RANK" in os.environ):   # (one rank under torchrun: RCCL with a 1-rank group)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local_rank %= max(torch.cuda.device_count(), 1)     # one rank per GPU on the driver's node; ranks may share a GPU in the
@@ -412,17 +561,17 @@ def main():
 
     # ---- dominant kernel (sdf_dist_kernel): HIP events on the launch stream in separate single-stream, graph-less passes of
     #      the same workload, one per launch size the timed region actually ran (with several sequences in flight the kernels
-    #      share the GPU and a per-launch time is meaningless); algorithmic work from the kernels' own counters
+    #      share the GPU and a per-launch time is meaningless); work and algorithmic bytes from the kernels' own counters
     roofline = None
     if rank == 0:
         sizes_run = {}
         for q in plan(args.steps):
             for g in q:
                 sizes_run[g] = sizes_run.get(g, 0) + 1
-        per_size, tot_flops, tot_ms, tot_full = [], 0.0, 0.0, 0.0
+        per_size, tot_flops, tot_ms, tot_full, tot_bytes = [], 0.0, 0.0, 0.0, 0.0
         for g in sorted(sizes_run):
             mdl = instance(0, g)
-            timer = hip.KernelTimer(0.0, 0, 0.0, 0.0)
+            timer = hip.KernelTimer(0.0, 0, 0.0, 0.0, 0)
             hip.lib().ihmr_set_kernel_timer(C.byref(timer))
             graphs = mdl.use_graphs
             mdl.use_graphs = False   # event records cannot sit inside a captured graph
@@ -432,58 +581,79 @@ def main():
             hip.lib().ihmr_set_kernel_timer(None)
             # work EXECUTED per launch, from the kernels' own counters (DESIGN.md "Measurement"): the same refinement once more,
             # untimed (the counters are global atomics), one sdf_prep_kernel + one sdf_dist_kernel launch per iteration
-            stats, flops = None, None
+            stats, flops, abytes = None, None, None
+            n_launch = max(int(timer.n_sdf_eval), 1)
             if not args.no_work_counters:
                 mdl.set_input(inputs[g]); mdl.init_optimize()
                 mdl.sdf_counters_start()
                 mdl.optimize(0, 1)
                 cnt = mdl.sdf_counters_stop()
-                n_launch = n_iter = max(int(timer.n_sdf_eval) // TIMED_REPEAT, 1)
                 stats = dict(sphere_tests=cnt["sphere_tests"] / n_launch, dist_evals=cnt["dist_evals"] / n_launch,
                              voxels_from_lists=cnt["voxels_from_lists"] / n_launch,
                              voxels_full_search=(cnt["voxels_without_list"] + cnt["voxels_rebuilt"]) / n_launch,
-                             inside_voxels=cnt["inside_voxels"] / n_iter, needed_voxels=cnt["needed_voxels"] / n_iter,
-                             ray_tests=cnt["ray_tests"] / n_iter)
+                             inside_voxels=cnt["inside_voxels"] / n_launch, needed_voxels=cnt["needed_voxels"] / n_launch,
+                             ray_tests=cnt["ray_tests"] / n_launch)
                 # flops of ONE launch: 11 per bounding-sphere test (|p - centroid|^2: 8, cull test: 3) and 75 per exact
                 # point-triangle distance -- what the kernel executed; a full search of every inside voxel (the kernel without its
                 # candidate lists, round 1's model) would execute 1538 sphere tests per inside voxel
                 flops = 11.0 * stats["sphere_tests"] + 75.0 * stats["dist_evals"]
+                # algorithmic bytes of ONE launch: every hand's table once (sphere records 16 B + the three
+                # corners 36 B per triangle, 1538 triangles) + per inside voxel its work-list entry, map word, candidate list
+                # (384 B) and the result
+                abytes = 2.0 * g * B * 1538 * (16 + 36) + stats["inside_voxels"] * (4 + 4 + 384 + 4)
             mdl.use_graphs = graphs
-            # launch duration = event-bracketed time minus the cost of an (empty) event pair recorded right before it
-            avg_ms = (timer.ms_sdf_eval - timer.ms_event_pair) / max(timer.n_sdf_eval, 1)
+            # launch duration = event-bracketed time of the in-loop launch minus the cost of an (empty) event pair recorded right
+            # before it; the 7 warm repeats that follow each timed launch are reported beside it (they start from the
+            # first launch's nearest-triangle hints with the tables in L2, i.e. they are biased low)
+            avg_ms = (timer.ms_sdf_eval - timer.ms_event_pair) / n_launch
+            rep_ms = timer.ms_sdf_repeat / max(int(timer.n_sdf_repeat), 1)
             ach = flops / (avg_ms * 1e-3) / 1e12 if (avg_ms > 0 and flops) else None
             per_size.append(dict(batches_per_launch=g, launch_sequences_in_timed_region=sizes_run[g], avg_launch_ms=avg_ms,
-                                 avg_event_bracket_ms=timer.ms_sdf_eval / max(timer.n_sdf_eval, 1), launches_timed=int(timer.n_sdf_eval),
-                                 algorithmic_flops_per_launch=flops, work_per_launch=stats, achieved=ach,
+                                 warm_repeat_launch_ms=rep_ms, launches_timed=int(timer.n_sdf_eval),
+                                 algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=abytes, work_per_launch=stats, achieved=ach,
                                  full_search_flops_per_launch=(1538 * 11.0 * stats["inside_voxels"] + 75.0 * stats["dist_evals"]) if stats else None,
-                                 frac=(ach / FP32_PEAK_TFLOPS) if ach else None,
-                                 brute_force_equivalent_tflops=stats["inside_voxels"] * 1538 * 100.0 / (avg_ms * 1e-3) / 1e12 if (avg_ms > 0 and stats) else None))
+                                 frac=(ach / FP32_PEAK_TFLOPS) if ach else None))
             if avg_ms > 0 and flops:
                 tot_flops += flops * sizes_run[g]
                 tot_ms += avg_ms * sizes_run[g]
+                tot_bytes += abytes * sizes_run[g]
                 tot_full += (1538 * 11.0 * stats["inside_voxels"] + 75.0 * stats["dist_evals"]) * sizes_run[g]
-        # HBM traffic: the committed PMC summary of the launch size that carried most of the timed region's work
+        # HBM traffic: the committed PMC summary of THIS code (source hash checked) at the launch size that carried most of the
+        # timed region's work
         g_main = max(sizes_run, key=lambda g: g * sizes_run[g])
-        traffic, traffic_src = pmc_traffic("sdf_dist_kernel", g_main) if (B == 64 and args.epoch == 49) else (None, None)
+        traffic, traffic_src, prof_us = pmc_traffic("sdf_dist_kernel", g_main) if (B == 64 and args.epoch == 49) else (None, None, None)
+        main_ms = next((p["avg_launch_ms"] for p in per_size if p["batches_per_launch"] == g_main), None)
         ach = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None
         ach_full = tot_full / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 and tot_full > 0 else None
-        roofline = dict(bound="valu", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=(ach / FP32_PEAK_TFLOPS) if ach else None,
+        ach_bw = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 and tot_bytes > 0 else None
+        ctr_bw = traffic / (main_ms * 1e-3) / 1e9 if (traffic and main_ms) else None
+        frac_valu = (ach / FP32_PEAK_TFLOPS) if ach else None
+        frac_hbm = (ach_bw / HBM_PEAK_GBS) if ach_bw else None
+        # both roofs, the binding one (the larger fraction of its peak) is the headline
+        hbm_binds = frac_hbm is not None and (frac_valu is None or frac_hbm > frac_valu)
+        roofline = dict(bound="hbm" if hbm_binds else "valu",
+                        achieved=ach_bw if hbm_binds else ach, peak=HBM_PEAK_GBS if hbm_binds else FP32_PEAK_TFLOPS,
+                        unit="GB/s" if hbm_binds else "TFLOP/s", frac=frac_hbm if hbm_binds else frac_valu,
+                        valu=dict(achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=frac_valu),
+                        hbm=dict(achieved=ach_bw, peak=HBM_PEAK_GBS, unit="GB/s", frac=frac_hbm,
+                                 counter_traffic_rate=ctr_bw, counter_traffic_frac=(ctr_bw / HBM_PEAK_GBS) if ctr_bw else None,
+                                 note="achieved = ALGORITHMIC bytes (every hand's triangle table once + per inside voxel its list and "
+                                      "result) / launch time; counter_traffic_rate = the PMC bytes of the profile / this run's launch time"),
                         traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
-                        traffic_batches_per_launch=g_main,
-                        traffic_note="HBM bytes per launch from the committed rocprofv3 PMC summary of this command at --streams 1 and "
-                                     "the same launch size (counters cannot be read from inside the process), not of this run",
+                        traffic_batches_per_launch=g_main, profile_avg_launch_us=prof_us,
+                        traffic_note="HBM bytes per launch from the committed rocprofv3 PMC summary of this command at --streams 1, the same "
+                                     "launch size and the SAME library source hash (counters cannot be read from inside the process); null "
+                                     "when no profile of the loaded library is committed",
                         kernel="sdf_dist_kernel", by_launch_size=per_size,
                         full_search_equivalent=dict(achieved=ach_full, frac=(ach_full / FP32_PEAK_TFLOPS) if ach_full else None,
                                                     note="the same launches priced with the work of searching all 1538 triangles for every "
                                                          "inside voxel (the kernel without its candidate lists; rounds 1 and early 2 were "
                                                          "priced this way): comparable across rounds, not what the kernel executes"),
                         note="largest share of GPU time in the rocprofv3 kernel summary (profiles/).  Pure fp32 VALU kernel (compares, "
-                             "selects, FMAs; no GEMM shape): priced against the 157.3 TFLOP/s fp32 vector peak.  `achieved` = "
-                             "flops the kernel executed (its own counters: 11 per bounding-sphere test, 75 per exact point-triangle "
-                             "distance) / HIP-event launch time, aggregated over the launch sizes the timed region ran "
-                             "(by_launch_size), each timed in a single-stream pass.  The candidate lists remove work (see "
-                             "full_search_flops_per_launch for the same voxels without them), so this fraction is not comparable "
-                             "with round 1's; compare launch times (by_launch_size[].avg_launch_ms)")
+                             "selects, FMAs; no GEMM shape): priced against the 157.3 TFLOP/s fp32 vector peak AND against HBM.  "
+                             "valu.achieved = flops the kernel executed (its own counters: 11 per bounding-sphere test, 75 per exact "
+                             "point-triangle distance) / HIP-event time of the in-loop launch, aggregated over the launch sizes the "
+                             "timed region ran (by_launch_size), each timed in a single-stream pass")
 
     # ---- single-batch latency: ONE batch of --batch samples, one stream, nothing else in flight.
     #      ms/refine-iter = stage-loop wall time / iterations (excludes set_input and the export); images/s = batch /
@@ -573,14 +743,36 @@ def main():
         del big2
         del big, big_in
 
-    cpu = None
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(batch_cpu, args.epoch, freq)
+        cpu, oracle_out = cpu_baseline(batch_cpu, args.epoch, freq)
+        parity = parity_vs_oracle(batch_cpu, oracle_out, -1)
     second = None
     if extras and not args.no_cpu_baseline:
         del pool, model
         torch.cuda.empty_cache()
         second = dict(baseline=secondary("baseline"), mlp=secondary("mlp"))
+
+    selftest = None
+    if dist is not None and args.rccl_selftest:
+        from ihmr_amd import dist as D
+        dev = torch.device("cuda", torch.cuda.current_device())
+        v = np.arange(9, dtype=np.float64) + rank
+        tot = D.reduce_metrics(v)                           # float64 9-vector, summed on a device tensor
+        exp = sum(np.arange(9, dtype=np.float64) + r for r in range(world))
+        mx = torch.tensor([float(rank)], device=dev, dtype=torch.float64)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        parts = [torch.zeros(4, device=dev) for _ in range(world)]
+        dist.all_gather(parts, torch.full((4,), float(rank), device=dev))
+        flat = torch.ones(1 << 20, device=dev) * (rank + 1)
+        red = D.OverlappedGradientReducer(flat, [(1 << 19, 1 << 20), (0, 1 << 19)], bucket_bytes=1 << 20)
+        red.ready(0); red.ready(1)
+        f = red.finish()
+        torch.cuda.synchronize()
+        selftest = dict(backend=dist.get_backend(), world=world, all_reduce_sum_f64_ok=bool(np.array_equal(tot, exp)),
+                        all_reduce_max_ok=bool(float(mx.item()) == world - 1),
+                        all_gather_ok=bool(all(float(p[0].item()) == i for i, p in enumerate(parts))),
+                        gradient_bucket_ok=bool(torch.all(flat == world * (world + 1) / 2).item() and abs(f - 1.0 / world) < 1e-12))
 
     if rank == 0:
         amortised = ms_per_step / (n_iters + 1)
@@ -604,8 +796,10 @@ def main():
                                  achieved=78e3 * B * world / (amortised * 1e-3) / 1e9, peak=6300.0, unit="GB/s",
                                  frac=78e3 * B * world / (amortised * 1e-3) / 1e9 / (6300.0 * world),
                                  note="whole-iteration rate at the bench's concurrency: the part is latency-, not bandwidth-bound"),
-            parity=dict(mean_penetration_depth_m=float(np.mean(res["collision_loss_origin_scale"]))),
+            parity=dict(timed_run_mean_penetration_depth_m=float(np.mean(res["collision_loss_origin_scale"])), vs_oracle=parity),
         )
+        if selftest is not None:
+            out["rccl_selftest"] = selftest
         if cpu is not None:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out))

@@ -146,8 +146,11 @@ __device__ __forceinline__ float sdf_unnorm(float x, int align_corners) {
 #define SDF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // A hand's table, global -> LDS without passing through registers (global_load_lds: the LDS address is wave-uniform base + lane *
-// size, the layout stays linear).  Asynchronous: the caller goes on issuing its other loads and closes with __syncthreads()
-// (which waits for the workgroup's outstanding memory operations).  n16 16-byte units by 256 threads.
+// size, the layout stays linear).  Asynchronous: the caller goes on issuing its other loads and closes with SDF_STAGE_CLOSE():
+// every wave waits for its OWN outstanding vector-memory operations (s_waitcnt vmcnt(0): the DMA writes to LDS are tracked by the
+// issuing wave's vmcnt only -- a workgroup barrier alone does not wait for them), then the barrier makes all waves' pieces visible
+// to all (the form of CK's block_sync_lds_direct_load).  n16 16-byte units by 256 threads.
+#define SDF_STAGE_CLOSE() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 __device__ __forceinline__ void sdf_stage_async(const void* __restrict__ src, char* dst_lds, int n16) {
     const int tid = threadIdx.x, wave = tid / WAVE;
     for (int base = wave * WAVE; base < n16; base += SDF_THREADS) {
@@ -651,7 +654,7 @@ __device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int coll
             SDF_LDS_BARRIER();       // (the previous table's readers are done; LDS traffic only)
             sdf_stage_async(ws.sph + (size_t)H * NFP, reinterpret_cast<char*>(sph_s), NFP);
             sdf_stage_async(ws.rad + (size_t)H * NFP, reinterpret_cast<char*>(rad_s), NFP / 4);
-            __syncthreads();
+            SDF_STAGE_CLOSE();
             curH = H;
         }
         const float4* abc = ws.abc + (size_t)H * NFP * 3;
@@ -901,7 +904,7 @@ __device__ __forceinline__ void sdf_list_search(const SdfWorkspace& ws, int coll
         for (int c = 0; c < SDF_LIST_PIECE; ++c) ids4[c] = has ? piece[c] : make_uint4(PK, PK, PK, PK);
         const float4 A0 = abc[3 * nr], B0 = abc[3 * nr + 1], C0 = abc[3 * nr + 2];
         if (stage) {
-            __syncthreads();            // the table has landed (waits for this wave's other loads too: they were all in flight)
+            SDF_STAGE_CLOSE();          // the table has landed (waits for this wave's other loads too: they were all in flight)
             curH = H;
         }
         const float px = (float)(2 * (int)(vox & 31u) + 1) / (float)SDF_G - 1.0f, py = (float)(2 * (int)((vox >> 5) & 31u) + 1) / (float)SDF_G - 1.0f,

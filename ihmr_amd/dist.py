@@ -15,10 +15,16 @@ import torch
 import torch.distributed as dist
 
 
+def launched_by_torchrun() -> bool:
+    """True under ``python -m torch.distributed.run`` (also with ONE rank: the process group is then initialised and every
+    collective really goes through the backend -- how the RCCL path is exercised on a single-GPU box)."""
+    return "TORCHELASTIC_RUN_ID" in os.environ and "RANK" in os.environ
+
+
 def init_dist(backend: str | None = None):
-    """Returns (rank, world_size).  No-op for single-process runs."""
+    """Returns (rank, world_size).  No-op for plain single-process runs (not launched by torch.distributed.run)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not launched_by_torchrun():
         return 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     rank = int(os.environ["RANK"])
@@ -30,7 +36,10 @@ def init_dist(backend: str | None = None):
     if backend == "nccl":
         torch.cuda.set_device(local % torch.cuda.device_count())
     if not dist.is_initialized():
-        dist.init_process_group(backend)
+        if backend == "nccl":     # bind the communicator to this rank's GPU up front (eager init, no device guessing at first use)
+            dist.init_process_group(backend, device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend)
     return rank, world
 
 
@@ -47,8 +56,9 @@ def shard_indices(num_samples: int, batch_size: int, rank: int, world: int):
 
 
 def reduce_metrics(sums: np.ndarray, device=None) -> np.ndarray:
-    """all_reduce(SUM) of the additive metric vector (float64); identity for single-process runs."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    """all_reduce(SUM) of the additive metric vector (float64); identity when no process group exists (a one-rank group still
+    goes through the backend)."""
+    if not (dist.is_available() and dist.is_initialized()):
         return np.asarray(sums, dtype=np.float64)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -63,7 +73,7 @@ def all_reduce_gradients(flat_grads: torch.Tensor) -> float:
     reference's sub-networks (``models/mlp_model.py:383-385``), as a single bucket: the largest IHMR-MLP head is
     0.75 M parameters = 3 MB, a fraction of a millisecond on one xGMI link.  Returns the factor the optimizer has to
     apply to the summed gradient (1 / world size: DDP averages)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return 1.0
     dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
     return 1.0 / dist.get_world_size()
@@ -95,7 +105,7 @@ class OverlappedGradientReducer:
 
     def __init__(self, flat_grads: torch.Tensor, spans, bucket_bytes: int = 25 << 20):
         self.grads, self.plan, self.handles = flat_grads, plan_gradient_buckets(spans, bucket_bytes // 4), []
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.active = dist.is_available() and dist.is_initialized()
 
     def ready(self, k: int):
         if self.active and k in self.plan:

@@ -74,7 +74,8 @@ class TrainWeights(C.Structure):
 
 
 class KernelTimer(C.Structure):
-    _fields_ = [("ms_sdf_eval", C.c_double), ("n_sdf_eval", C.c_long), ("algo_flops_sdf_eval", C.c_double), ("ms_event_pair", C.c_double)]
+    _fields_ = [("ms_sdf_eval", C.c_double), ("n_sdf_eval", C.c_long), ("ms_sdf_repeat", C.c_double), ("ms_event_pair", C.c_double),
+                ("n_sdf_repeat", C.c_long)]
 
 
 def sources():
@@ -83,6 +84,16 @@ def sources():
 
 
 HASH_PATH = osp.join(_HERE, "libihmr_hip.srchash")
+
+
+def loaded_source_hash() -> str | None:
+    """Source hash of the library this process would load, from its build record (None for an IHMR_HIP_LIBRARY override or a
+    missing record).  bench.py quotes a committed profile only when the profile's recorded hash equals this."""
+    if os.environ.get("IHMR_HIP_LIBRARY") or not osp.isfile(HASH_PATH):
+        return None
+    with open(HASH_PATH) as fh:
+        rec = fh.read().split()
+    return rec[0] if len(rec) == 2 else None
 
 
 def _source_hash() -> str:
@@ -153,6 +164,10 @@ def _resolve_library() -> str:
         return build()
     if not osp.isfile(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} is missing and hipcc is not available to build it")
+    if is_stale():
+        raise RuntimeError(f"{LIB_PATH} does not match its sources (or its build record {HASH_PATH} is missing) and hipcc is not "
+                           "available to rebuild it: the ctypes structs of this package would not match the binary.  Rebuild where "
+                           "hipcc exists, or name a library explicitly with IHMR_HIP_LIBRARY")
     return LIB_PATH
 
 

@@ -220,14 +220,24 @@ class OptimizeModel:
     SDF_COUNTERS = ("ray_tests", "dist_evals", "inside_voxels", "needed_voxels", "sphere_tests", "voxels_from_lists",
                     "voxels_without_list", "voxels_rebuilt")
 
+    def _drop_graphs(self):
+        """Destroy every captured graph of this instance (they are re-captured on demand)."""
+        for g in self._graphs.values():
+            hip.lib().ihmr_graph_destroy(g)
+        self._graphs = {}
+
     def sdf_counters_start(self):
-        """Zero the collision kernels' work counters and switch them on for everything launched (or captured) from now on."""
+        """Zero the collision kernels' work counters and switch them on for everything launched (or captured) from now on.
+        The counter switch is baked into a captured launch, so the instance's graphs are dropped here and again in
+        :meth:`sdf_counters_stop`: a graph captured with the counters on never survives into a timed run."""
         hip.check(hip.lib().ihmr_opt_sdf_counters(C.byref(self.io), self.batch_size, None, 1), "ihmr_opt_sdf_counters")
+        self._drop_graphs()
 
     def sdf_counters_stop(self):
         """Synchronise, switch the counters off and return their totals since :meth:`sdf_counters_start` (diagnostics)."""
         out = (C.c_ulonglong * 8)()
         hip.check(hip.lib().ihmr_opt_sdf_counters(C.byref(self.io), self.batch_size, out, 0), "ihmr_opt_sdf_counters")
+        self._drop_graphs()
         return {k: int(out[i]) for i, k in enumerate(self.SDF_COUNTERS)}
 
     def run_stage(self, stage):
@@ -263,9 +273,7 @@ class OptimizeModel:
         try:
             if sys is None or sys.is_finalizing():
                 return
-            for g in self._graphs.values():
-                hip.lib().ihmr_graph_destroy(g)
-            self._graphs = {}
+            self._drop_graphs()
         except Exception:
             pass
 

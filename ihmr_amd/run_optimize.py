@@ -116,7 +116,7 @@ def main(argv=None):
         for k in ("mpjpe_3d", "inter_mpjpe_3d", "collision_ave", "collision_max"):
             print(f"{k} : {m[k]:.3f} (optimize)")
         print(json.dumps(dict(num_samples=args.num_samples, world=world, seconds=elapsed, **m)))
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     return Evaluator.metrics_from_sums(sums)
 

@@ -64,7 +64,11 @@ class SDFLoss(nn.Module):
         holding the real package can switch to pin this seam (``include/ihmr_hip.h: ihmr_sdf_options``)."""
         super().__init__()
         assert grid_size == 32, "the kernels are built for the 32^3 grid of the upstream module"
-        self.align_corners, self.loss_divisor = bool(align_corners), float(loss_divisor)
+        # one value for the options struct AND the autograd backward (the C side reads <= 0 as "default"; the backward divides by it)
+        loss_divisor = float(loss_divisor)
+        if not loss_divisor > 0.0:
+            raise ValueError(f"SDFLoss(loss_divisor={loss_divisor}): must be > 0 (4 = num_hands^2 of the parent project, 1 = plain sum)")
+        self.align_corners, self.loss_divisor = bool(align_corners), loss_divisor
         self.register_buffer("faces_right", torch.tensor(np.asarray(faces_right).astype(np.int32)))
         self.register_buffer("faces_left", torch.tensor(np.asarray(faces_left).astype(np.int32)))
         self.robustifier = robustifier

@@ -334,11 +334,14 @@ int ihmr_preprocess_images(const uint8_t* pixels, const int64_t* offsets, const 
                            float* joints_out, void* stream);
 
 /* per-kernel timing hook for bench.py: when non-NULL, the library records hipEvents around the
- * dominant kernel (sdf_dist_kernel) on `stream` and accumulates (count, ms) here; host pointer, read after sync.
- * While a timer is set, every call launches the (idempotent) kernel 8 times back to back between ONE pair of events;
- * n_sdf_eval counts launches.  ms_event_pair: an EMPTY event pair recorded right before each timed group, i.e. what
- * the two event records cost by themselves; (ms_sdf_eval - ms_event_pair) / n_sdf_eval is the launch duration. */
-typedef struct ihmr_kernel_timer { double ms_sdf_eval; long n_sdf_eval; double algo_flops_sdf_eval; double ms_event_pair; } ihmr_kernel_timer;
+ * dominant kernel (sdf_dist_kernel) on `stream` and accumulates here; host pointer, read after ihmr_flush_kernel_timer().
+ * While a timer is set, every call brackets its ONE in-loop launch of the kernel with a pair of events
+ * (ms_sdf_eval, n_sdf_eval: the launch the refinement really runs -- cold candidate-list hints, tables not yet in L2),
+ * then launches the (idempotent) kernel 7 more times between a second pair (ms_sdf_repeat, n_sdf_repeat: warm repeats,
+ * reported beside it, never as the launch duration).  ms_event_pair: an EMPTY event pair recorded right before each
+ * timed call, i.e. what two event records cost by themselves; (ms_sdf_eval - ms_event_pair) / n_sdf_eval is the launch
+ * duration. */
+typedef struct ihmr_kernel_timer { double ms_sdf_eval; long n_sdf_eval; double ms_sdf_repeat; double ms_event_pair; long n_sdf_repeat; } ihmr_kernel_timer;
 int ihmr_set_kernel_timer(ihmr_kernel_timer* t);
 int ihmr_flush_kernel_timer(void);
 

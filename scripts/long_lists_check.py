@@ -16,7 +16,7 @@ for off in (False, True):
     fwd = lambda p, s, t: two_hand.forward_from_packed(m.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
     batch = synthetic_opt_batch(B, fwd, seed=4321)
     m.set_input(batch); m.init_optimize()
-    if not off: m.sdf_counters_start(); m._graphs = {}
+    if not off: m.sdf_counters_start()
     m.optimize()
     if not off: print({k: v for k, v in m.sdf_counters_stop().items() if k.startswith("voxels") or k == "inside_voxels"})
     torch.cuda.synchronize()

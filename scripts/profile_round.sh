@@ -17,4 +17,13 @@ python3 scripts/pmc_sq_summary.py gpurun_out/pmc_s gpurun_out/${tag}_pmc_sq.csv 
 find gpurun_out/pmc_f -name "*counter_collection.csv" | head -1 | xargs head -3
 python3 scripts/pmc_summary.py gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/${tag}_pmc_traffic.csv
 rm -rf gpurun_out/kt gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/pmc_s
+# which code was profiled: bench.py quotes a profile only when this hash equals the hash of the library it loads
+python3 - "$tag" "${FUSE:-8}" "$CMD" <<'PY'
+import json, sys, time
+sys.path.insert(0, ".")
+from ihmr_amd import hip
+tag, fuse, cmd = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+json.dump(dict(srchash=hip.loaded_source_hash(), config="opt", batches_per_launch=fuse, command=cmd, unix_time=int(time.time())),
+          open(f"gpurun_out/{tag}_meta.json", "w"))
+PY
 tail -1 gpurun_out/${tag}_kt.log | cut -c1-400

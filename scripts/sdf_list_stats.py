@@ -16,7 +16,6 @@ fwd = lambda p, s, t: two_hand.forward_from_packed(m.mano_models["right"], p.cud
 m.set_input(synthetic_opt_batch(B, fwd, seed=1234)); m.init_optimize()
 for i, stage in enumerate(m.strategy):
     m.sdf_counters_start()
-    m._graphs = {}       # (re)capture the stage graph with the counters on
     m.run_stage(stage)
     c = m.sdf_counters_stop()
     print(f"stage {i}: " + ", ".join(f"{k} {v}" for k, v in c.items()))

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of CPU-oracle time on the GPU box (the headline workload, the reference's default schedule)")
 
 
 @pytest.fixture(scope="session")

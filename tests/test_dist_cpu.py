@@ -150,3 +150,24 @@ def test_evaluator_matches_reference_metrics():
         assert np.allclose(a, g[f"j3d_err_{i}"], atol=1e-9)
         p = E.get_single_pa_inter_joints_error(g[f"pred_{i}"], g[f"gt_{i}"], g[f"valid_{i}"], float(g[f"scale_{i}"]))
         assert np.allclose(p, g[f"pa_err_{i}"], atol=1e-7)
+
+
+def _single_worker(rank, world, port, out):
+    import ihmr_amd.dist as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", TORCHELASTIC_RUN_ID="t")
+    r, w = D.init_dist("gloo")
+    assert (r, w) == (0, 1) and torch.distributed.is_initialized()
+    sums = D.reduce_metrics(np.arange(9, dtype=np.float64))
+    g = torch.arange(8, dtype=torch.float32)
+    f = D.all_reduce_gradients(g)
+    np.save(out, np.concatenate([sums, [f], g.numpy()]))
+    torch.distributed.destroy_process_group()
+
+
+def test_one_rank_group_goes_through_the_backend(tmp_path):
+    """A ONE-rank launch under torch.distributed.run initialises a real process group and the reductions run through it
+    (what tests/test_gpu_multirank.py does with RCCL on the single GPU of a test box)."""
+    out = str(tmp_path / "one.npy")
+    mp.spawn(_single_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    got = np.load(out)
+    assert np.array_equal(got[:9], np.arange(9)) and got[9] == 1.0 and np.array_equal(got[10:], np.arange(8))

@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, timeout=600):
+def _run(args, timeout=600, nproc=2, backend="gloo"):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, IHMR_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    env = dict(os.environ, IHMR_DIST_BACKEND=backend, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -45,3 +45,21 @@ def test_training_loops_with_two_ranks():
     assert log[-1]["steps"] == 8 and log[-1]["loss_last"] < log[-1]["loss_first"]
     log = _run(["-m", "ihmr_amd.run_train_baseline", "--num_samples", "8", "--batchSize", "8", "--total_epoch", "6", "--lr", "1e-4"])
     assert len(log) == 6 and log[-1]["loss_last"] < log[0]["loss_first"]
+
+
+def test_rccl_backend_runs_the_collectives_with_one_rank():
+    """RCCL itself (backend "nccl") on the one GPU a test box has: ONE rank launched exactly as the driver launches N
+    (``torch.distributed.run``), so the process group is real -- ``init_process_group("nccl", device_id=...)``, the barrier, the
+    MAX all-reduce of the step time in bench.py and the float64 metric all-reduce of ``run_optimize`` on a device tensor all
+    go through RCCL (two ranks cannot share a GPU in one RCCL communicator; a multi-GPU node only adds peers)."""
+    from ihmr_amd import run_optimize
+    log = _run(["-m", "ihmr_amd.run_optimize", "--num_samples", "64", "--batchSize", "32", "--opt_epoch", "4"], nproc=1, backend="nccl")[-1]
+    one = run_optimize.main(["--num_samples", "64", "--batchSize", "32", "--opt_epoch", "4"])
+    assert log["world"] == 1
+    for k in ("mpjpe_3d", "inter_mpjpe_3d", "collision_ave", "collision_max"):
+        assert abs(log[k] - one[k]) <= 1e-12 * max(1.0, abs(one[k])), (k, log[k], one[k])
+    lines = _run(["bench.py", "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--rccl-selftest"],
+                 nproc=1, backend="nccl")
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["value"] > 0
+    st = lines[0]["rccl_selftest"]
+    assert st["backend"] == "nccl" and st["all_reduce_sum_f64_ok"] and st["all_reduce_max_ok"] and st["all_gather_ok"] and st["gradient_bucket_ok"]

@@ -222,6 +222,39 @@ def test_sdf_collision_matches_oracle(mano_arrays):
     _report("sdf d/dverts", hv_g.grad.cpu(), hv_ref.grad, atol=1e-4 * float(hv_ref.grad.abs().max()))
 
 
+@pytest.mark.parametrize("robustifier", [0.05, 1.0])
+def test_sdf_collision_robustifier_matches_oracle(mano_arrays, robustifier):
+    """The train-time branch of seam B (loss_utils.py:36-38: `SDFLoss(..., robustifier=...)`): per-vertex value
+    r^2 / (r^2 + 1), r = phi / robustifier, and its gradient, against the oracle."""
+    from ihmr_amd.sdf import SDFLoss
+    from oracle.sdf_ref import SDFLossRef
+    right, left = mano_arrays
+    B = 5
+    hv, _ = _two_hand_verts(mano_arrays, B, 11)
+    ref_mod = SDFLossRef(right["faces"], left["faces"], robustifier=robustifier)
+    hv_ref = hv.clone().requires_grad_(True)
+    l_ref, pv_ref, os_ref = ref_mod(hv_ref, return_per_vert_loss=True, return_origin_scale_loss=True)
+    w = torch.linspace(0.7, 1.3, B)
+    (l_ref * w).sum().backward()
+    mod = SDFLoss(right["faces"], left["faces"], robustifier=robustifier).to(_dev())
+    hv_g = hv.clone().to(_dev()).requires_grad_(True)
+    l, pv, os_ = mod(hv_g, return_per_vert_loss=True, return_origin_scale_loss=True)
+    (l * w.to(_dev())).sum().backward()
+    assert int((pv_ref > 0).sum()) > 50, "test batch must actually penetrate"
+    _report(f"robust {robustifier} per_vert", pv.detach().cpu(), pv_ref.detach(), atol=2e-6, rtol=1e-5)
+    _report(f"robust {robustifier} origin_scale", os_.detach().cpu(), os_ref.detach(), atol=2e-7, rtol=1e-5)
+    _report(f"robust {robustifier} loss", l.detach().cpu(), l_ref.detach(), atol=1e-5, rtol=1e-5)
+    _report(f"robust {robustifier} d/dverts", hv_g.grad.cpu(), hv_ref.grad, atol=1e-4 * float(hv_ref.grad.abs().max()))
+
+
+def test_sdf_loss_divisor_must_be_positive(mano_arrays):
+    from ihmr_amd.sdf import SDFLoss
+    right, left = mano_arrays
+    for bad in (0.0, -4.0):
+        with pytest.raises(ValueError):
+            SDFLoss(right["faces"], left["faces"], loss_divisor=bad)
+
+
 def test_sdf_disjoint_hands_zero(mano_arrays):
     from ihmr_amd.sdf import SDFLoss
     right, left = mano_arrays
@@ -648,6 +681,59 @@ def test_opt_batch64_matches_oracle(mano_arrays):
     _report("B=64 joints [m]", g["pred_joints_3d"], r["pred_joints_3d"], atol=1e-4)
     _report("B=64 penetration depth [m]", g["collision_loss_origin_scale"], r["collision_loss_origin_scale"], atol=1e-4)
     _report("B=64 collision_loss", g["collision_loss"], r["collision_loss"], atol=2e-4, rtol=1e-3)
+
+
+@pytest.mark.slow
+def test_opt_headline_workload_matches_oracle(mano_arrays):
+    """BASELINE.json's metric config itself -- IHMR-OPT, batch 64, opt_default at epoch 49 = 4 x 50 = 200 refinement iterations,
+    snapshot every 10 (what bench.py times) -- against the oracle (minutes of CPU time): selection indices identical, joints /
+    vertices / penetration depth within the 1e-4 of north_star, mean penetration depth and MPJPE side by side."""
+    B, epoch, freq = 64, 49, 10
+    orc, model, batch = _oracle_and_model(mano_arrays, B, epoch, freq, seed=1234, record=False)
+    torch.set_num_threads(max(1, min(32, (__import__("os").cpu_count() or 8))))
+    orc.set_input(batch); orc.init_optimize(); orc.optimize()
+    model.set_input(batch); model.init_optimize(); model.optimize()
+    torch.cuda.synchronize()
+    r, g = orc.get_pred_result(), model.get_pred_result()
+    sel_ref, sel_got = np.stack(orc.selected), torch.stack(model.selected_history).cpu().numpy()
+    print(f"[parity] headline: selection agreement {float((sel_ref == sel_got).mean()):.4f}")
+    assert np.array_equal(sel_ref, sel_got)
+    _report("headline joints [m]", g["pred_joints_3d"], r["pred_joints_3d"], atol=1e-4)
+    _report("headline right verts [m]", g["pred_right_hand_verts"], r["pred_right_hand_verts"], atol=1e-4)
+    _report("headline left verts [m]", g["pred_left_hand_verts"], r["pred_left_hand_verts"], atol=1e-4)
+    _report("headline penetration depth [m]", g["collision_loss_origin_scale"], r["collision_loss_origin_scale"], atol=1e-4)
+    mp_ref, mp_got = float(r["collision_loss_origin_scale"].mean()), float(g["collision_loss_origin_scale"].mean())
+    mpjpe = lambda x: float(np.linalg.norm(x["pred_joints_3d"] - x["gt_joints_3d"][..., :3], axis=-1).mean())
+    print(f"[parity] headline: mean penetration depth ref={mp_ref:.6e} got={mp_got:.6e}; MPJPE ref={mpjpe(r):.6e} got={mpjpe(g):.6e}")
+    assert abs(mp_ref - mp_got) < 1e-4 and abs(mpjpe(r) - mpjpe(g)) < 1e-4
+
+
+@pytest.mark.slow
+def test_opt_reference_default_schedule_matches_oracle(mano_arrays):
+    """The reference's own default schedule (strategies/opt_default.py:15,34,53,73: epoch 300 = 4 x 301 iterations, 31 snapshots
+    per stage) at B = 8 against the oracle, with the candidate lists of the collision kernels ON and OFF: the long schedule
+    is where stale lists would show (hands drift furthest from the pose their lists were built at)."""
+    from ihmr_amd.optimize_model import OptimizeModel
+    B, epoch, freq = 8, 300, 10
+    orc, model, batch = _oracle_and_model(mano_arrays, B, epoch, freq, seed=808, record=False)
+    torch.set_num_threads(max(1, min(32, (__import__("os").cpu_count() or 8))))
+    orc.set_input(batch); orc.init_optimize(); orc.optimize()
+    r = orc.get_pred_result()
+    sel_ref = np.stack(orc.selected)
+    o2 = _make_opt(B, epoch=epoch, save_mid_freq=freq)
+    o2.sdf_no_candidate_lists = True
+    outs = {}
+    for name, m in (("lists", model), ("no lists", OptimizeModel(o2))):
+        m.set_input(batch); m.init_optimize(); m.optimize()
+        torch.cuda.synchronize()
+        g = m.get_pred_result()
+        outs[name] = g
+        assert np.array_equal(sel_ref, torch.stack(m.selected_history).cpu().numpy()), name
+        _report(f"4x301 [{name}] joints [m]", g["pred_joints_3d"], r["pred_joints_3d"], atol=1e-4)
+        _report(f"4x301 [{name}] right verts [m]", g["pred_right_hand_verts"], r["pred_right_hand_verts"], atol=1e-4)
+        _report(f"4x301 [{name}] penetration depth [m]", g["collision_loss_origin_scale"], r["collision_loss_origin_scale"], atol=1e-4)
+    for k in ("pred_pose_params", "pred_shape_params", "pred_right_hand_verts", "pred_left_hand_verts", "collision_loss_origin_scale"):
+        assert np.array_equal(outs["lists"][k], outs["no lists"][k]), f"candidate lists changed {k}"
 
 
 # ----------------------------------------------------------------------------------- seams A + B composed (import-swap route)
