@@ -43,17 +43,25 @@
 #endif
 #define SDF_ITEM 16                // inside voxels per work item of the distance kernel (one hand per item); power of two
 
-// Per-hand, per-iteration triangle tables:
-//   sph[f] = (cx, cy, cz, r): bounding sphere about the centroid c, conservative radius (the distance kernel uses it only for
-//            conservative culling); padding triangles are parked at 1e18, so arithmetic alone culls them.  Goes to LDS as it
-//            is (direct global -> LDS loads)
-//   rad[f] = r again, as a plain array (conflict-free LDS reads for the lanes-across-triangles pass)
-//   abc[f] = {a,0} {b,0} {c,0}                                                           (exact distance)
+// Per-hand, per-iteration tables (written by the prep kernel, read by the distance kernel):
+//   sph[f] = (mx, my, mz, R): the triangle's minimum enclosing circle -- centre m ON the triangle (circumcentre of an acute
+//            triangle, midpoint of the longest edge otherwise; the centroid for a near-degenerate one), conservative radius -- used
+//            as a bounding sphere and as the in-plane circle of the plane + circle bound; padding triangles are parked at 1e18, so
+//            arithmetic alone culls them.  Goes to LDS as it is (direct global -> LDS loads)
+//   nrm[f] = the unit normal in 3 x 10 signed bits (n ~ q / 511) | SDF_NRM_NOPLANE for a near-degenerate triangle (sphere bound only)
+//   vn4[v] = (x, y, z, 0): the hand's normalised vertices; the exact distance gathers a triangle's corners from here through the
+//            packed face table fpk (12 KB per hand instead of a 77 KB per-triangle corner table)
+#define SDF_NV4 784                 // vertices per hand in vn4 (778 padded to a multiple of 16)
+#define SDF_NRM_NOPLANE 0x40000000u
+#define SDF_NRM_EN 1.05e-3f         // max component error of the 10-bit normal (0.5 / 511) + the fp32 error of the normal itself
+#define SDF_NRM_EM 2e-6f            // centre off-plane by rounding + evaluation error of the plane distance
 struct SdfWorkspace {          // carved from the caller's workspace; H = 2B hands, hand id = hnd*B + b
     float* box;                // [H][4]  centre xyz, scale
     float4* sph;               // [H][NFP]
-    float* rad;                // [H][NFP]
-    float4* abc;               // [H][NFP][3]
+    unsigned* nrm;             // [H][NFP]
+    float4* vn4;               // [H][SDF_NV4]
+    const unsigned* fpk[2];    // [NFP] packed faces a | b << 10 | c << 20 of the right / left hand (constants of the model)
+    int B;                     // hands [0, B) are right hands, [B, 2B) left hands
     float* phi;                // [H][32768]  (only the voxels a sample reads are defined)
     unsigned* inside_list;     // [xcd_cap] inside voxels of the whole batch: (hand << 16) | voxel id, 16-aligned run per hand
     int* inside_count;         // [8] (slot 0 in use)
@@ -88,8 +96,9 @@ __host__ __device__ inline size_t sdf_list_bytes(int H) {
 __host__ __device__ inline size_t sdf_ws_bytes(int H, bool lists = false) {
     size_t n = lists ? sdf_list_bytes(H) : 0;
     n += (size_t)H * 4 * sizeof(float);
-    n += (size_t)H * NFP * 4 * sizeof(float4);      // sph + abc
-    n += (size_t)H * NFP * sizeof(float);           // rad
+    n += (size_t)H * NFP * sizeof(float4);          // sph
+    n += (size_t)H * NFP * sizeof(unsigned);        // nrm
+    n += (size_t)H * SDF_NV4 * sizeof(float4);      // vn4
     n += (size_t)H * SDF_NVOX * sizeof(float);
     n += sdf_xcd_cap(H) * sizeof(unsigned);
     n += 128 + 256;
@@ -101,8 +110,10 @@ static inline SdfWorkspace sdf_carve(void* ws, int H, bool lists = false) {
     char* p = (char*)ws;
     w.box = (float*)p; p += (size_t)H * 4 * sizeof(float);
     w.sph = (float4*)p; p += (size_t)H * NFP * sizeof(float4);
-    w.abc = (float4*)p; p += (size_t)H * NFP * 3 * sizeof(float4);
-    w.rad = (float*)p; p += (size_t)H * NFP * sizeof(float);
+    w.vn4 = (float4*)p; p += (size_t)H * SDF_NV4 * sizeof(float4);
+    w.nrm = (unsigned*)p; p += (size_t)H * NFP * sizeof(unsigned);
+    w.fpk[0] = w.fpk[1] = nullptr;
+    w.B = H / 2;
     w.phi = (float*)p; p += (size_t)H * SDF_NVOX * sizeof(float);
     w.stats = (unsigned long long*)p; p += 64;
     w.inside_count = (int*)p; p += 64;
@@ -354,9 +365,11 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     for (int rep = 0; rep < VPT; ++rep) {
         const int v = tid + rep * PT;
         if (v >= NV) break;
-        vn[3 * v] = (vn[3 * v] - cx) / sc;
-        vn[3 * v + 1] = (vn[3 * v + 1] - cy) / sc;
-        vn[3 * v + 2] = (vn[3 * v + 2] - cz) / sc;
+        {
+            const float nx = (vn[3 * v] - cx) / sc, ny = (vn[3 * v + 1] - cy) / sc, nz = (vn[3 * v + 2] - cz) / sc;
+            vn[3 * v] = nx; vn[3 * v + 1] = ny; vn[3 * v + 2] = nz;
+            ws.vn4[(size_t)H * SDF_NV4 + v] = make_float4(nx, ny, nz, 0.f);     // the exact distance gathers triangle corners from here
+        }
         if (!DENSE) {
             const float qx = (oq[rep][0] - cx) / sc, qy = (oq[rep][1] - cy) / sc, qz = (oq[rep][2] - cz) / sc;
             const float ix = sdf_unnorm(qx, ws.align_corners), iy = sdf_unnorm(qy, ws.align_corners), iz = sdf_unnorm(qz, ws.align_corners);
@@ -428,8 +441,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     }
     // ---- lane = triangle: records for the distance kernel + ray parity of the needed voxels it can hit
     float4* sph = ws.sph + (size_t)H * NFP;
-    float* rad = ws.rad + (size_t)H * NFP;
-    float4* abc = ws.abc + (size_t)H * NFP * 3;
+    unsigned* nrm = ws.nrm + (size_t)H * NFP;
     unsigned long long st_tests = 0;
 #pragma unroll
     for (int it = 0; it < TRI_IT; ++it) {
@@ -443,24 +455,49 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         const float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
         const float det = __builtin_fmaf(e1z, e2y, -(e1y * e2z));
         const bool ok = f < NF && fabsf(det) >= 1e-12f;
-        abc[3 * f] = make_float4(a[0], a[1], a[2], 0.f);
-        abc[3 * f + 1] = make_float4(bb[0], bb[1], bb[2], 0.f);
-        abc[3 * f + 2] = make_float4(c[0], c[1], c[2], 0.f);
-        // bounding sphere about the centroid (conservative radius)
-        const float gx = (a[0] + bb[0] + c[0]) * (1.0f / 3.0f), gy = (a[1] + bb[1] + c[1]) * (1.0f / 3.0f),
-                    gz = (a[2] + bb[2] + c[2]) * (1.0f / 3.0f);
-        float r2 = 0.f;
+        // ---- record for the distance kernel: minimum enclosing circle (centre m on the triangle, conservative radius) + normal.
+        //      Used for conservative culling only -- the minimum itself is evaluated exactly from the corners
         {
-            float dx = a[0] - gx, dy = a[1] - gy, dz = a[2] - gz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
-            dx = bb[0] - gx; dy = bb[1] - gy; dz = bb[2] - gz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
-            dx = c[0] - gx; dy = c[1] - gy; dz = c[2] - gz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
-        }
-        // padding triangles (f >= NF): parked at 1e18 with radius 0, so the distance kernel culls them by arithmetic alone
-        {
-            const float qx = f < NF ? gx : 1e18f, qy = f < NF ? gy : 1e18f, qz = f < NF ? gz : 1e18f;
-            const float r = f < NF ? sqrtf(r2) * 1.0001f + 1e-6f : 0.0f;
-            sph[f] = make_float4(qx, qy, qz, r);
-            rad[f] = r;
+            const float e3x = c[0] - bb[0], e3y = c[1] - bb[1], e3z = c[2] - bb[2];
+            const float la = e3x * e3x + e3y * e3y + e3z * e3z;        // squared edge opposite a
+            const float lb = e2x * e2x + e2y * e2y + e2z * e2z;        // ... opposite b
+            const float lc = e1x * e1x + e1y * e1y + e1z * e1z;        // ... opposite c
+            const float nx = __builtin_fmaf(e1y, e2z, -(e1z * e2y)), ny = __builtin_fmaf(e1z, e2x, -(e1x * e2z)),
+                        nz = __builtin_fmaf(e1x, e2y, -(e1y * e2x));
+            const float n2 = nx * nx + ny * ny + nz * nz;
+            // well-conditioned: sin^2 of the angle at a >= 1e-4 (the normal's direction is then good to ~1e-5 in fp32)
+            const bool well = f < NF && n2 >= 1e-4f * (lb * lc) && n2 > 1e-30f;
+            const float wa = la * (lb + lc - la), wb = lb * (la + lc - lb), wc = lc * (la + lb - lc);
+            float mx, my, mz;
+            if (!well) {                                   // centroid: on the triangle whatever its shape
+                mx = (a[0] + bb[0] + c[0]) * (1.0f / 3.0f); my = (a[1] + bb[1] + c[1]) * (1.0f / 3.0f); mz = (a[2] + bb[2] + c[2]) * (1.0f / 3.0f);
+            } else if (wa <= 0.f) {                        // angle at a >= 90 degrees: midpoint of the opposite edge
+                mx = 0.5f * (bb[0] + c[0]); my = 0.5f * (bb[1] + c[1]); mz = 0.5f * (bb[2] + c[2]);
+            } else if (wb <= 0.f) {
+                mx = 0.5f * (a[0] + c[0]); my = 0.5f * (a[1] + c[1]); mz = 0.5f * (a[2] + c[2]);
+            } else if (wc <= 0.f) {
+                mx = 0.5f * (a[0] + bb[0]); my = 0.5f * (a[1] + bb[1]); mz = 0.5f * (a[2] + bb[2]);
+            } else {                                       // acute: circumcentre as a CONVEX combination of the corners (weights in (0,1))
+                const float inv_w = 1.0f / (wa + wb + wc);
+                const float ua = wa * inv_w, ub_ = wb * inv_w, uc = wc * inv_w;
+                mx = ua * a[0] + ub_ * bb[0] + uc * c[0]; my = ua * a[1] + ub_ * bb[1] + uc * c[1]; mz = ua * a[2] + ub_ * bb[2] + uc * c[2];
+            }
+            float r2 = 0.f;
+            {
+                float dx = a[0] - mx, dy = a[1] - my, dz = a[2] - mz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+                dx = bb[0] - mx; dy = bb[1] - my; dz = bb[2] - mz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+                dx = c[0] - mx; dy = c[1] - my; dz = c[2] - mz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+            }
+            unsigned nw = SDF_NRM_NOPLANE;
+            if (well) {
+                const float inv_n = 511.0f / sqrtf(n2);
+                const int qx = (int)rintf(nx * inv_n), qy = (int)rintf(ny * inv_n), qz = (int)rintf(nz * inv_n);
+                nw = ((unsigned)qx & 1023u) | (((unsigned)qy & 1023u) << 10) | (((unsigned)qz & 1023u) << 20);
+            }
+            // padding triangles (f >= NF): parked at 1e18 with radius 0, so the distance kernel culls them by arithmetic alone
+            const bool real = f < NF;
+            sph[f] = make_float4(real ? mx : 1e18f, real ? my : 1e18f, real ? mz : 1e18f, real ? sqrtf(r2) * 1.0001f + 1e-6f : 0.0f);
+            nrm[f] = real ? nw : SDF_NRM_NOPLANE;
         }
         if (!ok) continue;                                   // degenerate in yz: the +x ray never counts it
         const float inv = 1.0f / det;
