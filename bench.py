@@ -349,8 +349,8 @@ def secondary(config, with_cpu=True):
         m._core.use_graphs = core_graphs
         nl = max(int(timer.n_sdf_eval), 1)
         k_ms = (timer.ms_sdf_eval - timer.ms_event_pair) / nl
-        flops = (11.0 * cnt["sphere_tests"] + 75.0 * cnt["dist_evals"]) / nl
-        abytes = 2.0 * B * 1538 * (16 + 36) + cnt["inside_voxels"] / nl * 8
+        flops = (11.0 * cnt["sphere_tests"] + 30.0 * cnt["plane_tests"] + 75.0 * cnt["dist_evals"]) / nl
+        abytes = 2.0 * B * (1538 * (16 + 4) + 778 * 16) + cnt["inside_voxels"] / nl * 8
         traffic, tsrc, prof_us = pmc_traffic("sdf_dist_kernel", None, "mlp")
         ach, bw = flops / (k_ms * 1e-3) / 1e12, abytes / (k_ms * 1e-3) / 1e9
         hbm_binds = bw / HBM_PEAK_GBS > ach / FP32_PEAK_TFLOPS
@@ -588,28 +588,27 @@ def main():
                 mdl.sdf_counters_start()
                 mdl.optimize(0, 1)
                 cnt = mdl.sdf_counters_stop()
-                stats = dict(sphere_tests=cnt["sphere_tests"] / n_launch, dist_evals=cnt["dist_evals"] / n_launch,
+                stats = dict(sphere_tests=cnt["sphere_tests"] / n_launch, plane_tests=cnt["plane_tests"] / n_launch, dist_evals=cnt["dist_evals"] / n_launch,
                              voxels_from_lists=cnt["voxels_from_lists"] / n_launch,
                              voxels_full_search=(cnt["voxels_without_list"] + cnt["voxels_rebuilt"]) / n_launch,
                              inside_voxels=cnt["inside_voxels"] / n_launch, needed_voxels=cnt["needed_voxels"] / n_launch,
                              ray_tests=cnt["ray_tests"] / n_launch)
-                # flops of ONE launch: 11 per bounding-sphere test (|p - centroid|^2: 8, cull test: 3) and 75 per exact
-                # point-triangle distance -- what the kernel executed; a full search of every inside voxel (the kernel without its
-                # candidate lists, round 1's model) would execute 1538 sphere tests per inside voxel
-                flops = 11.0 * stats["sphere_tests"] + 75.0 * stats["dist_evals"]
-                # algorithmic bytes of ONE launch: every hand's table once (sphere records 16 B + the three
-                # corners 36 B per triangle, 1538 triangles) + per inside voxel its work-list entry, map word, candidate list
-                # (384 B) and the result
-                abytes = 2.0 * g * B * 1538 * (16 + 36) + stats["inside_voxels"] * (4 + 4 + 384 + 4)
+                # flops of ONE launch: 11 per bounding-sphere test (|p - m|^2: 8, cull test: 3), 30 per plane + circle test and 75
+                # per exact point-triangle distance -- what the kernel executed; a full search of every inside voxel (the kernel
+                # without its candidate lists, round 1's model) would execute 1538 sphere tests per inside voxel
+                flops = 11.0 * stats["sphere_tests"] + 30.0 * stats["plane_tests"] + 75.0 * stats["dist_evals"]
+                # algorithmic bytes of ONE launch: every hand's tables once (sphere record 16 B + packed
+                # normal 4 B per triangle, 1538 triangles; 16 B per vertex, 778 vertices) + per inside voxel its work-list
+                # entry, map word, candidate list (384 B) and the result
+                abytes = 2.0 * g * B * (1538 * (16 + 4) + 778 * 16) + stats["inside_voxels"] * (4 + 4 + 384 + 4)
             mdl.use_graphs = graphs
             # launch duration = event-bracketed time of the in-loop launch minus the cost of an (empty) event pair recorded right
-            # before it; the 7 warm repeats that follow each timed launch are reported beside it (they start from the
-            # first launch's nearest-triangle hints with the tables in L2, i.e. they are biased low)
+            # before it (no warm repeats -- they measured 77.5 us against 76.5 us in-loop, and the kernel now pulls its
+            # work from a cursor that one launch spends)
             avg_ms = (timer.ms_sdf_eval - timer.ms_event_pair) / n_launch
-            rep_ms = timer.ms_sdf_repeat / max(int(timer.n_sdf_repeat), 1)
             ach = flops / (avg_ms * 1e-3) / 1e12 if (avg_ms > 0 and flops) else None
             per_size.append(dict(batches_per_launch=g, launch_sequences_in_timed_region=sizes_run[g], avg_launch_ms=avg_ms,
-                                 warm_repeat_launch_ms=rep_ms, launches_timed=int(timer.n_sdf_eval),
+                                 launches_timed=int(timer.n_sdf_eval),
                                  algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=abytes, work_per_launch=stats, achieved=ach,
                                  full_search_flops_per_launch=(1538 * 11.0 * stats["inside_voxels"] + 75.0 * stats["dist_evals"]) if stats else None,
                                  frac=(ach / FP32_PEAK_TFLOPS) if ach else None))

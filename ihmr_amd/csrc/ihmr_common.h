@@ -51,6 +51,7 @@ struct ihmr_mano {
     int32_t* jseg_start;  // [17] first segment of each joint
     int nseg;
     int32_t* faces;       // [3][NFP] SoA, padded with face 0
+    uint32_t* faces_pk;   // [NFP] the same as a | b << 10 | c << 20 (vertex ids < 1024): one load per triangle in the distance kernel
     float* J_regressor;   // [16][778] (host-side precompute source, kept for update_shapedirs)
     int max_depth;
     int nnz;

@@ -19,7 +19,6 @@
 #include "train_conv.h"
 
 static ihmr_kernel_timer* g_timer = nullptr;
-#define IHMR_TIMED_REPEAT 7      // warm repeats after the in-loop launch of a timed call
 struct TimedPair { hipEvent_t e0, e1, a, b, c; int reps; };   // (e0,e1): an empty pair right before, the cost of the events themselves; (a,b): the in-loop launch; (b,c): the repeats
 static std::vector<TimedPair> g_pending;
 
@@ -119,6 +118,9 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
             if (id < 0 || id >= NV) { delete m; return -1; }
             fsoa[(size_t)k * NFP + f] = id;
         }
+    std::vector<uint32_t> fpk(NFP, 0u);
+    for (int f = 0; f < NFP; ++f)
+        fpk[f] = (uint32_t)fsoa[f] | ((uint32_t)fsoa[(size_t)NFP + f] << 10) | ((uint32_t)fsoa[(size_t)2 * NFP + f] << 20);
     std::vector<float> pd4, sd4, vt4;
     pack4(pd.data(), NPF, pd4);
     pack4(sd_t.data(), 10, sd4);
@@ -131,7 +133,7 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
     m->sparse4 = sparse4;
     rc |= upload(&m->pose_mean, pm); rc |= upload(&m->parents, par); rc |= upload(&m->depth, depth);
     rc |= upload(&m->tip_ids, tips); rc |= upload(&m->wj_start, start); rc |= upload(&m->wj_vert, wv);
-    rc |= upload(&m->wj_w, ww); rc |= upload(&m->seg_q, seg_q); rc |= upload(&m->jseg_start, jseg); rc |= upload(&m->faces, fsoa); rc |= upload(&m->J_regressor, jr);
+    rc |= upload(&m->wj_w, ww); rc |= upload(&m->seg_q, seg_q); rc |= upload(&m->jseg_start, jseg); rc |= upload(&m->faces, fsoa); rc |= upload(&m->faces_pk, fpk); rc |= upload(&m->J_regressor, jr);
     m->max_depth = maxd;
     m->nnz = (int)wv.size();
     m->nseg = (int)seg_q.size() - 1;
@@ -152,7 +154,7 @@ extern "C" int ihmr_mano_destroy(ihmr_mano* m) {
     if (!m) return 0;
     void* ptrs[] = {m->v_template, m->shapedirs_t, m->posedirs, m->J_template, m->J_shapedirs, m->weights, m->pose_mean,
                     m->parents, m->depth, m->tip_ids, m->wj_start, m->wj_vert, m->wj_w, m->faces, m->J_regressor, m->pd4, m->sd4, m->vt4, m->seg_q, m->jseg_start,
-                    m->w4_w, m->w4_j};
+                    m->w4_w, m->w4_j, m->faces_pk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -230,16 +232,18 @@ extern "C" int ihmr_mano_lbs_bwd(const ihmr_mano* m, int N, const void* workspac
 }
 
 // ------------------------------------------------------------------------------------------ seam B
-extern "C" size_t ihmr_sdf_workspace_bytes(int B) { return sdf_ws_bytes(2 * B) + (size_t)2 * NFP * 3 * 4 + 256; }
+// (tail: the SoA and the packed copies of the caller's two face arrays)
+extern "C" size_t ihmr_sdf_workspace_bytes(int B) { return sdf_ws_bytes(2 * B) + (size_t)2 * NFP * 4 * 4 + 256; }
 
 static int g_collect_stats = 0;
 
-static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const int32_t* faces_l_soa, int B, SdfWorkspace ws,
-                      float robustifier, float* loss, float* per_vert, float* origin, float* dval, bool dense, hipStream_t st) {
+static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const int32_t* faces_l_soa, const uint32_t* fpk_r,
+                      const uint32_t* fpk_l, int B, SdfWorkspace ws, float robustifier, float* loss, float* per_vert, float* origin, float* dval, bool dense, hipStream_t st) {
     // the inside-voxel counter is zero on entry (faces_to_soa_kernel on seam B, the skeleton kernel of the iteration
     // on seam C); the prep kernel appends to it
     // small launches: the 1024-thread form (half the chain per thread), see sdf_collision.h
     const bool small = 2 * B <= SDF_PREP_SMALL_MAX_HANDS;
+    ws.fpk[0] = fpk_r; ws.fpk[1] = fpk_l; ws.B = B;
     if (dense)
         hipLaunchKernelGGL((sdf_prep_kernel<true, SDF_PREP_THREADS_LARGE>), dim3(2 * B), dim3(SDF_PREP_THREADS_LARGE), 0, st, vl, B, faces_r_soa,
                            faces_l_soa, ws, g_collect_stats);
@@ -261,20 +265,21 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
         HIP_TRY(hipEventRecord(tp.e1, st));
         HIP_TRY(hipEventRecord(tp.a, st));
     }
-    // work items (16 inside voxels of one hand) are dealt to the workgroups with a stride; ~1800 items per 128 samples:
-    // 2048 workgroups up to there (one item each, no second table staging), 4096 beyond (measured at 512 samples:
-    // 1024 / 2048 / 3072 / 4096 workgroups 67.3 / 66.0 / 64.2 / 64.1 us)
-    const int dist_blocks = std::min(4096, std::max(SDF_DIST_BLOCKS, 32 * B));
-    hipLaunchKernelGGL(sdf_dist_kernel, dim3(dist_blocks), dim3(SDF_THREADS), 0, st, ws, g_collect_stats);
+    // persistent grid: as many workgroups as the GPU holds at once; they pull work units from a queue (sdf_collision.h)
+    static int dist_blocks = 0;
+    if (dist_blocks == 0) {
+        int dev = 0, cus = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        dist_blocks = SDF_DIST_WG_PER_CU * (cus > 0 ? cus : 256);
+    }
+    if (g_collect_stats) hipLaunchKernelGGL(sdf_dist_kernel<true>, dim3(dist_blocks), dim3(SDF_THREADS), 0, st, ws);
+    else hipLaunchKernelGGL(sdf_dist_kernel<false>, dim3(dist_blocks), dim3(SDF_THREADS), 0, st, ws);
     if (timed) {
-        // timed pass: (a,b) brackets the launch the refinement really runs.  The kernel is idempotent (same inputs -> same phi), so
-        // it is then launched IHMR_TIMED_REPEAT more times between (b,c): warm repeats (the first launch has written every voxel's
-        // nearest-triangle hint and left the tables in L2), reported beside the in-loop figure, never instead of it
+        // timed pass: (a,b) brackets the launch the refinement really runs (a second launch would find the work cursor spent)
         HIP_TRY(hipEventRecord(tp.b, st));
-        for (int rep = 0; rep < IHMR_TIMED_REPEAT; ++rep)
-            hipLaunchKernelGGL(sdf_dist_kernel, dim3(dist_blocks), dim3(SDF_THREADS), 0, st, ws, g_collect_stats);
         HIP_TRY(hipEventRecord(tp.c, st));
-        tp.reps = IHMR_TIMED_REPEAT;
+        tp.reps = 0;
         g_pending.push_back(tp);
     }
     if (loss)
@@ -284,12 +289,18 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
 }
 
 // seam-B callers hand over (F,3) int32 AoS faces on the device; the SoA copy lives in the workspace tail
-__global__ void faces_to_soa_kernel(const int32_t* __restrict__ aos, int32_t* __restrict__ soa, int* zero8) {
-    if (zero8 && blockIdx.x == 0 && threadIdx.x < SDF_NXCD) zero8[threadIdx.x] = 0;  // inside-voxel counter (8 slots, slot 0 in use)
+__global__ void faces_to_soa_kernel(const int32_t* __restrict__ aos, int32_t* __restrict__ soa, uint32_t* __restrict__ packed, int* zero8) {
+    if (zero8 && blockIdx.x == 0 && threadIdx.x < SDF_NZERO) sdf_zero_counter(zero8, (int)threadIdx.x);  // inside-voxel counters, work cursors
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= NFP) return;
     const int s = f < NF ? f : 0;
-    for (int k = 0; k < 3; ++k) soa[k * NFP + f] = aos[s * 3 + k];
+    uint32_t pk = 0;
+    for (int k = 0; k < 3; ++k) {
+        const int32_t id = min(max(aos[s * 3 + k], 0), NV - 1);      // (an out-of-range id of the caller cannot leave the vertex array)
+        soa[k * NFP + f] = id;
+        pk |= (uint32_t)id << (10 * k);
+    }
+    packed[f] = pk;
 }
 
 extern "C" int ihmr_sdf_collision_ex(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
@@ -303,10 +314,11 @@ extern "C" int ihmr_sdf_collision_ex(const int32_t* faces_right, const int32_t* 
         if (options->loss_divisor > 0.f) ws.loss_div = options->loss_divisor;
     }
     int32_t* soa = (int32_t*)((char*)workspace + sdf_ws_bytes(2 * B));
-    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa, ws.inside_count);
-    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP, (int*)nullptr);
+    uint32_t* pk = (uint32_t*)(soa + 6 * NFP);
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa, pk, ws.inside_count);
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP, pk + NFP, (int*)nullptr);
     VertLayout vl{hand_verts, (long)2 * NV3, (long)NV3};
-    return sdf_launch(vl, soa, soa + 3 * NFP, B, ws, robustifier, loss, per_vert, origin_scale, dval, false, st);
+    return sdf_launch(vl, soa, soa + 3 * NFP, pk, pk + NFP, B, ws, robustifier, loss, per_vert, origin_scale, dval, false, st);
 }
 
 extern "C" int ihmr_sdf_collision(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
@@ -322,10 +334,11 @@ extern "C" int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* fa
     hipStream_t st = (hipStream_t)stream;
     SdfWorkspace ws = sdf_carve(workspace, 2 * B);
     int32_t* soa = (int32_t*)((char*)workspace + sdf_ws_bytes(2 * B));
-    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa, ws.inside_count);
-    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP, (int*)nullptr);
+    uint32_t* pk = (uint32_t*)(soa + 6 * NFP);
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_right, soa, pk, ws.inside_count);
+    hipLaunchKernelGGL(faces_to_soa_kernel, dim3((NFP + 255) / 256), dim3(256), 0, st, faces_left, soa + 3 * NFP, pk + NFP, (int*)nullptr);
     VertLayout vl{hand_verts, (long)2 * NV3, (long)NV3};
-    int rc = sdf_launch(vl, soa, soa + 3 * NFP, B, ws, 0.f, nullptr, nullptr, nullptr, nullptr, true, st);
+    int rc = sdf_launch(vl, soa, soa + 3 * NFP, pk, pk + NFP, B, ws, 0.f, nullptr, nullptr, nullptr, nullptr, true, st);
     if (rc) return rc;
     // workspace order is hand = hnd*B + b; the caller's grid is (B,2,...)
     for (int b = 0; b < B; ++b)
@@ -367,7 +380,8 @@ static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
     ws.align_corners = io->sdf_align_corners ? 1 : 0;
     if (io->sdf_loss_divisor > 0.f) ws.loss_div = io->sdf_loss_divisor;
     VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
-    int rc = sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, B, ws, 0.f, nullptr, nullptr, nullptr, nullptr, false, st);
+    int rc = sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, m->faces_pk, m_left ? m_left->faces_pk : m->faces_pk, B, ws, 0.f,
+                        nullptr, nullptr, nullptr, nullptr, false, st);
     if (rc) return rc;
     // collision sampling (loss_batch[2], masked by hand type; gradient -> g_verts) and the joint losses in one launch
     hipLaunchKernelGGL(opt_sample_loss_kernel, dim3(B), dim3(SDF_SAMPLE_THREADS), 0, st, *io, wk, B, w, vl, ws, need_cam);
@@ -489,7 +503,7 @@ extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, c
     hipStream_t st = (hipStream_t)stream;
     OptWork wk = opt_carve(io->workspace, B);
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B, true);
-    HIP_TRY(hipMemsetAsync(ws.stats, 0, 64, st));
+    HIP_TRY(hipMemsetAsync(ws.stats, 0, 128, st));
     ihmr_kernel_timer* keep = g_timer;
     g_timer = nullptr;
     g_collect_stats = 1;
@@ -503,21 +517,21 @@ extern "C" int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, c
 }
 
 // diagnostics of the fused loop: enable = 1 zeroes the SDF work counters and switches them on for every launch recorded or issued
-// afterwards (a stage graph captured while they are on keeps counting); enable = 0 synchronises, copies the eight counters out
+// afterwards (a stage graph captured while they are on keeps counting); enable = 0 synchronises, copies the sixteen counter slots out
 // (ray tests, exact distances, inside voxels, needed voxels, bounding-sphere tests, voxels answered from candidate lists, voxels
-// of such hands handed to the full search, voxels whose lists were rebuilt) and switches them off.
-extern "C" int ihmr_opt_sdf_counters(const ihmr_opt_io* io, int B, unsigned long long* out8, int enable) {
+// of such hands handed to the full search, voxels whose lists were rebuilt, plane + circle tests; the rest unused) and switches them off.
+extern "C" int ihmr_opt_sdf_counters(const ihmr_opt_io* io, int B, unsigned long long* out16, int enable) {
     if (!io || B <= 0) return -1;
     SdfWorkspace ws = sdf_carve(opt_carve(io->workspace, B).sdf_ws, 2 * B, true);
     HIP_TRY(hipDeviceSynchronize());
     if (enable) {
-        HIP_TRY(hipMemset(ws.stats, 0, 64));
+        HIP_TRY(hipMemset(ws.stats, 0, 128));
         g_collect_stats = 1;
         return 0;
     }
     g_collect_stats = 0;
-    if (!out8) return -1;
-    HIP_TRY(hipMemcpy(out8, ws.stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (!out16) return -1;
+    HIP_TRY(hipMemcpy(out16, ws.stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -826,5 +840,16 @@ extern "C" int ihmr_flush_kernel_timer(void) {
     return 0;
 }
 
+
+#ifdef SDF_STAMPS
+// experiment builds only (scripts/sdf_stamps.py): zero = 1 clears the per-wave phase sums, zero = 0 copies them to the host (4096 * 4 * 8 int64)
+extern "C" int ihmr_debug_stamps(long long* host, int zero) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (zero) { void* p; HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_sdf_stamps))); HIP_TRY(hipMemset(p, 0, sizeof(long long) * 4096 * 4 * 8)); return 0; }
+    HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sdf_stamps), sizeof(long long) * 4096 * 4 * 8));
+    HIP_TRY(hipMemcpyFromSymbol(host + 4096 * 4 * 8, HIP_SYMBOL(g_sdf_span), sizeof(long long) * 4096 * 4 * 4));
+    return 0;
+}
+#endif
 
 extern "C" const char* ihmr_version(void) { return "ihmr_hip 0.1 (gfx950)"; }

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_op
     __shared__ float sk[2][SK_STRIDE];
     const int b = blockIdx.x, tid = threadIdx.x;
     // the collision kernels of this iteration append to the inside-voxel counter: start it at zero
-    if (b == 0 && tid >= 192 && tid < 192 + SDF_NXCD) inside_count[tid - 192] = 0;
+    if (b == 0 && tid >= 192 && tid < 192 + SDF_NZERO) sdf_zero_counter(inside_count, tid - 192);
     if (st.reset_state && tid < OPT_NPARAM) { io.adam_m[b * OPT_NPARAM + tid] = 0.f; io.adam_v[b * OPT_NPARAM + tid] = 0.f; }
     if (st.mask && tid < OPT_NPARAM) { opt_snapshot_losses(io, B, st, b, tid); opt_param_apply(io, wk, B, st, b, tid); }
     __syncthreads();   // the updated parameters are read back below by other threads of this workgroup

@@ -34,10 +34,7 @@
 #define SDF_PREP_SMALL_MAX_HANDS 128     // up to this many hands per launch (one batch of 64) the 1024-thread form is used; at 256 hands (IHMR-MLP, batch 128) the 512-thread form is 11 % faster end to end
 #define SDF_NCOL (SDF_G * SDF_G)   // 1024 columns (k,j)
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
-#ifndef SDF_DIST_BLOCKS
-#define SDF_DIST_BLOCKS 2048          // smallest grid of sdf_dist_kernel (a multiple of 16); 4 workgroups (40 KB LDS, <= 128 VGPRs) per CU
-#endif
-#define SDF_SURV_CAP 512             // LDS slots per wave for the triangles surviving the sphere cull (typically ~40)
+#define SDF_DIST_WG_PER_CU 4          // sdf_dist_kernel: 40 KB LDS, <= 128 VGPRs; its grid is persistent: this many workgroups per CU
 #ifndef SDF_ITEM_RUN
 #define SDF_ITEM_RUN 2
 #endif
@@ -64,8 +61,9 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     int B;                     // hands [0, B) are right hands, [B, 2B) left hands
     float* phi;                // [H][32768]  (only the voxels a sample reads are defined)
     unsigned* inside_list;     // [xcd_cap] inside voxels of the whole batch: (hand << 16) | voxel id, 16-aligned run per hand
-    int* inside_count;         // [8] (slot 0 in use)
-    unsigned long long* stats; // [8] optional work counters
+    int* inside_count;         // [SDF_NCTR] [0] entries in inside_list, [1] in inside_list_a; [SDF_CURSOR] the distance kernel's work cursor, on a
+                               //            128-byte line of its own (the counters are read while the cursor is hammered)
+    unsigned long long* stats; // [16] optional work counters (ihmr_opt_sdf_counters)
     int xcd_cap;
     // candidate lists of the fused refinement loop (list_mode 0 = off: single-shot callers)
     float* vn_ref;             // [H][2334]  normalised vertices of the hand when its lists were built
@@ -75,14 +73,18 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     unsigned* lmap;            // [H][32768] voxel -> its list | (the triangle that was nearest the last time it was evaluated) << 16
                                //            (defined where lbits is set)
     unsigned short* lists;     // [H][SDF_LCAP_V][SDF_LCAP_L] triangle ids
-    unsigned* inside_list_a;   // [xcd_cap] inside voxels of the hands whose lists are valid (unpadded run per hand; inside_count[1])
+    unsigned* inside_list_a;   // [xcd_cap] inside voxels of the hands whose lists are valid (aligned run per hand; inside_count[1])
     int list_mode, force_rebuild;
     // conventions of the upstream module that nothing in the reference pins (ihmr_sdf_options; defaults = DESIGN.md section 4)
     int align_corners;         // grid_sample(align_corners): 0 = False (the default of the reference's pinned torch 1.6.0)
     float loss_div;            // loss[b] = sum of the 1556 sampled values / loss_div (4 = num_hands^2 of the parent project)
 };
 
-__host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)H * (SDF_NVOX + SDF_ITEM); }   // one batch-wide list
+#define SDF_NCTR 64
+#define SDF_CURSOR 32
+#define SDF_NZERO 3                  // counters that have to be zero before the prep kernel: sdf_zero_counter(c, i), i < SDF_NZERO
+__device__ __forceinline__ void sdf_zero_counter(int* c, int i) { c[i < 2 ? i : SDF_CURSOR] = 0; }
+__host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)H * (SDF_NVOX + 64); }   // one batch-wide list
 
 #define SDF_LCAP_V 1024              // candidate lists per hand (one per inside voxel, in the order of the hand's run at build time)
 #define SDF_LCAP_L 192               // triangles per list (three 64-lane chunks; a voxel whose list would be longer gets none)
@@ -101,7 +103,7 @@ __host__ __device__ inline size_t sdf_ws_bytes(int H, bool lists = false) {
     n += (size_t)H * SDF_NV4 * sizeof(float4);      // vn4
     n += (size_t)H * SDF_NVOX * sizeof(float);
     n += sdf_xcd_cap(H) * sizeof(unsigned);
-    n += 128 + 256;
+    n += 128 + SDF_NCTR * 4 + 256;
     return (n + 255) & ~(size_t)255;
 }
 
@@ -115,8 +117,8 @@ static inline SdfWorkspace sdf_carve(void* ws, int H, bool lists = false) {
     w.fpk[0] = w.fpk[1] = nullptr;
     w.B = H / 2;
     w.phi = (float*)p; p += (size_t)H * SDF_NVOX * sizeof(float);
-    w.stats = (unsigned long long*)p; p += 64;
-    w.inside_count = (int*)p; p += 64;
+    w.stats = (unsigned long long*)p; p += 128;
+    w.inside_count = (int*)p; p += SDF_NCTR * 4;
     w.xcd_cap = (int)sdf_xcd_cap(H);
     w.inside_list = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
     w.vn_ref = nullptr; w.hmode = nullptr; w.run_start = nullptr; w.lbits = nullptr; w.lmap = nullptr; w.lists = nullptr;
@@ -443,7 +445,8 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     float4* sph = ws.sph + (size_t)H * NFP;
     unsigned* nrm = ws.nrm + (size_t)H * NFP;
     unsigned long long st_tests = 0;
-#pragma unroll
+    // (two loops over the lane's triangles -- records, then ray parity: together they would not fit the 64 registers of 8 waves / SIMD)
+#pragma unroll 1
     for (int it = 0; it < TRI_IT; ++it) {
         const int f = tid + it * PT;
         if (f >= NFP) break;
@@ -453,8 +456,6 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         const float c[3] = {vn[3 * fc], vn[3 * fc + 1], vn[3 * fc + 2]};
         const float e1x = bb[0] - a[0], e1y = bb[1] - a[1], e1z = bb[2] - a[2];
         const float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
-        const float det = __builtin_fmaf(e1z, e2y, -(e1y * e2z));
-        const bool ok = f < NF && fabsf(det) >= 1e-12f;
         // ---- record for the distance kernel: minimum enclosing circle (centre m on the triangle, conservative radius) + normal.
         //      Used for conservative culling only -- the minimum itself is evaluated exactly from the corners
         {
@@ -499,6 +500,19 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
             sph[f] = make_float4(real ? mx : 1e18f, real ? my : 1e18f, real ? mz : 1e18f, real ? sqrtf(r2) * 1.0001f + 1e-6f : 0.0f);
             nrm[f] = real ? nw : SDF_NRM_NOPLANE;
         }
+    }
+#pragma unroll
+    for (int it = 0; it < TRI_IT; ++it) {
+        const int f = tid + it * PT;
+        if (f >= NFP) break;
+        const int fa = fidx[it][0], fb = fidx[it][1], fc = fidx[it][2];
+        const float a[3] = {vn[3 * fa], vn[3 * fa + 1], vn[3 * fa + 2]};
+        const float bb[3] = {vn[3 * fb], vn[3 * fb + 1], vn[3 * fb + 2]};
+        const float c[3] = {vn[3 * fc], vn[3 * fc + 1], vn[3 * fc + 2]};
+        const float e1x = bb[0] - a[0], e1y = bb[1] - a[1], e1z = bb[2] - a[2];
+        const float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
+        const float det = __builtin_fmaf(e1z, e2y, -(e1y * e2z));
+        const bool ok = f < NF && fabsf(det) >= 1e-12f;
         if (!ok) continue;                                   // degenerate in yz: the +x ray never counts it
         const float inv = 1.0f / det;
         const bool tri_safe = sdf_ray_tri_safe(e1x, e1y, e1z, e2x, e2y, e2z, inv);
@@ -645,97 +659,197 @@ __device__ __forceinline__ float sdf_point_tri_dist2(const float* a, const float
     return DOT3(dx, dy, dz, dx, dy, dz);
 }
 
+// ------------------------------------------------------------------------------------- distance kernel: shared pieces
+// Both searches of sdf_dist_kernel work the same way on a wave's current voxels (slots): conservative culling against the hand's
+// table in LDS -> dense (slot, triangle) pairs in the wave's queue -> sdf_refine_pairs (plane + circle bound) -> sdf_exact_pairs
+// (closest-point distance, 64-bit LDS atomic min on (distance bits, triangle)).  `best[slot]` always holds a distance some
+// triangle attains or exceeds (its upper bound), so every cull against it is exact: a culled triangle cannot be the minimum.
+typedef float sdf_v2f __attribute__((ext_vector_type(2)));
+#define SDF_QCAP 512                                   // pairs a wave queues before it evaluates them
+#define SDF_VSLOTS 8                                   // voxels a wave works on at a time (full search 4, list search 8)
+#define SDF_NRM_N 1540                                 // normals staged to LDS (NF rounded up to a multiple of 4)
+#define SDF_WAVE_LDS (SDF_QCAP * 4 + SDF_VSLOTS * 8 + SDF_VSLOTS * 2)
+#define SDF_DIST_LDS (NFP * 16 + SDF_NRM_N * 4 + (SDF_THREADS / WAVE) * SDF_WAVE_LDS)
+struct SdfWaveLds {
+    unsigned* q;                  // [SDF_QCAP] (slot << 16) | triangle
+    unsigned long long* best;     // [SDF_VSLOTS] (squared distance bits << 32) | triangle   (bits of a float >= 0: unsigned order = float order)
+    unsigned short* vox;          // [SDF_VSLOTS] voxel id of the slot
+};
+__device__ __forceinline__ SdfWaveLds sdf_wave_lds(char* smem, int wave) {
+    char* p = smem + NFP * 16 + SDF_NRM_N * 4 + wave * SDF_WAVE_LDS;
+    return SdfWaveLds{reinterpret_cast<unsigned*>(p), reinterpret_cast<unsigned long long*>(p + SDF_QCAP * 4),
+                      reinterpret_cast<unsigned short*>(p + SDF_QCAP * 4 + SDF_VSLOTS * 8)};
+}
+__device__ __forceinline__ void sdf_vox_centre(int id, float& x, float& y, float& z) {
+    x = (float)(2 * (id & 31) + 1) / (float)SDF_G - 1.0f;
+    y = (float)(2 * ((id >> 5) & 31) + 1) / (float)SDF_G - 1.0f;
+    z = (float)(2 * (id >> 10) + 1) / (float)SDF_G - 1.0f;
+}
+// LDS hand-off between the lanes of one wave (DS operations of a wave execute in order; the fences only pin the compiler)
+#define SDF_WAVE_SYNC()                                              \
+    do {                                                             \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       \
+        __builtin_amdgcn_wave_barrier();                             \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       \
+    } while (0)
+
+// Phase stamps (experiment builds only: -DSDF_STAMPS=1 list search, =2 full search; scripts/sdf_stamps.py): shader-clock time per
+// phase of a work item, summed per wave into the spare counter slots 9..15
+#ifdef SDF_STAMPS
+#define SDF_TK(...) __VA_ARGS__
+#define SDF_STAMP() ((long long)__builtin_readcyclecounter())
+__device__ long long g_sdf_stamps[4096 * 4][8];       // per (workgroup, wave) sums, plain stores: no atomics in a stamped launch
+__device__ long long g_sdf_span[4096 * 4][4];         // entry / exit stamp, XCC id, items of the LAST launch (either search)
+#else
+#define SDF_TK(...)
+#define SDF_STAMP() 0ll
+#endif
+
+// Plane + circle lower bound for the queued pairs (the sphere cull leaves ~30 triangles per voxel, this ~9; one LDS gather and
+// ~35 instructions per pair against a global gather and ~150 for the exact distance).  A triangle lies in its plane inside the
+// circle (m, R) of its record, so for every point q of it |p - q|^2 = h^2 + |P - q|^2 >= h^2 + max(rho - R, 0)^2 with h the
+// distance of p from the plane, P its foot point and rho = |P - m| = sqrt(|p - m|^2 - h^2).  h is evaluated from the 10-bit
+// normal: |h' - h| <= EN * |p - m|_1 + EM (SDF_NRM_EN: rounding of the normal's components; SDF_NRM_EM: m off the plane by
+// rounding), so hlo = max(|h'| - e, 0) <= |h| <= |h'| + e = hhi and lb^2 = hlo^2 + max(sqrt(max(d2 - hhi^2, 0)) - R, 0)^2 is a
+// lower bound; a near-degenerate triangle has no normal (SDF_NRM_NOPLANE) and keeps the sphere bound.  Pairs with lb above the
+// slot's upper bound are dropped, the rest compacted in place.  Returns the new count.
+__device__ __forceinline__ int sdf_refine_pairs(const float4* tab_s, const unsigned* nrm_s, const SdfWaveLds& w, int npair, int lane) {
+    int nout = 0;
+    for (int base = 0; base < npair; base += WAVE) {
+        const bool live = base + lane < npair;
+        const unsigned pr = live ? w.q[base + lane] : 0u;
+        const int g = (int)(pr >> 16), f = (int)(pr & 0xffffu);
+        const float4 sp = tab_s[f];
+        const unsigned nw = nrm_s[f < SDF_NRM_N ? f : 0];
+        const int id = (int)w.vox[g];
+        const float ub2 = __uint_as_float((unsigned)(w.best[g] >> 32));
+        float px, py, pz;
+        sdf_vox_centre(id, px, py, pz);
+        const float dx = px - sp.x, dy = py - sp.y, dz = pz - sp.z;
+        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        const bool plane = (nw & SDF_NRM_NOPLANE) == 0u;
+        const float nx = (float)((int)(nw << 22) >> 22), ny = (float)((int)(nw << 12) >> 22), nz = (float)((int)(nw << 2) >> 22);
+        const float h = plane ? fabsf(__builtin_fmaf(nz, dz, __builtin_fmaf(ny, dy, nx * dx))) * (1.0f / 511.0f) : 0.0f;
+        const float e = plane ? __builtin_fmaf(SDF_NRM_EN, fabsf(dx) + fabsf(dy) + fabsf(dz), SDF_NRM_EM) : 0.0f;
+        const float hlo = fmaxf(h - e, 0.0f), hhi = h + e;
+        const float rho = sqrtf(fmaxf(__builtin_fmaf(-hhi, hhi, d2), 0.0f)) * 0.9999f;
+        const float rlo = fmaxf(rho - sp.w, 0.0f);
+        const float lb2 = __builtin_fmaf(rlo, rlo, hlo * hlo);
+        const float ub = sqrtf(ub2) * 1.0001f + 1e-6f;
+        const bool keep = live && !(lb2 > ub * ub * 1.00001f);
+        const unsigned long long m = __ballot(keep);
+        const int pos = nout + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (keep) w.q[pos] = pr;            // pos <= base + lane: never ahead of an entry that is still to be read
+        nout += __popcll(m);
+    }
+    return nout;
+}
+
+// Exact closest-point distances of the queued pairs, 64 per round; a triangle's corners are gathered from the hand's normalised
+// vertices through the packed face table.  Software pipeline, two rounds deep: the corners of round r + 1 and the (pair, face) of
+// round r + 2 are requested before the distances of round r are computed.
+__device__ __forceinline__ void sdf_exact_pairs(const float4* __restrict__ vn4, const unsigned* __restrict__ fpk, const SdfWaveLds& w,
+                                                int npair, int lane) {
+    if (npair <= 0) return;
+    unsigned pr0 = lane < npair ? w.q[lane] : 0u;
+    unsigned pk0 = fpk[pr0 & 0xffffu];
+    unsigned pr1 = WAVE + lane < npair ? w.q[WAVE + lane] : 0u;
+    unsigned pk1 = fpk[pr1 & 0xffffu];
+    float4 A = vn4[pk0 & 1023u], Bv = vn4[(pk0 >> 10) & 1023u], Cv = vn4[pk0 >> 20];
+    for (int base = 0; base < npair; base += WAVE) {
+        const unsigned pr = pr0;
+        const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
+        const bool live = base + lane < npair;
+        pr0 = pr1;
+        if (base + WAVE < npair) { A = vn4[pk1 & 1023u]; Bv = vn4[(pk1 >> 10) & 1023u]; Cv = vn4[pk1 >> 20]; }
+        if (base + 2 * WAVE < npair) {
+            const int i2 = base + 2 * WAVE + lane;
+            pr1 = i2 < npair ? w.q[i2] : 0u;
+            pk1 = fpk[pr1 & 0xffffu];
+        }
+        if (live) {
+            const int g = (int)(pr >> 16);
+            float qx, qy, qz;
+            sdf_vox_centre((int)w.vox[g], qx, qy, qz);
+            atomicMin(&w.best[g], ((unsigned long long)__float_as_uint(sdf_point_tri_dist2(a, b, c, qx, qy, qz)) << 32) | (pr & 0xffffu));
+        }
+    }
+}
+
+// the hand's table -> LDS (asynchronous; close with SDF_STAGE_CLOSE)
+__device__ __forceinline__ void sdf_stage_table(const SdfWorkspace& ws, int H, char* smem) {
+    sdf_stage_async(ws.sph + (size_t)H * NFP, smem, NFP);
+    sdf_stage_async(ws.nrm + (size_t)H * NFP, smem + NFP * 16, SDF_NRM_N / 4);
+}
+
+// work counters / phase stamps of one workgroup's pass over its work units (registers; flushed once at the end of the kernel)
+#define SDF_CNT(...) do { if (STATS) { __VA_ARGS__; } } while (0)      // (STATS: template parameter of the distance kernel)
+struct SdfAcc {
+    unsigned dist = 0, full = 0, build = 0, fresh = 0, ref = 0, sph = 0, vox = 0;      // (per workgroup and launch: 32 bits are plenty)
+    SDF_TK(long long tk[7] = {0, 0, 0, 0, 0, 0, 0};)      // items, front, (full: sphere passes), (list: walk), refine, exact, -
+};
+
 // ------------------------------------------------------------------------------------- distance: full search
 // (one of the two searches of sdf_dist_kernel, below; grid-strided over its slots.)  The inside voxels of
 // the whole batch sit in one list (balanced work matters more here than L2 affinity: the per-sample counts vary
 // by 3x).  A work item = SDF_ITEM (16) consecutive list entries = inside voxels of ONE hand: the workgroup stages
-// that hand's 1538 bounding spheres in LDS (32 KB), then each wave takes 4 voxels, two at a time through the
-// sphere passes (lanes across triangles, packed fp32 on the voxel pair): upper bound = nearest centroid, cull,
-// scan-compacted survivors of the wave's four voxels as dense (voxel, triangle) pairs, exact closest-point distance, 64-bit LDS
-// atomic min on (distance bits, triangle).  While a hand's candidate lists are being (re)built it also writes them.
-typedef float sdf_v2f __attribute__((ext_vector_type(2)));
-#define SDF_FULL_LDS (NFP * 20 + (SDF_THREADS / WAVE) * (SDF_SURV_CAP * 4 + 4 * 8))
-__device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int collect_stats, int slot, int nslot, char* smem) {
-    float4* const sph_s = reinterpret_cast<float4*>(smem);                                              // [NFP]
-    float* const rad_s = reinterpret_cast<float*>(smem + NFP * 16);                                     // [NFP]
-    unsigned (*const pairs_s)[SDF_SURV_CAP] = reinterpret_cast<unsigned (*)[SDF_SURV_CAP]>(smem + NFP * 20);   // (voxel slot << 16) | triangle: survivors of the wave's 4 voxels
-    unsigned long long (*const best_s)[4] =                // running min of (squared distance bits << 32) | triangle (bits of a float >= 0: uint order)
-        reinterpret_cast<unsigned long long (*)[4]>(smem + NFP * 20 + (SDF_THREADS / WAVE) * SDF_SURV_CAP * 4);
+// that hand's table in LDS (32 KB), then each wave takes 4 voxels, two at a time through the
+// sphere passes (lanes across triangles, packed fp32 on the voxel pair): upper bound = nearest circle centre (a point of its
+// triangle), sphere cull, scan-compacted survivors of the wave's four voxels as dense pairs -> refine -> exact (above).
+// While a hand's candidate lists are being (re)built it also writes them.
+// One work item of the full search: `item` = 16 consecutive entries of inside_list (one hand); half = -1: the whole item (four
+// voxels per wave, two passes), 0 / 1: one half of it (two workgroups share the item when there are few: two voxels per wave = ONE
+// pass -- a small launch is as long as its longest item).  curH = the hand whose table the workgroup's LDS holds.
+template <bool STATS>
+__device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, int half, char* smem, int& curH, SdfAcc& acc) {
+    const float4* const sph_s = reinterpret_cast<const float4*>(smem);                                  // [NFP] (centre, radius)
+    const unsigned* const nrm_s = reinterpret_cast<const unsigned*>(smem + NFP * 16);                   // [SDF_NRM_N]
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
-    const int total = ws.inside_count[0];
+    const SdfWaveLds w = sdf_wave_lds(smem, wave);
     const unsigned* glist = ws.inside_list;
-    unsigned* mypairs = pairs_s[wave];
-    unsigned long long* mybest = best_s[wave];
-    int curH = -1;
-    unsigned long long st_dist = 0, st_full = 0, st_build = 0, st_new = 0;
-    // a workgroup takes SDF_ITEM_RUN consecutive items at a time: consecutive items mostly belong to one hand, whose table is then
-    // staged once for the run
-    // (only when there are more items than workgroups: a single 64-sample batch has ~900 items for 2048 workgroups, one each)
-    // With few items (one batch of 64: ~200 items for 1024 workgroups) two workgroups share an item, a wave takes two voxels = ONE
-    // pass instead of two: the launch is as long as its longest item.
-    const int nitems = (total + SDF_ITEM - 1) / SDF_ITEM;
-    const int run = nitems > nslot ? SDF_ITEM_RUN : 1;
-    const int split = 2 * nitems <= nslot ? 2 : 1;
-    const int vpw = SDF_ITEM / 4 / split;                  // voxels per wave
-    for (int item0 = (slot / split) * run; item0 < nitems; item0 += (nslot / split) * run)
-    for (int item = item0; item < item0 + run && item < nitems; ++item) {
+    unsigned& st_dist = acc.dist; unsigned& st_full = acc.full; unsigned& st_build = acc.build;
+    unsigned& st_new = acc.fresh; unsigned& st_ref = acc.ref;
+    SDF_TK(long long* const tk = acc.tk;)
+    const int vpw = half < 0 ? SDF_ITEM / 4 : SDF_ITEM / 8;                  // voxels per wave
+    {
+        SDF_TK(const long long tk0 = SDF_STAMP();)
         const unsigned ent_l = lane < SDF_ITEM ? glist[item * SDF_ITEM + lane] : 0xffffffffu;
         const int H = (int)((unsigned)__builtin_amdgcn_readlane((int)ent_l, 0) >> 16);   // entry 0 of an item is always valid
-        const int e0 = (split == 2 ? (slot & 1) * (SDF_ITEM / 2) : 0) + wave * vpw;     // this wave's first entry of the item
-        if (split == 2 && (slot & 1) && (unsigned)__builtin_amdgcn_readlane((int)ent_l, SDF_ITEM / 2) == 0xffffffffu) continue;   // (padding)
+        const int e0 = (half > 0 ? SDF_ITEM / 2 : 0) + wave * vpw;     // this wave's first entry of the item
+        if (half > 0 && (unsigned)__builtin_amdgcn_readlane((int)ent_l, SDF_ITEM / 2) == 0xffffffffu) return;   // (padding; uniform)
         // 0: the hand's candidate lists are being (re)built -- by this search; 1: they are valid and these voxels have none; -1: no
         // candidate lists (single-shot callers)
         const int mode = ws.list_mode ? ws.hmode[H] : -1;
         const int run_start = ws.list_mode ? ws.run_start[H] : 0;
         if (H != curH) {             // uniform over the workgroup (same item for all waves)
             SDF_LDS_BARRIER();       // (the previous table's readers are done; LDS traffic only)
-            sdf_stage_async(ws.sph + (size_t)H * NFP, reinterpret_cast<char*>(sph_s), NFP);
-            sdf_stage_async(ws.rad + (size_t)H * NFP, reinterpret_cast<char*>(rad_s), NFP / 4);
+            sdf_stage_table(ws, H, smem);
             SDF_STAGE_CLOSE();
             curH = H;
         }
-        const float4* abc = ws.abc + (size_t)H * NFP * 3;
-        // The survivors of the wave's (up to) four voxels are evaluated together, one (voxel, triangle) pair per lane: ~38 per
-        // voxel fill 59 % of a 64-lane round, the ~150 of four voxels fill three rounds of four.  Minimum per voxel through LDS
-        // atomics on the float bits (squared distances are >= +0, so unsigned order = float order; a NaN sorts above +inf
-        // and is ignored, as fminf does).
-        if (lane < 4) mybest[lane] = 0x7f800000ull << 32;
+        const float4* vn4 = ws.vn4 + (size_t)H * SDF_NV4;
+        const unsigned* fpk = ws.fpk[H >= ws.B ? 1 : 0];
         unsigned ent4[4];             // this wave's four list entries (uniform)
 #pragma unroll
         for (int q = 0; q < 4; ++q) ent4[q] = q < vpw ? (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + q) : 0xffffffffu;
+        if (lane < 4) {
+            w.vox[lane] = (unsigned short)((lane == 0 ? ent4[0] : (lane == 1 ? ent4[1] : (lane == 2 ? ent4[2] : ent4[3]))) & 0xffffu);
+            w.best[lane] = (0x7f800000ull << 32) | 0xffffull;
+        }
         int npair = 0;
+        SDF_TK(const long long tk1 = SDF_STAMP(), tk_r0 = tk[4] + tk[5];)
         auto flush = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // software pipeline: the next round's triangle is requested before this round's distance is computed
-            unsigned pr_n = lane < npair ? mypairs[lane] : 0u;
-            float4 A_n = abc[3 * (int)(pr_n & 0xffffu)], B_n = abc[3 * (int)(pr_n & 0xffffu) + 1], C_n = abc[3 * (int)(pr_n & 0xffffu) + 2];
-            for (int base = 0; base < npair; base += WAVE) {
-                const unsigned pr = pr_n;
-                const float4 A = A_n, Bv = B_n, Cv = C_n;
-                const bool live = base + lane < npair;
-                const int nidx = base + WAVE + lane;
-                if (base + WAVE < npair) {
-                    pr_n = nidx < npair ? mypairs[nidx] : 0u;
-                    const int fn = (int)(pr_n & 0xffffu);
-                    A_n = abc[3 * fn], B_n = abc[3 * fn + 1], C_n = abc[3 * fn + 2];
-                }
-                if (live) {
-                    const int vs = (int)(pr >> 16);
-                    const int id = (int)((vs == 0 ? ent4[0] : (vs == 1 ? ent4[1] : (vs == 2 ? ent4[2] : ent4[3]))) & 0xffffu);
-                    const float qx = (float)(2 * (id & 31) + 1) / (float)SDF_G - 1.0f;
-                    const float qy = (float)(2 * ((id >> 5) & 31) + 1) / (float)SDF_G - 1.0f;
-                    const float qz = (float)(2 * (id >> 10) + 1) / (float)SDF_G - 1.0f;
-                    const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
-                    atomicMin(&mybest[vs], ((unsigned long long)__float_as_uint(sdf_point_tri_dist2(a, b, c, qx, qy, qz)) << 32) | (pr & 0xffffu));
-                }
-            }
-            st_dist += (unsigned long long)(lane == 0 ? npair : 0);
+            SDF_WAVE_SYNC();
+            SDF_TK(const long long f0 = SDF_STAMP();)
+            SDF_CNT(st_ref += (unsigned)(lane == 0 ? npair : 0));
+            npair = sdf_refine_pairs(sph_s, nrm_s, w, npair, lane);
+            SDF_WAVE_SYNC();
+            SDF_TK(const long long f1 = SDF_STAMP();)
+            sdf_exact_pairs(vn4, fpk, w, npair, lane);
+            SDF_CNT(st_dist += (unsigned)(lane == 0 ? npair : 0));
             npair = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            SDF_WAVE_SYNC();
+            SDF_TK(const long long f2 = SDF_STAMP(); tk[4] += f1 - f0; tk[5] += f2 - f1;)
         };
         int nmine = 0;    // voxels of this wave
         // ---- the full search for a pair of voxels (packed fp32): table read once for both
@@ -746,7 +860,7 @@ __device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int coll
             const sdf_v2f PY = {(float)(2 * ((id0 >> 5) & 31) + 1) / (float)SDF_G - 1.0f,
                                 (float)(2 * ((id1 >> 5) & 31) + 1) / (float)SDF_G - 1.0f};
             const sdf_v2f PZ = {(float)(2 * (id0 >> 10) + 1) / (float)SDF_G - 1.0f, (float)(2 * (id1 >> 10) + 1) / (float)SDF_G - 1.0f};
-            // d2[t] = |p - c|^2 (packed fp32 on the voxel pair); used for conservative culling only, the minimum over the survivors
+            // d2[t] = |p - m|^2 (packed fp32 on the voxel pair); used for conservative culling only, the minimum over the survivors
             // is computed exactly afterwards
             sdf_v2f d2[NFP / WAVE];
             sdf_v2f ub2 = {INFINITY, INFINITY};
@@ -757,15 +871,17 @@ __device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int coll
                 d2[t] = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
                 ub2 = __builtin_elementwise_min(ub2, d2[t]);
             }
-            // the centroid is a point of the triangle: dist <= |p - centroid|
+            // the circle centre is a point of its triangle: dist <= |p - m|
             const float ub_a = sqrtf(wave_reduce_min(ub2.x)) * 1.0001f + 1e-6f;
             const float ub_b = sqrtf(wave_reduce_min(ub2.y)) * 1.0001f + 1e-6f;
             const sdf_v2f ub_lim = {ub_a, ub_b};
+            // the slots' upper bound for the refine pass (no triangle id yet: any exact distance will be below it)
+            if (lane < nvox) w.best[vs0 + lane] = ((unsigned long long)__float_as_uint(lane ? ub_b * ub_b : ub_a * ub_a) << 32) | 0xffffull;
             unsigned keep_a = 0, keep_b = 0, list_a = 0, list_b = 0;
             if (mode == 0) {   // lists are being built: the same cull with the bound widened by twice the motion slack
 #pragma unroll
                 for (int t = 0; t < NFP / WAVE; ++t) {
-                    const float r = rad_s[lane + WAVE * t];
+                    const float r = sph_s[lane + WAVE * t].w;
                     const sdf_v2f lim = ub_lim + r;
                     const sdf_v2f lim2 = lim * lim * sdf_v2f{1.00001f, 1.00001f};
                     const sdf_v2f limw = lim + sdf_v2f{2.0f * SDF_LIST_SLACK, 2.0f * SDF_LIST_SLACK};
@@ -778,10 +894,10 @@ __device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int coll
             } else {
 #pragma unroll
                 for (int t = 0; t < NFP / WAVE; ++t) {
-                    const float r = rad_s[lane + WAVE * t];
+                    const float r = sph_s[lane + WAVE * t].w;
                     const sdf_v2f lim = ub_lim + r;
                     const sdf_v2f lim2 = lim * lim * sdf_v2f{1.00001f, 1.00001f};
-                    // cull iff |p - centroid| - radius > upper bound (exact: such a triangle cannot be the minimum)
+                    // cull iff |p - m| - radius > upper bound (exact: such a triangle cannot be the minimum)
                     keep_a |= !(d2[t].x > lim2.x) ? (1u << t) : 0u;
                     keep_b |= !(d2[t].y > lim2.y) ? (1u << t) : 0u;
                 }
@@ -792,25 +908,26 @@ __device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int coll
                 int cnt;
                 const int mine = __popc(keepmask);
                 int off = wave_incl_scan(mine, cnt) - mine;
-                if (cnt <= SDF_SURV_CAP) {
-                    if (npair + cnt > SDF_SURV_CAP) flush();
+                if (cnt <= SDF_QCAP) {
+                    if (npair + cnt > SDF_QCAP) flush();
                     off += npair;
                     while (keepmask) {
                         const int t = __ffs((int)keepmask) - 1;
                         keepmask &= keepmask - 1;
-                        mypairs[off++] = ((unsigned)vs << 16) | (unsigned)(lane + WAVE * t);
+                        w.q[off++] = ((unsigned)vs << 16) | (unsigned)(lane + WAVE * t);
                     }
                     npair += cnt;
-                } else {   // (degenerate geometry) more survivors than list slots: every lane walks its own triangles
+                } else {   // (degenerate geometry) more survivors than queue slots: every lane walks its own triangles
                     const float px = v ? PX.y : PX.x, py = v ? PY.y : PY.x, pz = v ? PZ.y : PZ.x;
                     while (keepmask) {
                         const int t = __ffs((int)keepmask) - 1;
                         keepmask &= keepmask - 1;
                         const int f = lane + WAVE * t;
-                        const float4 A = abc[3 * f], Bv = abc[3 * f + 1], Cv = abc[3 * f + 2];
+                        const unsigned pk = fpk[f];
+                        const float4 A = vn4[pk & 1023u], Bv = vn4[(pk >> 10) & 1023u], Cv = vn4[pk >> 20];
                         const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
-                        atomicMin(&mybest[vs], ((unsigned long long)__float_as_uint(sdf_point_tri_dist2(a, b, c, px, py, pz)) << 32) | (unsigned)f);
-                        st_dist += 1;
+                        atomicMin(&w.best[vs], ((unsigned long long)__float_as_uint(sdf_point_tri_dist2(a, b, c, px, py, pz)) << 32) | (unsigned)f);
+                        SDF_CNT(st_dist += 1);
                     }
                 }
                 if (mode == 0) {
@@ -841,7 +958,7 @@ __device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int coll
                 ++nmine;
             }
         };
-        // the wave's (up to four) voxels as two jobs of the search (ONE call site: the routine is large)
+        // the wave's (up to) four voxels as two jobs of the search (ONE call site: the routine is large)
         unsigned j_ent0[2], j_ent1[2];
         int nj = 0;
 #pragma unroll
@@ -851,79 +968,59 @@ __device__ __forceinline__ void sdf_full_search(const SdfWorkspace& ws, int coll
             if (j_ent0[k] != 0xffffffffu) nj = k + 1;     // padding sits only at the tail of a hand's run
         }
         const int lidx_base = mode == 0 ? item * SDF_ITEM - run_start + e0 : 0;
+        SDF_WAVE_SYNC();
 #pragma unroll 1
         for (int k = 0; k < nj; ++k)
             pair_pass(k == 0 ? j_ent0[0] : j_ent0[1], k == 0 ? j_ent1[0] : j_ent1[1], 2 * k, lidx_base + 2 * k);
         flush();
-        st_full += (unsigned long long)(lane == 0 ? nmine : 0);
-        st_build += (unsigned long long)(lane == 0 && mode == 0 ? nmine : 0);
-        st_new += (unsigned long long)(lane == 0 && mode == 1 ? nmine : 0);
+        SDF_TK(tk[0] += 1; tk[1] += tk1 - tk0; tk[2] += (SDF_STAMP() - tk1) - (tk[4] + tk[5] - tk_r0);)
+        SDF_CNT(st_full += (unsigned)(lane == 0 ? nmine : 0));
+        SDF_CNT(st_build += (unsigned)(lane == 0 && mode == 0 ? nmine : 0));
+        SDF_CNT(st_new += (unsigned)(lane == 0 && mode == 1 ? nmine : 0));
         if (lane < nmine) {
             const unsigned ent = lane == 0 ? ent4[0] : (lane == 1 ? ent4[1] : (lane == 2 ? ent4[2] : ent4[3]));
-            const unsigned long long bst = mybest[lane];
+            const unsigned long long bst = w.best[lane];
             ws.phi[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = sqrtf(__uint_as_float((unsigned)(bst >> 32)));
             // list of the voxel (if it got one: lbits) and the nearest triangle, which starts its next evaluation (sdf_list_search)
+            const unsigned tri = (unsigned)(bst & 0xffffu) < (unsigned)NF ? (unsigned)(bst & 0xffffu) : 0u;
             if (mode == 0 && lidx_base + lane < SDF_LCAP_V)
-                ws.lmap[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = (unsigned)(lidx_base + lane) | ((unsigned)(bst & 0xffffu) << 16);
+                ws.lmap[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = (unsigned)(lidx_base + lane) | (tri << 16);
         }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (collect_stats) {
-        unsigned long long d = st_dist;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-        if (lane == 0) {
-            atomicAdd(&ws.stats[1], d);                                  // exact point-triangle distances
-            atomicAdd(&ws.stats[4], st_full * (unsigned long long)NF);   // bounding-sphere tests
-            atomicAdd(&ws.stats[6], st_new);                             // voxels of hands with valid lists that have none
-            atomicAdd(&ws.stats[7], st_build);                           // voxels whose lists were (re)built
-        }
+        SDF_WAVE_SYNC();
     }
 }
 
 // ------------------------------------------------------------------------------------- distance from candidate lists
 // The inside voxels that HAVE a valid candidate list (inside_list_a; item = SDF_LIST_ITEM consecutive entries of one hand).
-// grid-strided over the items, block = 256 (4 waves), 4 workgroups per CU (<= 128 VGPRs, 34 KB LDS): the workgroup stages the
-// hand's CURRENT bounding spheres (LDS, once per run of two items), a wave takes WAVE / K voxels, K lanes per voxel, each lane
+// grid-strided over the items, block = 256 (4 waves), 4 workgroups per CU (<= 128 VGPRs, 40 KB LDS): the workgroup stages the
+// hand's CURRENT table (LDS, once per run of two items), a wave takes WAVE / K voxels, K lanes per voxel, each lane
 // walking its contiguous piece of the voxel's list (<= 192 triangle ids written when the lists were built: 16 bytes = 8 ids per
 // load, all requested up front).  Upper bound of a voxel = the exact distance to the triangle that was nearest the last time (any
 // triangle gives a valid bound, this one is nearly always the answer): no reduction pass, and only the triangles whose spheres
-// reach inside that bound survive; the survivors of the wave's voxels are queued as dense (voxel, triangle) pairs and evaluated
-// exactly, 64 per round.  Same minimum as the full search, bit for bit: the list holds every triangle that can be nearest while
-// the hand stays within SDF_LIST_SLACK of its reference pose (see pair_pass), and a culled triangle lies farther than a distance
-// some triangle attains.
-#define SDF_LIST_QCAP 512
+// reach inside that bound are queued -> refine -> exact.  Same minimum as the full search, bit for bit: the list holds every
+// triangle that can be nearest while the hand stays within SDF_LIST_SLACK of its reference pose (see pair_pass), and a culled
+// triangle lies farther than a distance some triangle attains.
 #define SDF_LIST_VPW (WAVE / SDF_LIST_K)          // voxels per wave
 #define SDF_LIST_PIECE (SDF_LCAP_L / SDF_LIST_K / 8)   // 16-byte loads per lane
-#define SDF_LIST_LDS (NFP * 16 + (SDF_THREADS / WAVE) * (SDF_LIST_QCAP * 4 + SDF_LIST_VPW * 8 + SDF_LIST_VPW * 2))
-__device__ __forceinline__ void sdf_list_search(const SdfWorkspace& ws, int collect_stats, int slot, int nslot, char* smem) {
-    float4* const tab_s = reinterpret_cast<float4*>(smem);                                              // [NFP] (centroid, radius)
-    unsigned (*const q_s)[SDF_LIST_QCAP] = reinterpret_cast<unsigned (*)[SDF_LIST_QCAP]>(smem + NFP * 16);    // (voxel of the wave << 16) | triangle
-    unsigned long long (*const best_s)[SDF_LIST_VPW] =     // (squared distance bits << 32) | triangle
-        reinterpret_cast<unsigned long long (*)[SDF_LIST_VPW]>(smem + NFP * 16 + (SDF_THREADS / WAVE) * SDF_LIST_QCAP * 4);
-    unsigned short (*const vox_s)[SDF_LIST_VPW] =
-        reinterpret_cast<unsigned short (*)[SDF_LIST_VPW]>(smem + NFP * 16 + (SDF_THREADS / WAVE) * (SDF_LIST_QCAP * 4 + SDF_LIST_VPW * 8));
+template <bool STATS>
+__device__ __forceinline__ void sdf_list_item(const SdfWorkspace& ws, int item, char* smem, int& curH, SdfAcc& acc) {
+    const float4* const tab_s = reinterpret_cast<const float4*>(smem);                                  // [NFP] (centre, radius)
+    const unsigned* const nrm_s = reinterpret_cast<const unsigned*>(smem + NFP * 16);                   // [SDF_NRM_N]
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
+    const SdfWaveLds w = sdf_wave_lds(smem, wave);
     const int grp = lane / SDF_LIST_K, sub = lane % SDF_LIST_K;
-    const int total = ws.inside_count[1];
     const unsigned* glist = ws.inside_list_a;
-    unsigned* q = q_s[wave];
-    unsigned long long* best = best_s[wave];
-    unsigned short* vox_w = vox_s[wave];
-    unsigned long long st_dist = 0, st_sph = 0, st_vox = 0;
-    int curH = -1;
-    // (sharing an item between two workgroups when there are few, as the full search does, is SLOWER here: 17.6 instead of 16.7 us
-    // for the launch of one batch of 64 -- half-empty waves, the same chain of loads)
-    const int nitems = (total + SDF_LIST_ITEM - 1) / SDF_LIST_ITEM;
-    const int run = nitems > nslot ? 2 : 1;
-    for (int item0 = slot * run; item0 < nitems; item0 += nslot * run)
-    for (int item = item0; item < item0 + run && item < nitems; ++item) {
+    unsigned& st_dist = acc.dist; unsigned& st_sph = acc.sph; unsigned& st_vox = acc.vox;
+    unsigned& st_ref = acc.ref;
+    SDF_TK(long long* const tk = acc.tk;)
+    {
         // the hand (entry 0 of an item is always valid); a new hand's table is requested first (global -> LDS, asynchronous) ...
+        SDF_TK(const long long tk0 = SDF_STAMP();)
         const int H = __builtin_amdgcn_readfirstlane((int)(glist[item * SDF_LIST_ITEM] >> 16));
         const bool stage = H != curH;          // uniform over the workgroup
         if (stage) {
             SDF_LDS_BARRIER();          // (the previous table's readers are done; LDS traffic only)
-            sdf_stage_async(ws.sph + (size_t)H * NFP, reinterpret_cast<char*>(tab_s), NFP);
+            sdf_stage_table(ws, H, smem);
         }
         // ... then this lane's voxel (the same for the K lanes of a group) and everything it needs from memory: all of it in flight
         // while the table goes to LDS
@@ -933,62 +1030,46 @@ __device__ __forceinline__ void sdf_list_search(const SdfWorkspace& ws, int coll
         unsigned* const lword = ws.lmap + (size_t)H * SDF_NVOX + vox;
         const unsigned lw = has ? *lword : 0u;
         const int nr = (int)(lw >> 16);
-        const float4* abc = ws.abc + (size_t)H * NFP * 3;
+        const float4* vn4 = ws.vn4 + (size_t)H * SDF_NV4;
+        const unsigned* fpk = ws.fpk[H >= ws.B ? 1 : 0];
         const uint4* piece = reinterpret_cast<const uint4*>(ws.lists + ((size_t)H * SDF_LCAP_V + (lw & 0xffffu)) * SDF_LCAP_L) + sub * SDF_LIST_PIECE;
         uint4 ids4[SDF_LIST_PIECE];
         constexpr unsigned PK = (unsigned)(NFP - 1) | ((unsigned)(NFP - 1) << 16);     // parked padding
 #pragma unroll
         for (int c = 0; c < SDF_LIST_PIECE; ++c) ids4[c] = has ? piece[c] : make_uint4(PK, PK, PK, PK);
-        const float4 A0 = abc[3 * nr], B0 = abc[3 * nr + 1], C0 = abc[3 * nr + 2];
+        const unsigned pk0 = fpk[nr];
+        const float4 A0 = vn4[pk0 & 1023u], B0 = vn4[(pk0 >> 10) & 1023u], C0 = vn4[pk0 >> 20];
         if (stage) {
             SDF_STAGE_CLOSE();          // the table has landed (waits for this wave's other loads too: they were all in flight)
             curH = H;
         }
-        const float px = (float)(2 * (int)(vox & 31u) + 1) / (float)SDF_G - 1.0f, py = (float)(2 * (int)((vox >> 5) & 31u) + 1) / (float)SDF_G - 1.0f,
-                    pz = (float)(2 * (int)(vox >> 10) + 1) / (float)SDF_G - 1.0f;
+        float px, py, pz;
+        sdf_vox_centre((int)vox, px, py, pz);
+        SDF_TK(const long long tk1 = SDF_STAMP();)
         float ub;
         {
             const float a[3] = {A0.x, A0.y, A0.z}, b[3] = {B0.x, B0.y, B0.z}, c[3] = {C0.x, C0.y, C0.z};
             const float ub2 = sdf_point_tri_dist2(a, b, c, px, py, pz);
             if (sub == 0) {
-                vox_w[grp] = (unsigned short)vox;
-                best[grp] = ((unsigned long long)__float_as_uint(ub2) << 32) | (unsigned)nr;
+                w.vox[grp] = (unsigned short)vox;
+                w.best[grp] = ((unsigned long long)__float_as_uint(ub2) << 32) | (unsigned)nr;
             }
             ub = sqrtf(ub2) * 1.0001f + 1e-6f;
         }
         int npair = 0;
+        SDF_TK(const long long tk2 = SDF_STAMP(), tk_r0 = tk[4] + tk[5];)
         auto flush = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // software pipeline: the next round's triangle is requested before this round's distance is computed
-            unsigned pr_n = lane < npair ? q[lane] : 0u;
-            float4 A_n = abc[3 * (int)(pr_n & 0xffffu)], B_n = abc[3 * (int)(pr_n & 0xffffu) + 1], C_n = abc[3 * (int)(pr_n & 0xffffu) + 2];
-            for (int base = 0; base < npair; base += WAVE) {
-                const unsigned pr = pr_n;
-                const float4 A = A_n, Bv = B_n, Cv = C_n;
-                const bool live = base + lane < npair;
-                if (base + WAVE < npair) {
-                    const int nidx = base + WAVE + lane;
-                    pr_n = nidx < npair ? q[nidx] : 0u;
-                    const int fn = (int)(pr_n & 0xffffu);
-                    A_n = abc[3 * fn], B_n = abc[3 * fn + 1], C_n = abc[3 * fn + 2];
-                }
-                if (live) {
-                    const int g = (int)(pr >> 16);
-                    const int id = (int)vox_w[g];
-                    const float qx = (float)(2 * (id & 31) + 1) / (float)SDF_G - 1.0f;
-                    const float qy = (float)(2 * ((id >> 5) & 31) + 1) / (float)SDF_G - 1.0f;
-                    const float qz = (float)(2 * (id >> 10) + 1) / (float)SDF_G - 1.0f;
-                    const float a[3] = {A.x, A.y, A.z}, b[3] = {Bv.x, Bv.y, Bv.z}, c[3] = {Cv.x, Cv.y, Cv.z};
-                    atomicMin(&best[g], ((unsigned long long)__float_as_uint(sdf_point_tri_dist2(a, b, c, qx, qy, qz)) << 32) | (pr & 0xffffu));
-                }
-            }
-            st_dist += (unsigned long long)(lane == 0 ? npair : 0);
+            SDF_WAVE_SYNC();
+            SDF_TK(const long long f0 = SDF_STAMP();)
+            SDF_CNT(st_ref += (unsigned)(lane == 0 ? npair : 0));
+            npair = sdf_refine_pairs(tab_s, nrm_s, w, npair, lane);
+            SDF_WAVE_SYNC();
+            SDF_TK(const long long f1 = SDF_STAMP();)
+            sdf_exact_pairs(vn4, fpk, w, npair, lane);
+            SDF_CNT(st_dist += (unsigned)(lane == 0 ? npair : 0));
             npair = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            SDF_WAVE_SYNC();
+            SDF_TK(const long long f2 = SDF_STAMP(); tk[4] += f1 - f0; tk[5] += f2 - f1;)
         };
 #pragma unroll
         for (int c = 0; c < SDF_LIST_PIECE; ++c) {
@@ -996,7 +1077,7 @@ __device__ __forceinline__ void sdf_list_search(const SdfWorkspace& ws, int coll
             // a piece is compact (parked padding only at its tail): done when no lane has a candidate left
             const unsigned long long more = __ballot((cur.x & 0xffffu) != (unsigned)(NFP - 1));
             if (!more) break;
-            st_sph += (unsigned long long)(lane == 0 ? 8 * __popcll(more) : 0);
+            SDF_CNT(st_sph += (unsigned)(lane == 0 ? 8 * __popcll(more) : 0));
             const unsigned ids[8] = {cur.x & 0xffffu, cur.x >> 16, cur.y & 0xffffu, cur.y >> 16, cur.z & 0xffffu, cur.z >> 16, cur.w & 0xffffu, cur.w >> 16};
             float4 sp[8];
 #pragma unroll
@@ -1007,7 +1088,7 @@ __device__ __forceinline__ void sdf_list_search(const SdfWorkspace& ws, int coll
                 const float dx = px - sp[k].x, dy = py - sp[k].y, dz = pz - sp[k].z;
                 const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
                 const float lim = ub + sp[k].w;
-                // cull iff |p - centroid| - radius > upper bound (exact: such a triangle cannot be the minimum); parked padding: never kept
+                // cull iff |p - m| - radius > upper bound (exact: such a triangle cannot be the minimum); parked padding: never kept
                 km |= ((int)ids[k] != nr && !(d2 > lim * lim * 1.00001f)) ? (1u << k) : 0u;
             }
             // survivors -> the wave's queue: one scan over the per-lane counts
@@ -1015,49 +1096,103 @@ __device__ __forceinline__ void sdf_list_search(const SdfWorkspace& ws, int coll
             const int mine = __popc(km);
             int off = wave_incl_scan(mine, cnt) - mine;
             if (cnt) {
-                if (npair + cnt > SDF_LIST_QCAP) flush();
+                if (npair + cnt > SDF_QCAP) flush();
                 off += npair;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if ((km >> k) & 1u) q[off++] = ((unsigned)grp << 16) | ids[k];
+                    if ((km >> k) & 1u) w.q[off++] = ((unsigned)grp << 16) | ids[k];
                 npair += cnt;
             }
         }
         flush();
+        SDF_TK(tk[0] += 1; tk[1] += tk1 - tk0; tk[3] += (SDF_STAMP() - tk2) - (tk[4] + tk[5] - tk_r0);)
         if (has && sub == 0) {
-            const unsigned long long bst = best[grp];
+            const unsigned long long bst = w.best[grp];
             ws.phi[(size_t)H * SDF_NVOX + vox] = sqrtf(__uint_as_float((unsigned)(bst >> 32)));
             reinterpret_cast<unsigned short*>(lword)[1] = (unsigned short)(bst & 0xffffu);
         }
-        {
+        if (STATS) {
             const unsigned long long mh = __ballot(has && sub == 0);
-            st_vox += (unsigned long long)(lane == 0 ? __popcll(mh) : 0);
+            st_vox += (unsigned)(lane == 0 ? __popcll(mh) : 0);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (collect_stats && lane == 0) {
-        atomicAdd(&ws.stats[1], st_dist + st_vox);   // exact point-triangle distances (one per voxel for the bound)
-        atomicAdd(&ws.stats[4], st_sph);             // bounding-sphere tests
-        atomicAdd(&ws.stats[5], st_vox);             // voxels answered from their lists
+        SDF_WAVE_SYNC();
     }
 }
 
 // ------------------------------------------------------------------------------------- distance: the launch
-// grid = SDF_DIST_BLOCKS.. (a multiple of 16), block = 256, 4 workgroups per CU.  Single-shot callers: every workgroup runs the full
-// search.  Fused loop: the two searches read disjoint lists and write disjoint voxels, so they share the launch -- alternate groups
-// of eight workgroups (one per XCD) take the full search and the list search, each grid-strided over its own items; both are bound
-// by memory / LDS round trips more than by issue slots, and fill each other's gaps on a CU.
-#define SDF_DIST_LDS (SDF_FULL_LDS > SDF_LIST_LDS ? SDF_FULL_LDS : SDF_LIST_LDS)
-__global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace ws, int collect_stats) {
+// A PERSISTENT grid (as many workgroups as the GPU holds at once: 4 per CU, 256 threads, 40 KB LDS, <= 128 VGPRs) that pulls work
+// units from one queue -- the full-search items first (the heavy ones: ~8 us against ~4.5 us), then the list-search items in pairs
+// (consecutive items mostly belong to one hand, whose table is then staged once).  The first unit of a workgroup is its own index,
+// every further one comes from an atomic cursor that is requested BEFORE the current unit is processed and read after it (the
+// round trip hides behind the work).  Why: with one or two items per workgroup and a grid of 4096 the launch lasted 45-65 us
+// while the sum of all workgroups' lifetimes was 22 us of the chip -- workgroups live ~5 us (max 23), and the dispatcher refilled
+// the freed slots too slowly to keep more than ~60 % of the wave slots busy (stamps: scripts/sdf_stamps.py).  Both searches use
+// the same table format, so a workgroup that moves from a hand's full-search item to its list items keeps the table.
+template <bool STATS>
+__global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace ws) {
     __shared__ __attribute__((aligned(16))) char smem[SDF_DIST_LDS];
-    if (!ws.list_mode) {
-        sdf_full_search(ws, collect_stats, (int)blockIdx.x, (int)gridDim.x, smem);
-        return;
+    __shared__ int s_next[2];
+#ifdef SDF_STAMPS
+    const long long span_t0 = (long long)wall_clock64();      // constant 100 MHz, the same on every CU (the shader clocks are not aligned)
+    const long long tk_in = SDF_STAMP();
+#endif
+    const int tid = threadIdx.x, nwg = (int)gridDim.x;
+#ifndef SDF_CHUNK_LIST
+#define SDF_CHUNK_LIST 2
+#endif
+    // Work units, heavy first: full-search items (halves of them when there are few: two workgroups share an item), then the
+    // list-search items, in pairs when there are many (consecutive items mostly share a hand: one table staging).
+    // Units b and nwg + b belong to workgroup b (no atomics: a small launch never touches the cursor, and the workgroups of a large
+    // one do not all hit it at t = 0 -- 1024 simultaneous atomics on one address take 12 us); every further unit comes from the cursor,
+    // requested at the START of the unit before (the workgroups are out of step by then) and read after it.
+    // (Eight queues, one per XCD, with stealing from the fullest: the same kernel time -- 57.8 against 58.5 us per 512 samples -- and a
+    // lower rate with two sequences in flight; static per-XCD lists: +12 %.  The tables do not stay in an XCD's L2 across kernels.)
+    const int n_full = (ws.inside_count[0] + SDF_ITEM - 1) / SDF_ITEM;
+    const int n_list = ws.list_mode ? (ws.inside_count[1] + SDF_LIST_ITEM - 1) / SDF_LIST_ITEM : 0;
+    const int split = 2 * n_full + n_list <= nwg ? 2 : 1;
+    const int pair = n_list + n_full > nwg ? SDF_CHUNK_LIST : 1;
+    const int u_full = n_full * split, total = u_full + (n_list + pair - 1) / pair;
+    int* const cursor = ws.inside_count + SDF_CURSOR;                     // zero on entry (zeroed with the list counters)
+    SdfAcc acc;
+    int curH = -1, round = 0;
+    for (int unit = (int)blockIdx.x; unit < total; ++round) {              // uniform over the workgroup
+        const bool own_next = round == 0;                                  // the second unit is static
+        int nxt = 0;
+        if (!own_next && tid == 0) nxt = 2 * nwg + atomicAdd(cursor, 1);
+        if (unit < u_full) {
+            sdf_full_item<STATS>(ws, unit / split, split == 2 ? unit % 2 : -1, smem, curH, acc);
+        } else {
+            const int i0 = (unit - u_full) * pair;
+            for (int i = i0; i < i0 + pair && i < n_list; ++i) sdf_list_item<STATS>(ws, i, smem, curH, acc);
+        }
+        if (own_next) { unit = nwg + (int)blockIdx.x; continue; }
+        if (tid == 0) s_next[round & 1] = nxt;
+        __syncthreads();
+        unit = s_next[round & 1];
     }
-    const int idx = (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7u)), half = (int)(gridDim.x >> 1);
-    if (((blockIdx.x >> 3) & 1u) == 0u) sdf_full_search(ws, collect_stats, idx, half, smem);
-    else sdf_list_search(ws, collect_stats, idx, half, smem);
+    const int lane = tid % WAVE;
+    if (STATS) {
+        unsigned long long d = acc.dist;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        if (lane == 0) {
+            atomicAdd(&ws.stats[1], d + (unsigned long long)acc.vox);                        // exact point-triangle distances (list search: + one per voxel for the bound)
+            atomicAdd(&ws.stats[4], (unsigned long long)acc.full * (unsigned long long)NF + (unsigned long long)acc.sph);   // bounding-sphere tests
+            atomicAdd(&ws.stats[5], (unsigned long long)acc.vox);                            // voxels answered from their lists
+            atomicAdd(&ws.stats[6], (unsigned long long)acc.fresh);                          // voxels of hands with valid lists that have none
+            atomicAdd(&ws.stats[7], (unsigned long long)acc.build);                          // voxels whose lists were (re)built
+            atomicAdd(&ws.stats[8], (unsigned long long)acc.ref);                            // plane + circle tests
+        }
+    }
+#ifdef SDF_STAMPS
+    if (lane == 0 && blockIdx.x < 4096) {
+        long long* d_ = g_sdf_stamps[blockIdx.x * 4 + tid / WAVE];
+        for (int k = 0; k < 6; ++k) d_[k] += acc.tk[k];
+        d_[6] += SDF_STAMP() - tk_in; d_[7] += 1;
+        long long* e_ = g_sdf_span[blockIdx.x * 4 + tid / WAVE];
+        e_[0] = span_t0; e_[1] = (long long)wall_clock64(); e_[2] = (long long)blockIdx.x; e_[3] = round;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------- sample
@@ -1197,5 +1332,5 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void sdf_sample_kernel(VertLayo
                                                                  float* __restrict__ origin, float* __restrict__ dval, int B) {
     __shared__ float red16[SDF_SAMPLE_THREADS / WAVE];
     sdf_sample_block(vl, ws, robustifier, loss, per_vert, origin, dval, nullptr, B, 0.f, nullptr, red16, blockIdx.x, SDF_SAMPLE_THREADS);
-    if (blockIdx.x == 0 && threadIdx.x < SDF_NXCD) ws.inside_count[threadIdx.x] = 0;   // ready for the next call's prep kernel
+    if (blockIdx.x == 0 && threadIdx.x < SDF_NZERO) sdf_zero_counter(ws.inside_count, (int)threadIdx.x);   // ready for the next call's prep kernel
 }

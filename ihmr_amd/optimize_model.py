@@ -218,7 +218,7 @@ class OptimizeModel:
         return dict(ray_tests=int(out[0]), dist_evals=int(out[1]), inside_voxels=int(out[2]), needed_voxels=int(out[3]))
 
     SDF_COUNTERS = ("ray_tests", "dist_evals", "inside_voxels", "needed_voxels", "sphere_tests", "voxels_from_lists",
-                    "voxels_without_list", "voxels_rebuilt")
+                    "voxels_without_list", "voxels_rebuilt", "plane_tests")
 
     def _drop_graphs(self):
         """Destroy every captured graph of this instance (they are re-captured on demand)."""
@@ -235,7 +235,7 @@ class OptimizeModel:
 
     def sdf_counters_stop(self):
         """Synchronise, switch the counters off and return their totals since :meth:`sdf_counters_start` (diagnostics)."""
-        out = (C.c_ulonglong * 8)()
+        out = (C.c_ulonglong * 16)()
         hip.check(hip.lib().ihmr_opt_sdf_counters(C.byref(self.io), self.batch_size, out, 0), "ihmr_opt_sdf_counters")
         self._drop_graphs()
         return {k: int(out[i]) for i, k in enumerate(self.SDF_COUNTERS)}

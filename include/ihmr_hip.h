@@ -203,11 +203,12 @@ int ihmr_opt_set_params(const ihmr_opt_io* io, const float* final_params, int B,
 int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                        const ihmr_opt_weights* w, unsigned long long* out4, void* stream);
 
-/* diagnostics of the fused loop.  enable = 1: zero the eight SDF work counters and switch them on for every launch issued or
- * recorded afterwards (a stage graph captured while they are on keeps counting); enable = 0: synchronise, copy them to out8 (host)
- * and switch them off: {ray tests, exact distances, inside voxels, needed voxels, bounding-sphere tests, voxels answered from
- * their candidate lists, voxels of such hands handed to the full search, voxels whose lists were rebuilt}. */
-int ihmr_opt_sdf_counters(const ihmr_opt_io* io, int B, unsigned long long* out8, int enable);
+/* diagnostics of the fused loop.  enable = 1: zero the SDF work counters and switch them on for every launch issued or
+ * recorded afterwards (a stage graph captured while they are on keeps counting); enable = 0: synchronise, copy the sixteen counter
+ * slots to out16 (host) and switch them off: {ray tests, exact distances, inside voxels, needed voxels, bounding-sphere tests,
+ * voxels answered from their candidate lists, voxels of such hands handed to the full search, voxels whose lists were rebuilt,
+ * plane + circle tests, 7 unused}. */
+int ihmr_opt_sdf_counters(const ihmr_opt_io* io, int B, unsigned long long* out16, int enable);
 
 /* ------------------------------------------------------------------ image encoder (ResNet-50 + heads) */
 /* One Conv2d / Linear of `InterHandEncoder.forward` (models/networks.py:66-80, models/resnet.py:138-156) as an
@@ -335,12 +336,10 @@ int ihmr_preprocess_images(const uint8_t* pixels, const int64_t* offsets, const 
 
 /* per-kernel timing hook for bench.py: when non-NULL, the library records hipEvents around the
  * dominant kernel (sdf_dist_kernel) on `stream` and accumulates here; host pointer, read after ihmr_flush_kernel_timer().
- * While a timer is set, every call brackets its ONE in-loop launch of the kernel with a pair of events
- * (ms_sdf_eval, n_sdf_eval: the launch the refinement really runs -- cold candidate-list hints, tables not yet in L2),
- * then launches the (idempotent) kernel 7 more times between a second pair (ms_sdf_repeat, n_sdf_repeat: warm repeats,
- * reported beside it, never as the launch duration).  ms_event_pair: an EMPTY event pair recorded right before each
- * timed call, i.e. what two event records cost by themselves; (ms_sdf_eval - ms_event_pair) / n_sdf_eval is the launch
- * duration. */
+ * While a timer is set, every call brackets its launch of the kernel with a pair of events (ms_sdf_eval, n_sdf_eval: the
+ * launch the refinement really runs).  ms_event_pair: an EMPTY event pair recorded right before each timed call, i.e. what two
+ * event records cost by themselves; (ms_sdf_eval - ms_event_pair) / n_sdf_eval is the launch duration.  (ms_sdf_repeat /
+ * n_sdf_repeat: unused since the kernel pulls its work from a cursor that one launch spends; kept for the struct layout.) */
 typedef struct ihmr_kernel_timer { double ms_sdf_eval; long n_sdf_eval; double ms_sdf_repeat; double ms_event_pair; long n_sdf_repeat; } ihmr_kernel_timer;
 int ihmr_set_kernel_timer(ihmr_kernel_timer* t);
 int ihmr_flush_kernel_timer(void);
