@@ -33,6 +33,7 @@
 #define SDF_PREP_THREADS_SMALL 1024
 #define SDF_PREP_SMALL_MAX_HANDS 128     // up to this many hands per launch (one batch of 64) the 1024-thread form is used; at 256 hands (IHMR-MLP, batch 128) the 512-thread form is 11 % faster end to end
 #define SDF_NCOL (SDF_G * SDF_G)   // 1024 columns (k,j)
+#define SDF_RAYQ 4096               // (triangle, needed column) pairs per window of the prep kernel's ray-parity queue (a hand has ~1000)
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
 #define SDF_DIST_WG_PER_CU 4          // sdf_dist_kernel: 40 KB LDS, <= 128 VGPRs; its grid is persistent: this many workgroups per CU
 #ifndef SDF_ITEM_RUN
@@ -213,6 +214,19 @@ __device__ __forceinline__ void tri_col_range(float y0, float y1, float y2, floa
     k1 = min(SDF_G - 1, (int)floorf((zmax + 1.0f) * 16.0f - 0.5f));
 }
 
+// Phase stamps (experiment builds only: -DSDF_STAMPS=1 list search, =2 full search; scripts/sdf_stamps.py): shader-clock time per
+// phase of a work item, summed per wave into the spare counter slots 9..15
+#ifdef SDF_STAMPS
+#define SDF_TK(...) __VA_ARGS__
+#define SDF_STAMP() ((long long)__builtin_readcyclecounter())
+__device__ long long g_sdf_stamps[4096 * 4][8];       // per (workgroup, wave) sums, plain stores: no atomics in a stamped launch
+__device__ long long g_sdf_span[4096 * 4][4];         // entry / exit stamp, XCC id, items of the LAST launch (either search)
+__device__ long long g_sdf_prep[4096][8];             // sdf_prep_kernel: phase sums per hand (wave 0), [7] = launches
+#else
+#define SDF_TK(...)
+#define SDF_STAMP() 0ll
+#endif
+
 // ------------------------------------------------------------------------------------- prep + parity
 // grid = 2B (block id = hand id H = hnd*B + b, so both hands of sample b sit on XCD b % 8 when B % 8 == 0),
 // block = PT (512 or 1024, see above).  Everything up to the inside/outside decision of a hand happens here, out of LDS:
@@ -291,8 +305,10 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     __shared__ float red[6][PT / WAVE];
     __shared__ float box[4];
     __shared__ int scratch[PT / WAVE];
+    __shared__ unsigned rayq[SDF_RAYQ];            // (triangle | column << 11) pairs of the ray-parity phase
     __shared__ int blk_inside, blk_base, blk_base_a;
     const int H = blockIdx.x, hnd = H / B, b = H % B, tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
+    SDF_TK(long long pk_[8]; pk_[0] = SDF_STAMP();)
     const float* own = vl.hand(b, hnd);
     const float* other = vl.hand(b, 1 - hnd);
     const int32_t* faces = hnd == 0 ? faces_r : faces_l;  // SoA [3][NFP]
@@ -361,6 +377,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     }
     SDF_LDS_BARRIER();
     const float cx = box[0], cy = box[1], cz = box[2], sc = box[3];
+    SDF_TK(pk_[1] = SDF_STAMP();)
     if (tid < 4) ws.box[H * 4 + tid] = box[tid];
     // ---- normalise own vertices into [-1,1]^3; which voxels will the other hand's vertices read?
 #pragma unroll
@@ -404,6 +421,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     // ---- temporal candidate lists (fused refinement loop): how far has this hand moved, in its own normalised frame, since its
     //      lists were built?  Within the slack they stay exact (sdf_dist_kernel); beyond it, or when the caller says so (first
     //      iteration of a stage: the parameters may have jumped), the hand starts over: reference frame := now, map cleared.
+    SDF_TK(pk_[2] = SDF_STAMP();)
     if (lists_on) {
         float* ref = ws.vn_ref + (size_t)H * NV3;
         float dmax = 0.f;
@@ -442,6 +460,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         }
     }
     // ---- lane = triangle: records for the distance kernel + ray parity of the needed voxels it can hit
+    SDF_TK(pk_[3] = SDF_STAMP();)
     float4* sph = ws.sph + (size_t)H * NFP;
     unsigned* nrm = ws.nrm + (size_t)H * NFP;
     unsigned long long st_tests = 0;
@@ -501,53 +520,99 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
             nrm[f] = real ? nw : SDF_NRM_NOPLANE;
         }
     }
+    SDF_TK(pk_[4] = SDF_STAMP();)
+    // ---- ray parity as DENSE (triangle, needed column) pairs.  A triangle-parallel loop over the needed columns of each triangle's
+    //      yz box is bound by its slowest lane (stamps: 5 us on average, 16 us for the slowest hand of a launch -- a palm triangle
+    //      covers 30 columns, most cover 0-2, and every iteration is a dependent LDS round trip).  So the lanes only ENUMERATE their
+    //      pairs (a store per column) into an LDS queue, and the pairs are then dealt evenly: thread p takes pairs p, p + PT, ...,
+    //      re-derives the triangle's constants (same expressions: the same bits) and does the (u,v) test and the hit mask.
+    {
+        const unsigned* fpk = ws.fpk[hnd];
+        int cnt[TRI_IT], jm0[TRI_IT], kr[TRI_IT];       // per triangle: needed columns in its box, j mask shift / width packed, k range packed
+        unsigned jmk[TRI_IT];
+        int mine = 0;
 #pragma unroll
-    for (int it = 0; it < TRI_IT; ++it) {
-        const int f = tid + it * PT;
-        if (f >= NFP) break;
-        const int fa = fidx[it][0], fb = fidx[it][1], fc = fidx[it][2];
-        const float a[3] = {vn[3 * fa], vn[3 * fa + 1], vn[3 * fa + 2]};
-        const float bb[3] = {vn[3 * fb], vn[3 * fb + 1], vn[3 * fb + 2]};
-        const float c[3] = {vn[3 * fc], vn[3 * fc + 1], vn[3 * fc + 2]};
-        const float e1x = bb[0] - a[0], e1y = bb[1] - a[1], e1z = bb[2] - a[2];
-        const float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
-        const float det = __builtin_fmaf(e1z, e2y, -(e1y * e2z));
-        const bool ok = f < NF && fabsf(det) >= 1e-12f;
-        if (!ok) continue;                                   // degenerate in yz: the +x ray never counts it
-        const float inv = 1.0f / det;
-        const bool tri_safe = sdf_ray_tri_safe(e1x, e1y, e1z, e2x, e2y, e2z, inv);
-        int j0, j1, k0, k1;
-        tri_col_range(a[1], bb[1], c[1], a[2], bb[2], c[2], j0, j1, k0, k1);
-        // one flat loop over the NEEDED columns of the bounding box (row masks: no LDS round trip for a column nobody
-        // reads): a wave iterates max(rows + needed columns) times, not max(k range) * max(j range)
-        if (j1 < j0 || k1 < k0) continue;
-        const unsigned jmask = (j1 - j0 == 31 ? 0xffffffffu : ((1u << (j1 - j0 + 1)) - 1u)) << j0;
-        int k = k0;
-        unsigned cols = rowany[k0] & jmask;
-        for (;;) {
-            if (cols == 0u) {
-                if (++k > k1) break;
-                cols = rowany[k] & jmask;
-                continue;
+        for (int it = 0; it < TRI_IT; ++it) {
+            const int f = tid + it * PT;
+            cnt[it] = 0; jmk[it] = 0u; kr[it] = 0; jm0[it] = 0;
+            if (f >= NF) continue;
+            const int fa = fidx[it][0], fb = fidx[it][1], fc = fidx[it][2];
+            const float ay = vn[3 * fa + 1], az = vn[3 * fa + 2], by = vn[3 * fb + 1], bz = vn[3 * fb + 2], cy2 = vn[3 * fc + 1], cz2 = vn[3 * fc + 2];
+            const float e1y = by - ay, e1z = bz - az, e2y = cy2 - ay, e2z = cz2 - az;
+            const float det = __builtin_fmaf(e1z, e2y, -(e1y * e2z));
+            if (!(fabsf(det) >= 1e-12f)) continue;                // degenerate in yz: the +x ray never counts it
+            int j0, j1, k0, k1;
+            tri_col_range(ay, by, cy2, az, bz, cz2, j0, j1, k0, k1);
+            if (j1 < j0 || k1 < k0) continue;
+            const unsigned jmask = (j1 - j0 == 31 ? 0xffffffffu : ((1u << (j1 - j0 + 1)) - 1u)) << j0;
+            int n = 0;
+            for (int k = k0; k <= k1; ++k) n += __popc(rowany[k] & jmask);
+            cnt[it] = n; jmk[it] = jmask; kr[it] = k0 | (k1 << 8);
+            mine += n;
+        }
+        // exclusive scan of the per-thread counts over the workgroup (wave scan + wave totals through LDS)
+        int wtot;
+        const int inc = wave_incl_scan(mine, wtot);
+        if (lane == WAVE - 1) scratch[wave] = wtot;
+        SDF_LDS_BARRIER();
+        int base_t = inc - mine, P = 0;
+#pragma unroll
+        for (int wv = 0; wv < PT / WAVE; ++wv) {
+            const int x = scratch[wv];
+            if (wv < wave) base_t += x;
+            P += x;
+        }
+        for (int win = 0; win < P; win += SDF_RAYQ) {             // (one window unless the hand has more than SDF_RAYQ pairs)
+            if (win > 0) SDF_LDS_BARRIER();                        // the previous window's readers are done
+            int o = base_t - win;
+#pragma unroll
+            for (int it = 0; it < TRI_IT; ++it) {
+                if (cnt[it] == 0) continue;
+                if (o + cnt[it] <= 0 || o >= SDF_RAYQ) { o += cnt[it]; continue; }
+                const int f = tid + it * PT, k1 = kr[it] >> 8;
+                for (int k = kr[it] & 255; k <= k1; ++k) {
+                    unsigned cols = rowany[k] & jmk[it];
+                    while (cols) {
+                        const int j = __ffs((int)cols) - 1;
+                        cols &= cols - 1u;
+                        if (o >= 0 && o < SDF_RAYQ) rayq[o] = (unsigned)f | ((unsigned)(k * SDF_G + j) << 11);
+                        ++o;
+                    }
+                }
             }
-            const int j = __ffs((int)cols) - 1;
-            cols &= cols - 1u;
-            const int col = k * SDF_G + j;
-            const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
-            const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
-            const unsigned need = needed[col];
-            const float sy = py - a[1], sz = pz - a[2];
-            const float uu = __builtin_fmaf(sz, e2y, -(sy * e2z)) * inv;
-            const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y));
-            const float vv = qx * inv;
-            st_tests += 1;
-            if (!((uu >= 0.0f) && (uu <= 1.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f))) continue;
-            const unsigned hits = sdf_ray_hits(need, tri_safe, a[0], e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx);
-            st_tests += __popc(need);
-            if (hits) atomicXor(&parity[col], hits);
+            SDF_LDS_BARRIER();
+            const int nwin = min(P - win, SDF_RAYQ);
+            for (int q = tid; q < nwin; q += PT) {
+                const unsigned e = rayq[q];
+                const int col = (int)(e >> 11);
+                const unsigned pk = fpk[e & 2047u];
+                const int fa = (int)(pk & 1023u), fb = (int)((pk >> 10) & 1023u), fc = (int)(pk >> 20);
+                const float a[3] = {vn[3 * fa], vn[3 * fa + 1], vn[3 * fa + 2]};
+                const float bb[3] = {vn[3 * fb], vn[3 * fb + 1], vn[3 * fb + 2]};
+                const float c[3] = {vn[3 * fc], vn[3 * fc + 1], vn[3 * fc + 2]};
+                const float e1x = bb[0] - a[0], e1y = bb[1] - a[1], e1z = bb[2] - a[2];
+                const float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
+                const float det = __builtin_fmaf(e1z, e2y, -(e1y * e2z));
+                const float inv = 1.0f / det;
+                const int j = col & (SDF_G - 1), k = col >> 5;
+                const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
+                const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
+                const unsigned need = needed[col];
+                const float sy = py - a[1], sz = pz - a[2];
+                const float uu = __builtin_fmaf(sz, e2y, -(sy * e2z)) * inv;
+                const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y));
+                const float vv = qx * inv;
+                st_tests += 1;
+                if (!((uu >= 0.0f) && (uu <= 1.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f))) continue;
+                const bool tri_safe = sdf_ray_tri_safe(e1x, e1y, e1z, e2x, e2y, e2z, inv);
+                const unsigned hits = sdf_ray_hits(need, tri_safe, a[0], e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx);
+                st_tests += __popc(need);
+                if (hits) atomicXor(&parity[col], hits);
+            }
         }
     }
     SDF_LDS_BARRIER();
+    SDF_TK(pk_[5] = SDF_STAMP();)
     // ---- publish: a thread owns CPT adjacent columns; phi = 0 for the outside voxels a sample reads, inside voxels
     //      into the batch-wide lists
     float* phi = ws.phi + (size_t)H * SDF_NVOX;
@@ -598,6 +663,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
             else run_b[ob++] = ent;
         }
     }
+    SDF_TK(if (tid == 0 && H < 4096) { pk_[6] = SDF_STAMP(); for (int k = 0; k < 6; ++k) g_sdf_prep[H][k] += pk_[k + 1] - pk_[k]; g_sdf_prep[H][6] += (long long)blk_inside; g_sdf_prep[H][7] += 1; })
     if (collect_stats) {
         unsigned long long c = st_tests;
 #pragma unroll
@@ -692,18 +758,6 @@ __device__ __forceinline__ void sdf_vox_centre(int id, float& x, float& y, float
         __builtin_amdgcn_wave_barrier();                             \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       \
     } while (0)
-
-// Phase stamps (experiment builds only: -DSDF_STAMPS=1 list search, =2 full search; scripts/sdf_stamps.py): shader-clock time per
-// phase of a work item, summed per wave into the spare counter slots 9..15
-#ifdef SDF_STAMPS
-#define SDF_TK(...) __VA_ARGS__
-#define SDF_STAMP() ((long long)__builtin_readcyclecounter())
-__device__ long long g_sdf_stamps[4096 * 4][8];       // per (workgroup, wave) sums, plain stores: no atomics in a stamped launch
-__device__ long long g_sdf_span[4096 * 4][4];         // entry / exit stamp, XCC id, items of the LAST launch (either search)
-#else
-#define SDF_TK(...)
-#define SDF_STAMP() 0ll
-#endif
 
 // Plane + circle lower bound for the queued pairs (the sphere cull leaves ~30 triangles per voxel, this ~9; one LDS gather and
 // ~35 instructions per pair against a global gather and ~150 for the exact distance).  A triangle lies in its plane inside the

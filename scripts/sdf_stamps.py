@@ -36,9 +36,15 @@ for stage_id in (1, 3):
     t0 = time.perf_counter()
     m.run_stage(m.strategy[stage_id]); torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    raw = np.zeros(4096 * 4 * 12, np.int64)
+    raw = np.zeros(4096 * 4 * 12 + 4096 * 8, np.int64)
     L.ihmr_debug_stamps(raw.ctypes.data, 0)
-    buf, span = raw[:4096 * 4 * 8].reshape(-1, 8), raw[4096 * 4 * 8:].reshape(-1, 4)
+    buf, span = raw[:4096 * 4 * 8].reshape(-1, 8), raw[4096 * 4 * 8:4096 * 4 * 12].reshape(-1, 4)
+    prep = raw[4096 * 4 * 12:].reshape(-1, 8)
+    prep = prep[prep[:, 7] > 0]
+    if len(prep):
+        ph = prep[:, :6] / prep[:, 7:8] / 2400.0
+        tot = ph.sum(1)
+        print('   prep per hand [us]: ' + '; '.join(f'{n} {ph[:, k].mean():.2f} (max {ph[:, k].max():.2f})' for k, n in enumerate(['loads+box', 'normalise+needed', 'list state', 'records', 'ray parity', 'publish'])) + f'; total mean {tot.mean():.2f} p90 {np.percentile(tot, 90):.2f} max {tot.max():.2f}')
     sp = span[span[:, 1] > 0]
     # the shader clocks of the XCDs are not aligned with each other: times relative to the first wave start of the same XCD
     xcd = (sp[:, 2] % 8).astype(int)
