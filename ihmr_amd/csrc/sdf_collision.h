@@ -70,6 +70,8 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     float* vn_ref;             // [H][2334]  normalised vertices of the hand when its lists were built
     int* hmode;                // [H]        this iteration: 0 = lists are being (re)built, 1 = lists are valid (written by the prep kernel)
     int* run_start;            // [H]        first entry of the hand's run in its list (this iteration)
+    float* hdisp;              // [H]        how far the hand has moved from the reference pose of its lists (this iteration; 0 while rebuilding)
+    int* lnext;                // [H]        next free candidate-list slot of the hand (voxels that appear after a rebuild take one)
     unsigned* lbits;           // [H][1024]  bit i of word (k,j): voxel (k,j,i) has a candidate list (cleared when the hand starts over)
     unsigned* lmap;            // [H][32768] voxel -> its list | (the triangle that was nearest the last time it was evaluated) << 16
                                //            (defined where lbits is set)
@@ -93,7 +95,7 @@ __host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)H * (SDF_N
 #define SDF_LIST_ITEM (4 * (WAVE / SDF_LIST_K))   // voxels per work item of sdf_list_search (4 waves)
 #define SDF_LIST_SLACK 0.04f         // lists stay valid while no vertex of the hand has moved further than this (normalised frame)
 __host__ __device__ inline size_t sdf_list_bytes(int H) {
-    return (size_t)H * ((size_t)NV3 * 4 + 8 + (size_t)SDF_NCOL * 4 + (size_t)SDF_NVOX * 4 + (size_t)SDF_LCAP_V * SDF_LCAP_L * 2) +
+    return (size_t)H * ((size_t)NV3 * 4 + 16 + (size_t)SDF_NCOL * 4 + (size_t)SDF_NVOX * 4 + (size_t)SDF_LCAP_V * SDF_LCAP_L * 2) +
            sdf_xcd_cap(H) * sizeof(unsigned) + 1024;
 }
 __host__ __device__ inline size_t sdf_ws_bytes(int H, bool lists = false) {
@@ -122,7 +124,7 @@ static inline SdfWorkspace sdf_carve(void* ws, int H, bool lists = false) {
     w.inside_count = (int*)p; p += SDF_NCTR * 4;
     w.xcd_cap = (int)sdf_xcd_cap(H);
     w.inside_list = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
-    w.vn_ref = nullptr; w.hmode = nullptr; w.run_start = nullptr; w.lbits = nullptr; w.lmap = nullptr; w.lists = nullptr;
+    w.vn_ref = nullptr; w.hmode = nullptr; w.run_start = nullptr; w.hdisp = nullptr; w.lnext = nullptr; w.lbits = nullptr; w.lmap = nullptr; w.lists = nullptr;
     w.inside_list_a = nullptr;
     w.list_mode = 0; w.force_rebuild = 1;
     if (lists) {
@@ -130,6 +132,8 @@ static inline SdfWorkspace sdf_carve(void* ws, int H, bool lists = false) {
         w.vn_ref = (float*)p; p += (size_t)H * NV3 * 4;
         w.hmode = (int*)p; p += (size_t)H * 4;
         w.run_start = (int*)p; p += (size_t)H * 4;
+        w.hdisp = (float*)p; p += (size_t)H * 4;
+        w.lnext = (int*)p; p += (size_t)H * 4;
         p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         w.lbits = (unsigned*)p; p += (size_t)H * SDF_NCOL * 4;
         w.inside_list_a = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
@@ -422,6 +426,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     //      lists were built?  Within the slack they stay exact (sdf_dist_kernel); beyond it, or when the caller says so (first
     //      iteration of a stage: the parameters may have jumped), the hand starts over: reference frame := now, map cleared.
     SDF_TK(pk_[2] = SDF_STAMP();)
+    bool lists_reused = false;
     if (lists_on) {
         float* ref = ws.vn_ref + (size_t)H * NV3;
         float dmax = 0.f;
@@ -439,11 +444,15 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         }
         SDF_LDS_BARRIER();
         bool reuse = !ws.force_rebuild;
+        float moved = 0.f;
         if (reuse) {
             float m = red[0][0];
             for (int w = 1; w < PT / WAVE; ++w) m = fmaxf(m, red[0][w]);
             reuse = m <= SDF_LIST_SLACK - 1e-4f;        // (a NaN compares false: rebuild)
+            moved = m * 1.0001f + 1e-6f;
         }
+        lists_reused = reuse;
+        if (tid == 0) ws.hdisp[H] = reuse ? moved : 0.f;
         if (!reuse) {
 #pragma unroll
             for (int rep = 0; rep < VPT; ++rep) {
@@ -641,7 +650,10 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     if (tid == 0) {              // (the two reservations from different waves: their round trips overlap)
         blk_inside = n_a + n_b;
         blk_base = n_b > 0 ? atomicAdd(&ws.inside_count[0], pad_b) : 0;
-        if (lists_on) ws.run_start[H] = blk_base;
+        if (lists_on) {
+            ws.run_start[H] = blk_base;
+            if (!lists_reused) ws.lnext[H] = n_b;      // a rebuild hands out slots 0 .. n_b - 1 by position in the run
+        }
     }
     if (tid == WAVE) blk_base_a = n_a > 0 ? atomicAdd(&ws.inside_count[1], pad_a) : 0;
     SDF_LDS_BARRIER();
@@ -875,6 +887,10 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
         // candidate lists (single-shot callers)
         const int mode = ws.list_mode ? ws.hmode[H] : -1;
         const int run_start = ws.list_mode ? ws.run_start[H] : 0;
+        // a voxel that appears while the hand's lists are valid gets a list too (next iteration it is answered from it): the hand has
+        // moved `disp` from the reference pose already and may move up to the slack from it, i.e. up to slack + disp from where it is
+        // now -- the list bound is widened by twice that
+        const float widen = mode == 1 ? 2.0f * (SDF_LIST_SLACK + ws.hdisp[H]) : 2.0f * SDF_LIST_SLACK;
         if (H != curH) {             // uniform over the workgroup (same item for all waves)
             SDF_LDS_BARRIER();       // (the previous table's readers are done; LDS traffic only)
             sdf_stage_table(ws, H, smem);
@@ -889,6 +905,15 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
         if (lane < 4) {
             w.vox[lane] = (unsigned short)((lane == 0 ? ent4[0] : (lane == 1 ? ent4[1] : (lane == 2 ? ent4[2] : ent4[3]))) & 0xffffu);
             w.best[lane] = (0x7f800000ull << 32) | 0xffffull;
+        }
+        // list slots of this wave's voxels: by position in the hand's run while the hand rebuilds; fresh ones (one atomic per wave,
+        // requested now, used after the sphere passes) for voxels that appear later
+        int slot_new = 0;
+        if (mode == 1 && lane == 0) {
+            int nv = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nv += ent4[q] != 0xffffffffu ? 1 : 0;
+            slot_new = atomicAdd(&ws.lnext[H], nv);
         }
         int npair = 0;
         SDF_TK(const long long tk1 = SDF_STAMP(), tk_r0 = tk[4] + tk[5];)
@@ -932,13 +957,13 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
             // the slots' upper bound for the refine pass (no triangle id yet: any exact distance will be below it)
             if (lane < nvox) w.best[vs0 + lane] = ((unsigned long long)__float_as_uint(lane ? ub_b * ub_b : ub_a * ub_a) << 32) | 0xffffull;
             unsigned keep_a = 0, keep_b = 0, list_a = 0, list_b = 0;
-            if (mode == 0) {   // lists are being built: the same cull with the bound widened by twice the motion slack
+            if (mode >= 0) {   // lists are being built: the same cull with the bound widened by twice the motion the list has to cover
 #pragma unroll
                 for (int t = 0; t < NFP / WAVE; ++t) {
                     const float r = sph_s[lane + WAVE * t].w;
                     const sdf_v2f lim = ub_lim + r;
                     const sdf_v2f lim2 = lim * lim * sdf_v2f{1.00001f, 1.00001f};
-                    const sdf_v2f limw = lim + sdf_v2f{2.0f * SDF_LIST_SLACK, 2.0f * SDF_LIST_SLACK};
+                    const sdf_v2f limw = lim + sdf_v2f{widen, widen};
                     const sdf_v2f limw2 = limw * limw * sdf_v2f{1.00001f, 1.00001f};
                     keep_a |= !(d2[t].x > lim2.x) ? (1u << t) : 0u;
                     keep_b |= !(d2[t].y > lim2.y) ? (1u << t) : 0u;
@@ -984,14 +1009,14 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
                         SDF_CNT(st_dist += 1);
                     }
                 }
-                if (mode == 0) {
+                if (mode >= 0) {
                     // the voxel's candidate list: every triangle whose bounding sphere comes within the (widened) bound; its slot =
-                    // the voxel's position in the hand's run (known without atomics).  Too long a list, or too many voxels: none.
+                    // the voxel's position in the hand's run (known without atomics) or a fresh one.  Too long a list, or too many voxels: none.
                     unsigned lm = v ? list_b : list_a;
                     int lcnt;
                     const int lmine = __popc(lm);
                     int loff = wave_incl_scan(lmine, lcnt) - lmine;
-                    const int lidx = lidx0 + v;
+                    const int lidx = (mode == 0 ? lidx0 : __builtin_amdgcn_readfirstlane(slot_new) + vs0) + v;
                     if (lcnt <= SDF_LCAP_L && lidx < SDF_LCAP_V) {
                         unsigned short* dst = ws.lists + ((size_t)H * SDF_LCAP_V + lidx) * SDF_LCAP_L;
                         constexpr int LQ = SDF_LCAP_L / SDF_LIST_K;     // element i at (i % K) * LQ + i / K: each of the K reader lanes gets a contiguous piece
@@ -1037,8 +1062,9 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
             ws.phi[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = sqrtf(__uint_as_float((unsigned)(bst >> 32)));
             // list of the voxel (if it got one: lbits) and the nearest triangle, which starts its next evaluation (sdf_list_search)
             const unsigned tri = (unsigned)(bst & 0xffffu) < (unsigned)NF ? (unsigned)(bst & 0xffffu) : 0u;
-            if (mode == 0 && lidx_base + lane < SDF_LCAP_V)
-                ws.lmap[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = (unsigned)(lidx_base + lane) | (tri << 16);
+            const int lslot = (mode == 0 ? lidx_base : __builtin_amdgcn_readfirstlane(slot_new)) + lane;
+            if (mode >= 0 && lslot < SDF_LCAP_V)
+                ws.lmap[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = (unsigned)lslot | (tri << 16);
         }
         SDF_WAVE_SYNC();
     }
