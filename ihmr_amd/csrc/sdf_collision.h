@@ -1220,6 +1220,9 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
 #ifndef SDF_CHUNK_LIST
 #define SDF_CHUNK_LIST 2
 #endif
+#ifndef SDF_TAPER
+#define SDF_TAPER 3
+#endif
     // Work units, heavy first: full-search items (halves of them when there are few: two workgroups share an item), then the
     // list-search items, in pairs when there are many (consecutive items mostly share a hand: one table staging).
     // Units b and nwg + b belong to workgroup b (no atomics: a small launch never touches the cursor, and the workgroups of a large
@@ -1231,7 +1234,13 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
     const int n_list = ws.list_mode ? (ws.inside_count[1] + SDF_LIST_ITEM - 1) / SDF_LIST_ITEM : 0;
     const int split = 2 * n_full + n_list <= nwg ? 2 : 1;
     const int pair = n_list + n_full > nwg ? SDF_CHUNK_LIST : 1;
-    const int u_full = n_full * split, total = u_full + (n_list + pair - 1) / pair;
+    // (the last SDF_TAPER-th of the list items go one by one: short units at the end of the queue shorten the tail of the launch:
+    // 48.5 -> 47.7 us per 512 samples)
+    const int n_paired = pair > 1 ? (n_list - n_list / SDF_TAPER) / pair * pair : 0;
+    const int u_full = n_full * split, u_pair = u_full + n_paired / (pair > 1 ? pair : 1), total = u_pair + (n_list - n_paired);
+    // (Tried: the late voxels of a hand with valid lists -- ~6 per hand and iteration, one full-search item each today -- searched
+    // by the workgroup of the hand's first list item, whose table is staged anyway ("riders"): 13 % less work, but the units that
+    // carry riders are 15-20 us chains -- 47.7 -> 57.8 us per 512 samples even when they go first, 16.4 -> 27.5 us per 64.)
     int* const cursor = ws.inside_count + SDF_CURSOR;                     // zero on entry (zeroed with the list counters)
     SdfAcc acc;
     int curH = -1, round = 0;
@@ -1241,9 +1250,11 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
         if (!own_next && tid == 0) nxt = 2 * nwg + atomicAdd(cursor, 1);
         if (unit < u_full) {
             sdf_full_item<STATS>(ws, unit / split, split == 2 ? unit % 2 : -1, smem, curH, acc);
-        } else {
+        } else if (unit < u_pair) {
             const int i0 = (unit - u_full) * pair;
-            for (int i = i0; i < i0 + pair && i < n_list; ++i) sdf_list_item<STATS>(ws, i, smem, curH, acc);
+            for (int i = i0; i < i0 + pair; ++i) sdf_list_item<STATS>(ws, i, smem, curH, acc);
+        } else {
+            sdf_list_item<STATS>(ws, n_paired + (unit - u_pair), smem, curH, acc);
         }
         if (own_next) { unit = nwg + (int)blockIdx.x; continue; }
         if (tid == 0) s_next[round & 1] = nxt;
