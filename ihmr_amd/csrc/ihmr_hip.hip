@@ -144,6 +144,8 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
         const int dyn = m->nseg * 12 * (int)sizeof(float);
         (void)hipFuncSetAttribute((const void*)lbs_bwd1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
         (void)hipFuncSetAttribute((const void*)lbs_bwd1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+        (void)hipFuncSetAttribute((const void*)opt_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * dyn);
+        (void)hipFuncSetAttribute((const void*)opt_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * dyn);
     }
     if (rc) return rc;
     *out = m;
@@ -355,10 +357,22 @@ extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
 static const ParamStep kNoStep{0, 0.f, 0.f, 1.f, -1, 0, 0};
 // reuse_v_posed: the workspace holds v_posed of the current pose and shape parameters (see lbs_skin_kernel)
 // lists: temporal candidate lists of the collision kernels -- 0 off (single-shot callers), 1 reuse while valid, 2 rebuild now
+// the collision workspace of the fused loop with the switches of this call (lists: 0 off, 1 reuse while valid, 2 rebuild now)
+static SdfWorkspace opt_sdf_ws(const ihmr_opt_io* io, const OptWork& wk, int B, int lists) {
+    SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B, true);
+    ws.list_mode = (lists != 0 && !io->sdf_no_candidate_lists) ? 1 : 0;
+    ws.force_rebuild = lists == 2 ? 1 : 0;
+    ws.align_corners = io->sdf_align_corners ? 1 : 0;
+    if (io->sdf_loss_divisor > 0.f) ws.loss_div = io->sdf_loss_divisor;
+    return ws;
+}
+
+// head = the Adam + skeleton launch, tail = the sampling + loss launch (a caller that fuses them into other launches skips them)
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
                        const ihmr_opt_weights& w, const ParamStep& prev, hipStream_t st, int need_cam = 0, bool reuse_v_posed = false,
-                       int lists = 0) {
-    hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B, true).inside_count);
+                       int lists = 0, bool head = true, bool tail = true) {
+    if (head)
+        hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B, true).inside_count);
     // (small launches: four instead of eight hands per workgroup -- half the chain per thread, see lbs_skin_kernel)
     const int N2 = 2 * B;
     const bool small = N2 <= LBS_SMALL_MAX_HANDS;
@@ -374,17 +388,13 @@ static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
         else hipLaunchKernelGGL((lbs_skin_kernel<true, false, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m,
                                 (const float*)wk.lbs.skel, N2, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
     }
-    SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B, true);
-    ws.list_mode = (lists != 0 && !io->sdf_no_candidate_lists) ? 1 : 0;
-    ws.force_rebuild = lists == 2 ? 1 : 0;
-    ws.align_corners = io->sdf_align_corners ? 1 : 0;
-    if (io->sdf_loss_divisor > 0.f) ws.loss_div = io->sdf_loss_divisor;
+    SdfWorkspace ws = opt_sdf_ws(io, wk, B, lists);
     VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
     int rc = sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, m->faces_pk, m_left ? m_left->faces_pk : m->faces_pk, B, ws, 0.f,
                         nullptr, nullptr, nullptr, nullptr, false, st);
     if (rc) return rc;
     // collision sampling (loss_batch[2], masked by hand type; gradient -> g_verts) and the joint losses in one launch
-    hipLaunchKernelGGL(opt_sample_loss_kernel, dim3(B), dim3(SDF_SAMPLE_THREADS), 0, st, *io, wk, B, w, vl, ws, need_cam);
+    if (tail) hipLaunchKernelGGL(opt_sample_loss_kernel, dim3(B), dim3(SDF_SAMPLE_THREADS), 0, st, *io, wk, B, w, vl, ws, need_cam);
     return (int)hipGetLastError();
 }
 
@@ -414,18 +424,38 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     ParamStep step{0, 0.f, 0.f, 1.f, -1, 1, 0};   // iteration 0: no step yet, zero the optimizer state
     // a stage that moves neither the finger pose nor the shape keeps v_posed: computed in its first iteration, reused after
     const bool vposed_fixed = (pm & (IHMR_PB_POSE_R | IHMR_PB_POSE_L | IHMR_PB_SHAPE_R | IHMR_PB_SHAPE_L)) == 0;
+    // Stages whose LBS backward is per hand only (no finger pose): the tail of an iteration -- sampling + losses, LBS backward, optimizer
+    // step + next skeletons -- is ONE launch per sample (opt_tail_kernel): 4 launches per iteration instead of 6
+    const bool fused_tail = need_mask != 0 && (need_mask & 2) == 0 && !io->no_fused_tail;
+    const size_t tail_lds = (size_t)2 * m->nseg * 12 * sizeof(float);
     for (int it = 0; it < sg->n_iters; ++it) {
         // the first iteration of a stage starts the candidate lists over: the select step of the previous stage may have moved
         // the parameters by more than one optimizer step
-        int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, vposed_fixed && it > 0, it == 0 ? 2 : 1);   // applies the step of iteration it - 1 first
-        if (rc) return rc;
-        if (need_mask)
-            lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
-                                wk.lbs, st);
         const double t = (double)(it + 1);
         const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
-        step = ParamStep{pm, w->shape_reg, sgd ? sg->lr : (float)((double)sg->lr / bc1), (float)sqrt(bc2),
-                         (it % sg->save_freq == 0) ? S++ : -1, 0, sgd};
+        const ParamStep next{pm, w->shape_reg, sgd ? sg->lr : (float)((double)sg->lr / bc1), (float)sqrt(bc2),
+                             (it % sg->save_freq == 0) ? S++ : -1, 0, sgd};
+        if (fused_tail) {
+            // head: only the first iteration needs the stand-alone kernel (zero the optimizer state, first skeletons); afterwards
+            // the tail of iteration it - 1 has already applied its step and written the skeletons of iteration it
+            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, vposed_fixed && it > 0, it == 0 ? 2 : 1, /*head=*/it == 0, /*tail=*/false);
+            if (rc) return rc;
+            SdfWorkspace ws = opt_sdf_ws(io, wk, B, it == 0 ? 2 : 1);
+            VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
+            if (it + 1 < sg->n_iters)
+                hipLaunchKernelGGL(opt_tail_kernel<true>, dim3(B), dim3(SDF_SAMPLE_THREADS), tail_lds, st, *m, *io, wk, B, *w, vl, ws, need_cam, need_mask,
+                                   next, ws.inside_count);
+            else
+                hipLaunchKernelGGL(opt_tail_kernel<false>, dim3(B), dim3(SDF_SAMPLE_THREADS), tail_lds, st, *m, *io, wk, B, *w, vl, ws, need_cam, need_mask,
+                                   next, ws.inside_count);
+        } else {
+            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, vposed_fixed && it > 0, it == 0 ? 2 : 1);   // applies the step of iteration it - 1 first
+            if (rc) return rc;
+            if (need_mask)
+                lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
+                                    wk.lbs, st);
+        }
+        step = next;
     }
     hipLaunchKernelGGL(opt_adam_kernel, dim3(B), dim3(128), 0, st, *io, wk, B, step);
     hipLaunchKernelGGL(opt_select_kernel, dim3((B + 63) / 64), dim3(64), 0, st, *io, B, S, *sg);

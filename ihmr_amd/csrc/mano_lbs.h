@@ -126,17 +126,19 @@ __device__ __forceinline__ void rodrigues_bwd(const float* r, const float* dR, f
 }
 
 // ------------------------------------------------------------------------------------- skeleton
-// 192 threads per hand h (tid = 0..191; every thread of the workgroup must call it: block-wide barriers inside).
+// 192 threads per hand h (tid = 0..191; every thread of the workgroup must call it: block-wide barriers inside; threads that own
+// no hand call it with active = false and only take part in the barriers).
 // TWO_HAND: hands [0,B) right, [B,2B) left of sample (h - B); joints out is (B,42,3) (posed joints only; the
 // 5 tips are written by the skin kernel), else (N,16,3).  sk = SK_STRIDE floats of LDS owned by this hand.
 template <bool TWO_HAND>
 __device__ __forceinline__ void lbs_skel_hand(const ihmr_mano& m, const float* __restrict__ orient,
                                               const float* __restrict__ pose, const float* __restrict__ betas,
                                               const float* __restrict__ trans, int B, float* __restrict__ skel,
-                                              float* __restrict__ joints, float* sk, int h, int tid) {
+                                              float* __restrict__ joints, float* sk, int h, int tid_in, bool active = true) {
     const bool left = TWO_HAND && h >= B;
+    const int tid = active ? tid_in : (1 << 20);       // an inactive thread fails every range test below
     float* sR = sk + SK_R; float* sJ = sk + SK_J; float* sG = sk + SK_G; float* sA = sk + SK_A;
-    const int my_depth = m.depth[tid / 12], my_parent = m.parents[tid / 12];   // kinematic tree: read once, up front
+    const int my_depth = active ? m.depth[tid_in / 12] : -1, my_parent = active ? m.parents[tid_in / 12] : 0;   // kinematic tree: read once, up front
     float* sPF = sk + SK_PF; float* sPose = sk + SK_POSE; float* sBeta = sk + SK_BETA; float* sShift = sk + SK_SHIFT;
     if (tid < 48) {
         float v = tid < 3 ? orient[h * 3 + tid] : pose[h * 45 + tid - 3];
@@ -192,7 +194,7 @@ __device__ __forceinline__ void lbs_skel_hand(const ihmr_mano& m, const float* _
         }
         __syncthreads();
     }
-    {
+    if (active) {
         const int j = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
         const float* G = sG + 12 * j;
         sA[12 * j + e] = c < 3 ? G[e] : G[4 * r + 3] - (G[4 * r + 0] * sJ[3 * j] + G[4 * r + 1] * sJ[3 * j + 1] + G[4 * r + 2] * sJ[3 * j + 2]);
@@ -451,15 +453,14 @@ struct LbsBwdShared {
 // dynamic LDS: float part[nseg][12] -- per-segment partial sums of dA (nseg is a property of the weight matrix:
 // 248 for 4 bones per vertex, up to LBS_SEG_CAP if dense); with it the workgroup needs ~38 KB: four fit a CU (1024 hands
 // = one round of the 256 CUs); d v_posed goes through the workspace (L2) instead of LDS for that
+// The backward of ONE hand by LBS_THREADS (256) threads tid = 0..255 (block-wide barriers inside: every thread of the workgroup
+// calls it, with its own hand's LDS).  lbs_bwd1_kernel = one hand per workgroup; opt_tail_kernel (refine.h) = both hands of a sample.
 template <bool TWO_HAND>
-__global__ __launch_bounds__(LBS_THREADS, 4) void lbs_bwd1_kernel(ihmr_mano m, LbsWork wk, int B,
-                                                               const float* __restrict__ d_verts,
-                                                               const float* __restrict__ d_joints,
-                                                               float* __restrict__ d_orient, float* __restrict__ d_betas,
-                                                               float* __restrict__ d_trans, int need_mask) {
-    __shared__ LbsBwdShared bw;
-    extern __shared__ __attribute__((aligned(16))) float bwd1_part[];   // [nseg][12]
-    const int h = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void lbs_bwd1_hand(const ihmr_mano& m, const LbsWork& wk, int B, int h, int tid, LbsBwdShared& bw,
+                                              float* bwd1_part /* [nseg][12], LDS */,
+                                              const float* __restrict__ d_verts, const float* __restrict__ d_joints,
+                                              float* __restrict__ d_orient, float* __restrict__ d_betas,
+                                              float* __restrict__ d_trans, int need_mask) {
     const bool left = TWO_HAND && h >= B;
     const int b = TWO_HAND ? (left ? h - B : h) : 0;
     const bool need_orient = need_mask & 1, need_pose = need_mask & 2, need_betas = need_mask & 4, need_trans = need_mask & 8;
@@ -794,6 +795,17 @@ __global__ __launch_bounds__(LBS_THREADS, 4) void lbs_bwd1_kernel(ihmr_mano m, L
             if (lane == 0) d_betas[h * 10 + l] = acc;
         }
     }
+}
+
+template <bool TWO_HAND>
+__global__ __launch_bounds__(LBS_THREADS, 4) void lbs_bwd1_kernel(ihmr_mano m, LbsWork wk, int B,
+                                                               const float* __restrict__ d_verts,
+                                                               const float* __restrict__ d_joints,
+                                                               float* __restrict__ d_orient, float* __restrict__ d_betas,
+                                                               float* __restrict__ d_trans, int need_mask) {
+    __shared__ LbsBwdShared bw;
+    extern __shared__ __attribute__((aligned(16))) float bwd1_part[];   // [nseg][12]
+    lbs_bwd1_hand<TWO_HAND>(m, wk, B, (int)blockIdx.x, (int)threadIdx.x, bw, bwd1_part, d_verts, d_joints, d_orient, d_betas, d_trans, need_mask);
 }
 
 // ------------------------------------------------------------------------------------- backward 2

@@ -380,6 +380,44 @@ __global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_op
     lbs_skel_hand<true>(m, io.orient, io.pose, io.shape, io.trans, B, wk.lbs.skel, wk.joints_raw, sk[hl], hl * B + b, tid % 192);
 }
 
+// Tail of a refinement iteration in ONE launch per sample (stages that do not move the finger pose: their LBS backward has no
+// batch-wide GEMM): collision sampling + joint losses (= opt_sample_loss_kernel), the LBS backward of both hands of the sample
+// (= lbs_bwd1_kernel, threads [0,256) right hand, [256,512) left hand), and -- STEP -- the optimizer step that closes the iteration
+// plus both skeletons of the next one (= opt_adam_skel_kernel).  Each phase consumes what the previous one of the SAME workgroup
+// wrote (g_verts / g_joints, then the parameter gradients): two launch boundaries and their tails fewer per iteration, nothing else
+// changes -- the phases are the same device functions, the results the same bits.  grid = B, block = 512, 2 workgroups per CU
+// (~56 KB static + 2 x nseg x 48 B dynamic LDS).
+template <bool STEP>
+__global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_mano m, ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,
+                                                                         VertLayout vl, SdfWorkspace ws, int need_cam, int need_mask,
+                                                                         ParamStep st, int* inside_count) {
+    __shared__ LossShared sh;
+    __shared__ float red16[SDF_SAMPLE_THREADS / WAVE];
+    __shared__ LbsBwdShared bw[2];
+    extern __shared__ __attribute__((aligned(16))) float tail_part[];   // [2][nseg][12]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    // ---- phase 1: collision sampling (waves 0-6) + joint / translation / finger losses (wave 7)
+    if (tid >= OPT_SAMPLE_WORKERS) opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS, need_cam);
+    const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
+    const float gs = w.collision * mask / (ws.loss_div * (float)(io.norm_batch > 0 ? io.norm_batch : B));
+    sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, io.coll_per_vert, io.coll_origin_scale, nullptr, wk.g_verts, B, gs,
+                     io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
+    __syncthreads();         // g_verts / g_joints of this sample: written above by this workgroup, read below by it
+    // ---- phase 2: LBS backward of both hands
+    const int hl = tid / LBS_THREADS;
+    lbs_bwd1_hand<true>(m, wk.lbs, B, hl * B + b, tid % LBS_THREADS, bw[hl], tail_part + (size_t)hl * m.nseg * 12, wk.g_verts, wk.g_joints,
+                        wk.g_orient, wk.g_shape, wk.g_trans, need_mask);
+    if (!STEP) return;
+    __syncthreads();         // the parameter gradients of this sample are in place
+    // ---- phase 3: the optimizer step of this iteration, then both skeletons of the next one (threads [0,192) / [192,384))
+    if (b == 0 && tid >= 384 && tid < 384 + SDF_NZERO) sdf_zero_counter(inside_count, tid - 384);   // the next iteration's collision kernels start from zero
+    if (st.mask && tid < OPT_NPARAM) { opt_snapshot_losses(io, B, st, b, tid); opt_param_apply(io, wk, B, st, b, tid); }
+    __syncthreads();         // the updated parameters are read back below by other threads of this workgroup
+    const int hs = tid / 192;
+    lbs_skel_hand<true>(m, io.orient, io.pose, io.shape, io.trans, B, wk.lbs.skel, wk.joints_raw, bw[hs < 2 ? hs : 0].sk, (hs < 2 ? hs : 0) * B + b, tid % 192,
+                        hs < 2);
+}
+
 // The reference's packed prediction vector final_params (B,122) = [cam 3 | R orient 3 | R pose 45 | L orient 3 |
 // L pose 45 | R shape 10 | L shape 10 | trans 3] (baseline_model.py:262-270, mlp_model.py:426-439) scattered into
 // the per-group state buffers of ihmr_opt_io.  grid = B, block = 128.

@@ -153,7 +153,8 @@ class OptimizeModel:
         self.io = hip.OptIO(**{k: v.data_ptr() for k, v in self.buf.items()}, norm_batch=self.norm_batch,
                             sdf_align_corners=int(bool(getattr(self.opt, "sdf_align_corners", False))),
                             sdf_loss_divisor=float(getattr(self.opt, "sdf_loss_divisor", 0.0) or 0.0),
-                            sdf_no_candidate_lists=int(bool(getattr(self.opt, "sdf_no_candidate_lists", False))))
+                            sdf_no_candidate_lists=int(bool(getattr(self.opt, "sdf_no_candidate_lists", False))),
+                            no_fused_tail=int(bool(getattr(self.opt, "no_fused_tail", False))))
         self.mano_params_weight = z(B, 2)
         self.init = {}
 
