@@ -813,7 +813,9 @@ __global__ __launch_bounds__(LBS_THREADS, 4) void lbs_bwd1_kernel(ihmr_mano m, L
 // v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate = a k-ordered fmaf chain): M = pose features (5 tiles of 32),
 // N = hands (tiles of 32), K = vertex coordinates, split into LBS_KG groups of LBS_KC 32-column chunks whose
 // partial sums part[kg][hand][e] are added in index order by bwd3 (bit-reproducible, no atomics).
-// grid = (5, ceil(N/32), LBS_KG), block = one wave.  Lane l feeds row/column l % 32; the K index of a chunk is
+// grid = (5, ceil(N/32), LBS_KG), block = one wave (four waves per workgroup, one K group each -- 1000 workgroups instead of 4000 --
+// changes nothing: 27.1 against 26.0 us per 1024 hands; the kernel is bound by address processing, not by workgroup dispatch).
+// Lane l feeds row/column l % 32; the K index of a chunk is
 // permuted so that lane half l / 32 owns 16 CONSECUTIVE columns (k = k0 + 16 (l/32) + s at MFMA step s): every
 // lane then streams 64 contiguous bytes of its basis row / its hand's gradient row, no LDS staging.
 typedef float lbs_f32x16 __attribute__((ext_vector_type(16)));

@@ -92,6 +92,7 @@ class OptimizeRef:
         self.optimizer_name = optimizer
         self.trace = []
         self.selected = []
+        self.select_table = []
 
     # optimize_model.py:120-168
     def set_input(self, data):
@@ -222,6 +223,8 @@ class OptimizeRef:
             all_losses = filter_by_losses(all_losses, stage["filter_loss"])
             sel, idxs = select_params(all_params, all_losses, stage["select_loss"])
             self.selected.append(idxs.cpu().numpy().copy())
+            # (S,B) table the argmin ran over: lets a test tell a different choice between numerically tied snapshots from a wrong one
+            self.select_table.append(all_losses[stage["select_loss"]].reshape(len(mid), -1).cpu().numpy().copy())
             for n, v in sel.items():
                 setattr(self, n, v)
         self.forward()
