@@ -307,9 +307,9 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     __shared__ unsigned parity[SDF_NCOL];
     __shared__ int cur[SDF_NCOL];
     __shared__ float red[6][PT / WAVE];
-    __shared__ float box[4];
     __shared__ int scratch[PT / WAVE];
-    __shared__ unsigned rayq[SDF_RAYQ];            // (triangle | column << 11) pairs of the ray-parity phase
+    __shared__ unsigned rayq[SDF_RAYQ];            // (triangle | column << 11) pairs of the ray-parity phase (carrying the packed corner
+                                                   // ids instead of the triangle, 8 bytes per pair, is slower: 44.0 -> 47.1 us per 1024 hands)
     __shared__ int blk_inside, blk_base, blk_base_a;
     const int H = blockIdx.x, hnd = H / B, b = H % B, tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
     SDF_TK(long long pk_[8]; pk_[0] = SDF_STAMP();)
@@ -319,28 +319,26 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     // ---- bounding box (min / max are exact, any order); a thread owns vertices tid, tid + PT, ...
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     float oq[VPT][3];
+    struct F3 { float x, y, z; };        // a vertex as ONE 12-byte load (rows of 3 floats, 4-byte aligned)
 #pragma unroll
     for (int rep = 0; rep < VPT; ++rep) {
         oq[rep][0] = oq[rep][1] = oq[rep][2] = 0.f;
         const int v = tid + rep * PT;
         if (v < NV) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float x = own[3 * v + k];
-                oq[rep][k] = other[3 * v + k];
-                vn[3 * v + k] = x;
-                mn[k] = fminf(mn[k], x);
-                mx[k] = fmaxf(mx[k], x);
-            }
+            const F3 o = reinterpret_cast<const F3*>(own)[v], q = reinterpret_cast<const F3*>(other)[v];
+            oq[rep][0] = q.x; oq[rep][1] = q.y; oq[rep][2] = q.z;
+            vn[3 * v] = o.x; vn[3 * v + 1] = o.y; vn[3 * v + 2] = o.z;
+            mn[0] = fminf(mn[0], o.x); mn[1] = fminf(mn[1], o.y); mn[2] = fminf(mn[2], o.z);
+            mx[0] = fmaxf(mx[0], o.x); mx[1] = fmaxf(mx[1], o.y); mx[2] = fmaxf(mx[2], o.z);
         }
     }
-    // face indices of this lane's (up to four) triangles: issued early, consumed after the box is known
+    // face indices of this lane's (up to four) triangles (packed: one load each): issued early, consumed after the box is known
     constexpr int TRI_IT = (NFP + PT - 1) / PT;
     int fidx[TRI_IT][3];
 #pragma unroll
     for (int it = 0; it < TRI_IT; ++it) {
-        const int f = min(tid + it * PT, NFP - 1);
-        fidx[it][0] = faces[f]; fidx[it][1] = faces[NFP + f]; fidx[it][2] = faces[2 * NFP + f];
+        const unsigned pk = ws.fpk[hnd][min(tid + it * PT, NFP - 1)];
+        fidx[it][0] = (int)(pk & 1023u); fidx[it][1] = (int)((pk >> 10) & 1023u); fidx[it][2] = (int)(pk >> 20);
     }
     // state of the temporal candidate lists, requested now and used much later: the hand's reference pose (this thread's vertices)
     // and which voxels of this thread's two columns have a list
@@ -350,8 +348,11 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
 #pragma unroll
     for (int rep = 0; rep < VPT; ++rep) {
         const int v = tid + rep * PT;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) rf[rep][k] = (lists_on && !ws.force_rebuild && v < NV) ? ws.vn_ref[(size_t)H * NV3 + 3 * v + k] : 0.f;
+        rf[rep][0] = rf[rep][1] = rf[rep][2] = 0.f;
+        if (lists_on && !ws.force_rebuild && v < NV) {
+            const F3 r = reinterpret_cast<const F3*>(ws.vn_ref + (size_t)H * NV3)[v];
+            rf[rep][0] = r.x; rf[rep][1] = r.y; rf[rep][2] = r.z;
+        }
     }
 #pragma unroll
     for (int rep = 0; rep < CPT; ++rep)
@@ -367,22 +368,24 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         parity[tid + rep * PT] = 0u;
     }
     SDF_LDS_BARRIER();
-    if (tid == 0) {
+    // every thread finishes the reduction itself (min / max are exact and order-free: the same box in every thread; the wave results
+    // are read as broadcasts) -- no serial section of one thread, no second barrier
+    float cx, cy, cz, sc;
+    {
         float lo[3], hi[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             lo[k] = red[k][0]; hi[k] = red[3 + k][0];
+#pragma unroll
             for (int w = 1; w < PT / WAVE; ++w) { lo[k] = fminf(lo[k], red[k][w]); hi[k] = fmaxf(hi[k], red[3 + k][w]); }
         }
-        box[0] = (lo[0] + hi[0]) * 0.5f;
-        box[1] = (lo[1] + hi[1]) * 0.5f;
-        box[2] = (lo[2] + hi[2]) * 0.5f;
-        box[3] = 0.6f * fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));  // (1 + 0.2) * 0.5 * max extent
+        cx = (lo[0] + hi[0]) * 0.5f;
+        cy = (lo[1] + hi[1]) * 0.5f;
+        cz = (lo[2] + hi[2]) * 0.5f;
+        sc = 0.6f * fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));  // (1 + 0.2) * 0.5 * max extent
     }
-    SDF_LDS_BARRIER();
-    const float cx = box[0], cy = box[1], cz = box[2], sc = box[3];
     SDF_TK(pk_[1] = SDF_STAMP();)
-    if (tid < 4) ws.box[H * 4 + tid] = box[tid];
+    if (tid < 4) ws.box[H * 4 + tid] = tid == 0 ? cx : (tid == 1 ? cy : (tid == 2 ? cz : sc));
     // ---- normalise own vertices into [-1,1]^3; which voxels will the other hand's vertices read?
 #pragma unroll
     for (int rep = 0; rep < VPT; ++rep) {
@@ -537,13 +540,13 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     //      re-derives the triangle's constants (same expressions: the same bits) and does the (u,v) test and the hit mask.
     {
         const unsigned* fpk = ws.fpk[hnd];
-        int cnt[TRI_IT], jm0[TRI_IT], kr[TRI_IT];       // per triangle: needed columns in its box, j mask shift / width packed, k range packed
+        int cnt[TRI_IT], kr[TRI_IT];       // per triangle: needed columns in its box, k range packed (+ the j mask below)
         unsigned jmk[TRI_IT];
         int mine = 0;
 #pragma unroll
         for (int it = 0; it < TRI_IT; ++it) {
             const int f = tid + it * PT;
-            cnt[it] = 0; jmk[it] = 0u; kr[it] = 0; jm0[it] = 0;
+            cnt[it] = 0; jmk[it] = 0u; kr[it] = 0;
             if (f >= NF) continue;
             const int fa = fidx[it][0], fb = fidx[it][1], fc = fidx[it][2];
             const float ay = vn[3 * fa + 1], az = vn[3 * fa + 2], by = vn[3 * fb + 1], bz = vn[3 * fb + 2], cy2 = vn[3 * fc + 1], cz2 = vn[3 * fc + 2];
