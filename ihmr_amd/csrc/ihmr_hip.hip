@@ -203,9 +203,10 @@ static void lbs_forward_launch(const ihmr_mano* m, bool two_hand, const float* o
 
 static void lbs_backward_launch(const ihmr_mano* m, bool two_hand, int N, int B, const float* d_verts, const float* d_joints,
                                 float* d_orient, float* d_pose, float* d_betas, float* d_trans, int need_mask, const LbsWork& wk,
-                                hipStream_t st) {
+                                hipStream_t st, bool bwd1_done = false) {
     const size_t part_lds = (size_t)m->nseg * 12 * sizeof(float);
-    if (two_hand)
+    if (bwd1_done) {}        // (the per-hand part ran inside opt_tail_kernel)
+    else if (two_hand)
         hipLaunchKernelGGL(lbs_bwd1_kernel<true>, dim3(N), dim3(LBS_THREADS), part_lds, st, *m, wk, B, d_verts, d_joints, d_orient,
                            d_betas, d_trans, need_mask);
     else
@@ -424,9 +425,11 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     ParamStep step{0, 0.f, 0.f, 1.f, -1, 1, 0};   // iteration 0: no step yet, zero the optimizer state
     // a stage that moves neither the finger pose nor the shape keeps v_posed: computed in its first iteration, reused after
     const bool vposed_fixed = (pm & (IHMR_PB_POSE_R | IHMR_PB_POSE_L | IHMR_PB_SHAPE_R | IHMR_PB_SHAPE_L)) == 0;
-    // Stages whose LBS backward is per hand only (no finger pose): the tail of an iteration -- sampling + losses, LBS backward, optimizer
-    // step + next skeletons -- is ONE launch per sample (opt_tail_kernel): 4 launches per iteration instead of 6
-    const bool fused_tail = need_mask != 0 && (need_mask & 2) == 0 && !io->no_fused_tail;
+    // The tail of an iteration -- sampling + losses, LBS backward of both hands, and in the stages that do not move the finger pose also the
+    // optimizer step + next skeletons -- is ONE launch per sample (opt_tail_kernel): 4 launches per iteration instead of 6 (finger-pose
+    // stage, whose backward continues with a batch-wide GEMM: 7 instead of 8)
+    const bool fused_tail = need_mask != 0 && !io->no_fused_tail;
+    const bool pose_stage = (need_mask & 2) != 0;
     const size_t tail_lds = (size_t)2 * m->nseg * 12 * sizeof(float);
     for (int it = 0; it < sg->n_iters; ++it) {
         // the first iteration of a stage starts the candidate lists over: the select step of the previous stage may have moved
@@ -436,18 +439,21 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
         const ParamStep next{pm, w->shape_reg, sgd ? sg->lr : (float)((double)sg->lr / bc1), (float)sqrt(bc2),
                              (it % sg->save_freq == 0) ? S++ : -1, 0, sgd};
         if (fused_tail) {
-            // head: only the first iteration needs the stand-alone kernel (zero the optimizer state, first skeletons); afterwards
-            // the tail of iteration it - 1 has already applied its step and written the skeletons of iteration it
-            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, vposed_fixed && it > 0, it == 0 ? 2 : 1, /*head=*/it == 0, /*tail=*/false);
+            // head (optimizer step of the previous iteration + skeletons): stand-alone in the first iteration (zero the optimizer state,
+            // first skeletons) and in the finger-pose stage; otherwise the tail of iteration it - 1 has done it
+            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, vposed_fixed && it > 0, it == 0 ? 2 : 1, /*head=*/it == 0 || pose_stage, /*tail=*/false);
             if (rc) return rc;
             SdfWorkspace ws = opt_sdf_ws(io, wk, B, it == 0 ? 2 : 1);
             VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
-            if (it + 1 < sg->n_iters)
+            if (!pose_stage && it + 1 < sg->n_iters)
                 hipLaunchKernelGGL(opt_tail_kernel<true>, dim3(B), dim3(SDF_SAMPLE_THREADS), tail_lds, st, *m, *io, wk, B, *w, vl, ws, need_cam, need_mask,
                                    next, ws.inside_count);
             else
                 hipLaunchKernelGGL(opt_tail_kernel<false>, dim3(B), dim3(SDF_SAMPLE_THREADS), tail_lds, st, *m, *io, wk, B, *w, vl, ws, need_cam, need_mask,
                                    next, ws.inside_count);
+            if (pose_stage)
+                lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
+                                    wk.lbs, st, /*bwd1_done=*/true);
         } else {
             int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, vposed_fixed && it > 0, it == 0 ? 2 : 1);   // applies the step of iteration it - 1 first
             if (rc) return rc;

@@ -380,10 +380,10 @@ __global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_op
     lbs_skel_hand<true>(m, io.orient, io.pose, io.shape, io.trans, B, wk.lbs.skel, wk.joints_raw, sk[hl], hl * B + b, tid % 192);
 }
 
-// Tail of a refinement iteration in ONE launch per sample (stages that do not move the finger pose: their LBS backward has no
-// batch-wide GEMM): collision sampling + joint losses (= opt_sample_loss_kernel), the LBS backward of both hands of the sample
-// (= lbs_bwd1_kernel, threads [0,256) right hand, [256,512) left hand), and -- STEP -- the optimizer step that closes the iteration
-// plus both skeletons of the next one (= opt_adam_skel_kernel).  Each phase consumes what the previous one of the SAME workgroup
+// Tail of a refinement iteration in ONE launch per sample: collision sampling + joint losses (= opt_sample_loss_kernel), the LBS
+// backward of both hands of the sample (= lbs_bwd1_kernel, threads [0,256) right hand, [256,512) left hand), and -- STEP: stages that
+// do not move the finger pose, whose LBS backward ends here (the finger-pose stage goes on with a batch-wide GEMM) -- the optimizer
+// step that closes the iteration plus both skeletons of the next one (= opt_adam_skel_kernel).  Each phase consumes what the previous one of the SAME workgroup
 // wrote (g_verts / g_joints, then the parameter gradients): two launch boundaries and their tails fewer per iteration, nothing else
 // changes -- the phases are the same device functions, the results the same bits.  grid = B, block = 512, 2 workgroups per CU
 // (~56 KB static + 2 x nseg x 48 B dynamic LDS).
