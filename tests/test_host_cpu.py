@@ -1,7 +1,10 @@
 """Host-side logic that needs no GPU: prediction-file schema, refinement-batch construction, strategy plumbing."""
+import os
 import types
 import numpy as np
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _fake_preds(B, seed=0):
@@ -182,3 +185,40 @@ def test_mpvpe_known_answers():
     # counted hands: sample 0 right (1 mm everywhere), sample 0 left (0), sample 1 right (0); sample 1 left has no annotation
     assert abs(ev.mpvpe_3d - 0.001 / 3) < 1e-9
     assert ev.metric_sums()[8] == 3 * 778
+
+
+def test_bench_quotes_only_profiles_of_the_loaded_library(monkeypatch):
+    """bench.py takes `roofline.traffic` from a committed rocprofv3 PMC summary only when the summary's `_meta.json` records the source
+    hash of the library that is loaded (round 2's line quoted a profile of older code); a profile of other code is never quoted."""
+    import json as _json
+    import bench
+    from ihmr_amd import hip
+    metas = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_meta.json")]
+    assert metas, "profiles/ holds no source-hash records"
+    with open(os.path.join(ROOT, "profiles", sorted(metas)[0])) as fh:
+        good = _json.load(fh)["srchash"]
+    monkeypatch.setattr(hip, "loaded_source_hash", lambda: good)
+    prefix, meta = bench.committed_profile(None, None)
+    assert prefix is not None and meta["srchash"] == good
+    t, src, us = bench.pmc_traffic("sdf_dist_kernel", meta["batches_per_launch"], meta["config"]) if meta["config"] == "opt" else (1.0, "x", 1.0)
+    assert t and src
+    monkeypatch.setattr(hip, "loaded_source_hash", lambda: "0" * 64)
+    assert bench.committed_profile(None, None) == (None, None)
+    assert bench.pmc_traffic("sdf_dist_kernel", 7) == (None, None, None)
+    monkeypatch.setattr(hip, "loaded_source_hash", lambda: None)          # IHMR_HIP_LIBRARY override / no build record
+    assert bench.committed_profile(None, None) == (None, None)
+
+
+def test_committed_profiles_belong_to_the_committed_sources():
+    """The final-code profile series of the round was taken from exactly the sources in the tree (hash of csrc/ + the header + the
+    hipcc flags), so the driver's bench line can quote it."""
+    import json as _json
+    from ihmr_amd import hip
+    cur = hip._source_hash()
+    hits = []
+    for f in os.listdir(os.path.join(ROOT, "profiles")):
+        if f.endswith("_meta.json"):
+            with open(os.path.join(ROOT, "profiles", f)) as fh:
+                if _json.load(fh)["srchash"] == cur:
+                    hits.append(f)
+    assert any("_f7_" in f for f in hits) and any("baseline" in f for f in hits) and any("mlp" in f for f in hits), hits
