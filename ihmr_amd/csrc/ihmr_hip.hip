@@ -213,7 +213,9 @@ static void lbs_backward_launch(const ihmr_mano* m, bool two_hand, int N, int B,
         hipLaunchKernelGGL(lbs_bwd1_kernel<false>, dim3(N), dim3(LBS_THREADS), part_lds, st, *m, wk, B, d_verts, d_joints, d_orient,
                            d_betas, d_trans, need_mask);
     if (need_mask & 2) {
-        hipLaunchKernelGGL(lbs_bwd2_kernel, dim3(5, (N + 31) / 32, LBS_KG), dim3(64), 0, st, *m, wk, N);
+        // LDS-tiled form from 64 hands on (one batch of 64 samples = 128 hands: 2 x 25 workgroups are too few; the streaming form stays there)
+        if (N >= LBS_B2_MIN_HANDS) hipLaunchKernelGGL(lbs_bwd2_lds_kernel, dim3((N + 63) / 64, LBS_KG), dim3(320), 0, st, *m, wk, N);
+        else hipLaunchKernelGGL(lbs_bwd2_kernel, dim3(5, (N + 31) / 32, LBS_KG), dim3(64), 0, st, *m, wk, N);
         if (two_hand) hipLaunchKernelGGL(lbs_bwd3_kernel<true>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
         else hipLaunchKernelGGL(lbs_bwd3_kernel<false>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
     }

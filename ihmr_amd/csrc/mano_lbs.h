@@ -873,6 +873,90 @@ __global__ __launch_bounds__(64) void lbs_bwd2_kernel(ihmr_mano m, LbsWork wk, i
     }
 }
 
+// The same GEMM with its operands staged through LDS (round 3).  A workgroup = five waves, one per 32-feature tile, x 64 hands, for one K
+// group: the 32 x (160 + 64) operand block of a 32-column chunk is loaded with the lanes ALONG k (8 lanes = 128 contiguous bytes of a
+// row; the streaming form above has every lane on a row of its own, i.e. 64 cache lines per load instruction -- bound by address
+// processing) and stored row-major with a row stride of 33 floats, so that the MFMA operand reads (lanes along the rows) hit 32
+// different banks; chunks double-buffered.  Same partial layout, same k -> MFMA step assignment (lane half l / 32 owns 16 consecutive
+// columns): the same bits as the streaming form.  grid = (ceil(N/64), LBS_KG), block = 320.
+#ifndef LBS_B2_MIN_HANDS
+#define LBS_B2_MIN_HANDS 256
+#endif
+#define LBS_B2_LDK 33
+#define LBS_B2_ROWS (160 + 64)
+__global__ __launch_bounds__(320) void lbs_bwd2_lds_kernel(ihmr_mano m, LbsWork wk, int N) {
+    __shared__ float tile[2][LBS_B2_ROWS][LBS_B2_LDK];
+    const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE, l31 = lane & 31, kp = lane >> 5;
+    const int h0 = blockIdx.x * 64, kg = blockIdx.y;
+    // loader: unit u = tid + 320 i, i < 6 (1792 of 1920 slots used): row = u / 8 (0..159 features, 160..223 hands), 4 columns at 4 (u % 8)
+    float v4[6][4];
+    auto load_chunk = [&](int c) {
+        const int k0 = (kg * LBS_KC + c) * 32;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int u = tid + 320 * i, row = u >> 3, k = k0 + 4 * (u & 7);
+            v4[i][0] = v4[i][1] = v4[i][2] = v4[i][3] = 0.f;
+            if (row >= LBS_B2_ROWS) continue;
+            const bool is_a = row < 160;
+            const int r = is_a ? row : h0 + (row - 160);
+            if (is_a ? r >= NPF : r >= N) continue;
+            const float* src = (is_a ? m.posedirs + (size_t)r * NV3 : wk.dvp + (size_t)r * NV3) + k;
+            if (k + 3 < NV3) {
+                typedef float lbs_f4u __attribute__((ext_vector_type(4), aligned(4)));
+                const lbs_f4u x = *reinterpret_cast<const lbs_f4u*>(src);
+                v4[i][0] = x.x; v4[i][1] = x.y; v4[i][2] = x.z; v4[i][3] = x.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v4[i][t] = k + t < NV3 ? src[t] : 0.f;
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int u = tid + 320 * i, row = u >> 3, kq = 4 * (u & 7);
+            if (row >= LBS_B2_ROWS) continue;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) tile[buf][row][kq + t] = v4[i][t];
+        }
+    };
+    lbs_f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < LBS_KC; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < LBS_KC) load_chunk(c + 1);               // in flight during the MFMAs below
+        const float* arow = &tile[cur][wave * 32 + l31][16 * kp];
+        const float* b0row = &tile[cur][160 + l31][16 * kp];
+        const float* b1row = &tile[cur][160 + 32 + l31][16 * kp];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const float a = arow[st], b0 = b0row[st], b1 = b1row[st];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        }
+        if (c + 1 < LBS_KC) store_chunk(cur ^ 1);            // the other buffer: its readers finished before the previous barrier
+        __syncthreads();
+    }
+    // C/D layout: column (hand) = lane & 31, row (feature) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int hand = h0 + 32 * half + l31;
+        if (hand >= N) continue;
+        const lbs_f32x16& acc = half ? acc1 : acc0;
+        float* dst = wk.dpf_part + ((size_t)kg * N + hand) * 136 + wave * 32 + 4 * kp;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int e4 = wave * 32 + 4 * kp + 8 * r4;
+            if (e4 + 3 < 136) *reinterpret_cast<float4*>(dst + 8 * r4) = make_float4(acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------- backward 3
 // finger-pose gradients: dR_j = chain part + pose-feature part (K-group sums in fixed order), through Rodrigues.
 // grid = N, block = 64: the wave first reduces the LBS_KG partial rows (coalesced, all loads in flight at once),
