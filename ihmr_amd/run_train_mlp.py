@@ -38,6 +38,7 @@ def main(argv=None):
     if world == 1:
         torch.cuda.set_device(0)
     B = args.batchSize
+    torch.manual_seed(args.seed)                              # same initial sub-network weights on every rank and in every run (they are broadcast anyway)
     opt = types.SimpleNamespace(isTrain=True, dist=world > 1, process_rank=rank if world > 1 else -1, batchSize=B, inputSize=224,
                                 input_nc=3, num_joints=42, total_params_dim=122, cam_params_dim=3, pose_params_dim=96,
                                 shape_params_dim=20, trans_params_dim=3, model_root="", checkpoints_dir="./checkpoints",
@@ -62,8 +63,9 @@ def main(argv=None):
         model.opt.total_epoch = total_epoch
         torch.cuda.synchronize()
         t0, steps = time.time(), 0
-        first = last = None
+        first = last = None                                     # mean loss over the batches of the first / the last epoch (the same batches)
         for epoch in range(1, total_epoch + 1):                 # train_mlp.py:79-121
+            ep = []
             for b in data:
                 model.set_input(b)
                 model.retrive_prev_prediction()
@@ -71,9 +73,10 @@ def main(argv=None):
                 model.compute_loss(stage["loss_weights"])
                 model.optimize_parameters()
                 steps += 1
-                if first is None:
-                    first = float(model.loss)
-            last = float(model.loss)
+                ep.append(model.loss)                           # (read back after the epoch: no host sync inside the step)
+            last = float(sum(float(x) for x in ep) / len(ep))
+            if first is None:
+                first = last
             model.update_learning_rate(epoch, sid)
         torch.cuda.synchronize()
         dt = time.time() - t0
