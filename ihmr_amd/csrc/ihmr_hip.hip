@@ -180,24 +180,34 @@ extern "C" int ihmr_mano_update_shapedirs(ihmr_mano* m, const float* shapedirs_h
 // ------------------------------------------------------------------------------------------ seam A
 extern "C" size_t ihmr_mano_workspace_bytes(int N) { return lbs_ws_bytes(N); }
 
-static void lbs_forward_launch(const ihmr_mano* m, bool two_hand, const float* orient, const float* pose, const float* betas,
-                               const float* trans, int N, int B, float* verts, float* joints, const LbsWork& wk, hipStream_t st) {
-    // small launches: four instead of eight hands per skin workgroup (half the chain per thread, see lbs_skin_kernel)
+// the skinning launch (REUSE: the workspace holds v_posed of the current pose and shape parameters, see lbs_skin_kernel)
+// small launches: four instead of eight hands per skin workgroup (half the chain per thread)
+template <bool TWO_HAND, bool REUSE>
+static void lbs_skin_launch_mode(const ihmr_mano* m, int N, int B, float* verts, float* joints, const LbsWork& wk, hipStream_t st) {
     const bool small = N <= LBS_SMALL_MAX_HANDS;
     const int hg8 = 8 * (small ? LBS_HG_SMALL : LBS_HG);
     const dim3 skin_grid(8, 4 * ((N + hg8 - 1) / hg8));
+    if (small) hipLaunchKernelGGL((lbs_skin_kernel<TWO_HAND, REUSE, LBS_HG_SMALL>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B,
+                                  verts, joints, wk.v_posed);
+    else hipLaunchKernelGGL((lbs_skin_kernel<TWO_HAND, REUSE, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
+                            joints, wk.v_posed);
+}
+#define LBS_SKIN_FULL 0
+#define LBS_SKIN_REUSE 1
+template <bool TWO_HAND>
+static void lbs_skin_launch(const ihmr_mano* m, int mode, int N, int B, float* verts, float* joints, const LbsWork& wk, hipStream_t st) {
+    if (mode == LBS_SKIN_REUSE) lbs_skin_launch_mode<TWO_HAND, true>(m, N, B, verts, joints, wk, st);
+    else lbs_skin_launch_mode<TWO_HAND, false>(m, N, B, verts, joints, wk, st);
+}
+
+static void lbs_forward_launch(const ihmr_mano* m, bool two_hand, const float* orient, const float* pose, const float* betas,
+                               const float* trans, int N, int B, float* verts, float* joints, const LbsWork& wk, hipStream_t st) {
     if (two_hand) {
         hipLaunchKernelGGL(lbs_skel_kernel<true>, dim3(N), dim3(192), 0, st, *m, orient, pose, betas, trans, B, wk.skel, joints);
-        if (small) hipLaunchKernelGGL((lbs_skin_kernel<true, false, LBS_HG_SMALL>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B,
-                                      verts, joints, wk.v_posed);
-        else hipLaunchKernelGGL((lbs_skin_kernel<true, false, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
-                                joints, wk.v_posed);
+        lbs_skin_launch<true>(m, LBS_SKIN_FULL, N, B, verts, joints, wk, st);
     } else {
         hipLaunchKernelGGL(lbs_skel_kernel<false>, dim3(N), dim3(192), 0, st, *m, orient, pose, betas, trans, B, wk.skel, joints);
-        if (small) hipLaunchKernelGGL((lbs_skin_kernel<false, false, LBS_HG_SMALL>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B,
-                                      verts, joints, wk.v_posed);
-        else hipLaunchKernelGGL((lbs_skin_kernel<false, false, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
-                                joints, wk.v_posed);
+        lbs_skin_launch<false>(m, LBS_SKIN_FULL, N, B, verts, joints, wk, st);
     }
 }
 
@@ -358,7 +368,7 @@ extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
 
 // `prev` = the Adam step of the previous iteration (group < 0: none), applied at the head of the skeleton kernel
 static const ParamStep kNoStep{0, 0.f, 0.f, 1.f, -1, 0, 0};
-// reuse_v_posed: the workspace holds v_posed of the current pose and shape parameters (see lbs_skin_kernel)
+// skin_mode: LBS_SKIN_REUSE = the workspace holds v_posed of the current pose and shape parameters (see lbs_skin_kernel); < 0: no skin launch
 // lists: temporal candidate lists of the collision kernels -- 0 off (single-shot callers), 1 reuse while valid, 2 rebuild now
 // the collision workspace of the fused loop with the switches of this call (lists: 0 off, 1 reuse while valid, 2 rebuild now)
 static SdfWorkspace opt_sdf_ws(const ihmr_opt_io* io, const OptWork& wk, int B, int lists) {
@@ -370,27 +380,14 @@ static SdfWorkspace opt_sdf_ws(const ihmr_opt_io* io, const OptWork& wk, int B, 
     return ws;
 }
 
-// head = the Adam + skeleton launch, tail = the sampling + loss launch (a caller that fuses them into other launches skips them)
+// head = the Adam + skeleton launch, skin = the skinning launch, tail = the sampling + loss launch (a caller that fuses them into other launches skips them)
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
-                       const ihmr_opt_weights& w, const ParamStep& prev, hipStream_t st, int need_cam = 0, bool reuse_v_posed = false,
+                       const ihmr_opt_weights& w, const ParamStep& prev, hipStream_t st, int need_cam = 0, int skin_mode = LBS_SKIN_FULL,
                        int lists = 0, bool head = true, bool tail = true) {
     if (head)
         hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B, true).inside_count);
-    // (small launches: four instead of eight hands per workgroup -- half the chain per thread, see lbs_skin_kernel)
-    const int N2 = 2 * B;
-    const bool small = N2 <= LBS_SMALL_MAX_HANDS;
-    const dim3 skin_grid(8, 4 * ((N2 + 8 * (small ? LBS_HG_SMALL : LBS_HG) - 1) / (8 * (small ? LBS_HG_SMALL : LBS_HG))));
-    if (reuse_v_posed) {
-        if (small) hipLaunchKernelGGL((lbs_skin_kernel<true, true, LBS_HG_SMALL>), skin_grid, dim3(LBS_THREADS), 0, st, *m,
-                                      (const float*)wk.lbs.skel, N2, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
-        else hipLaunchKernelGGL((lbs_skin_kernel<true, true, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m,
-                                (const float*)wk.lbs.skel, N2, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
-    } else {
-        if (small) hipLaunchKernelGGL((lbs_skin_kernel<true, false, LBS_HG_SMALL>), skin_grid, dim3(LBS_THREADS), 0, st, *m,
-                                      (const float*)wk.lbs.skel, N2, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
-        else hipLaunchKernelGGL((lbs_skin_kernel<true, false, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m,
-                                (const float*)wk.lbs.skel, N2, B, io->verts, wk.joints_raw, wk.lbs.v_posed);
-    }
+    // (skin_mode < 0: the tail launch of the previous iteration has skinned the stored v_posed with the new skeletons, opt_tail_kernel<true, true>)
+    if (skin_mode >= 0) lbs_skin_launch<true>(m, skin_mode, 2 * B, B, io->verts, wk.joints_raw, wk.lbs, st);
     SdfWorkspace ws = opt_sdf_ws(io, wk, B, lists);
     VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
     int rc = sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, m->faces_pk, m_left ? m_left->faces_pk : m->faces_pk, B, ws, 0.f,
@@ -427,6 +424,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     ParamStep step{0, 0.f, 0.f, 1.f, -1, 1, 0};   // iteration 0: no step yet, zero the optimizer state
     // a stage that moves neither the finger pose nor the shape keeps v_posed: computed in its first iteration, reused after
     const bool vposed_fixed = (pm & (IHMR_PB_POSE_R | IHMR_PB_POSE_L | IHMR_PB_SHAPE_R | IHMR_PB_SHAPE_L)) == 0;
+    const int keep_mode = vposed_fixed ? LBS_SKIN_REUSE : LBS_SKIN_FULL;
     // The tail of an iteration -- sampling + losses, LBS backward of both hands, and in the stages that do not move the finger pose also the
     // optimizer step + next skeletons -- is ONE launch per sample (opt_tail_kernel): 4 launches per iteration instead of 6 (finger-pose
     // stage, whose backward continues with a batch-wide GEMM: 7 instead of 8)
@@ -443,11 +441,16 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
         if (fused_tail) {
             // head (optimizer step of the previous iteration + skeletons): stand-alone in the first iteration (zero the optimizer state,
             // first skeletons) and in the finger-pose stage; otherwise the tail of iteration it - 1 has done it
-            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, vposed_fixed && it > 0, it == 0 ? 2 : 1, /*head=*/it == 0 || pose_stage, /*tail=*/false);
+            // ... and in a stage that keeps v_posed (translation, orientation) the tail has skinned the next vertices as well: 3 launches
+            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? LBS_SKIN_FULL : (vposed_fixed ? -1 : keep_mode), it == 0 ? 2 : 1,
+                                 /*head=*/it == 0 || pose_stage, /*tail=*/false);
             if (rc) return rc;
             SdfWorkspace ws = opt_sdf_ws(io, wk, B, it == 0 ? 2 : 1);
             VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
-            if (!pose_stage && it + 1 < sg->n_iters)
+            if (vposed_fixed && it + 1 < sg->n_iters)
+                hipLaunchKernelGGL((opt_tail_kernel<true, true>), dim3(B), dim3(SDF_SAMPLE_THREADS), tail_lds, st, *m, *io, wk, B, *w, vl, ws, need_cam, need_mask,
+                                   next, ws.inside_count);
+            else if (!pose_stage && it + 1 < sg->n_iters)
                 hipLaunchKernelGGL(opt_tail_kernel<true>, dim3(B), dim3(SDF_SAMPLE_THREADS), tail_lds, st, *m, *io, wk, B, *w, vl, ws, need_cam, need_mask,
                                    next, ws.inside_count);
             else
@@ -457,7 +460,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
                 lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
                                     wk.lbs, st, /*bwd1_done=*/true);
         } else {
-            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, vposed_fixed && it > 0, it == 0 ? 2 : 1);   // applies the step of iteration it - 1 first
+            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? LBS_SKIN_FULL : keep_mode, it == 0 ? 2 : 1);   // applies the step of iteration it - 1 first
             if (rc) return rc;
             if (need_mask)
                 lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,

@@ -387,7 +387,10 @@ __global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_op
 // wrote (g_verts / g_joints, then the parameter gradients): two launch boundaries and their tails fewer per iteration, nothing else
 // changes -- the phases are the same device functions, the results the same bits.  grid = B, block = 512, 2 workgroups per CU
 // (~56 KB static + 2 x nseg x 48 B dynamic LDS).
-template <bool STEP>
+// SKIN (with STEP, stages that keep v_posed -- neither finger pose nor shape moves): a fourth phase skins the stored v_posed of both
+// hands with the skeletons just computed (= lbs_skin_kernel<true, REUSE>, the same operations in the same order: the same bits), so
+// the next iteration starts at the collision kernels: 3 launches per iteration.
+template <bool STEP, bool SKIN = false>
 __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_mano m, ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,
                                                                          VertLayout vl, SdfWorkspace ws, int need_cam, int need_mask,
                                                                          ParamStep st, int* inside_count) {
@@ -413,9 +416,76 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
     if (b == 0 && tid >= 384 && tid < 384 + SDF_NZERO) sdf_zero_counter(inside_count, tid - 384);   // the next iteration's collision kernels start from zero
     if (st.mask && tid < OPT_NPARAM) { opt_snapshot_losses(io, B, st, b, tid); opt_param_apply(io, wk, B, st, b, tid); }
     __syncthreads();         // the updated parameters are read back below by other threads of this workgroup
+    // (SKIN: the vertex data of phase 4 is requested here, ahead of the skeleton chain: v_posed does not change in such a stage)
+    constexpr int VR = (NV + LBS_THREADS - 1) / LBS_THREADS;
+    const int lt = tid % LBS_THREADS, hv = hl * B + b;
+    float vp[VR][3];
+    float4 wr[VR];
+    uint32_t jr[VR];
+    if (SKIN) {
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            const int v = min(lt + r * LBS_THREADS, NV - 1);
+            const float* s0 = wk.lbs.v_posed + ((size_t)hv * NV + v) * 3;
+            vp[r][0] = s0[0]; vp[r][1] = s0[1]; vp[r][2] = s0[2];
+            wr[r] = m.sparse4 ? m.w4_w[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            jr[r] = m.sparse4 ? m.w4_j[v] : 0u;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     const int hs = tid / 192;
     lbs_skel_hand<true>(m, io.orient, io.pose, io.shape, io.trans, B, wk.lbs.skel, wk.joints_raw, bw[hs < 2 ? hs : 0].sk, (hs < 2 ? hs : 0) * B + b, tid % 192,
                         hs < 2);
+    if (!SKIN) return;
+    // ---- phase 4: the next iteration's vertices (threads [0,256) right hand, [256,512) left hand; the skinning matrices A and the left
+    //      hand's shift are in this hand's LDS record -- visible since the barrier that closes lbs_skel_hand's last LDS phase)
+    const float* sA = bw[hl].sk + SK_A;
+    const float* sShift = bw[hl].sk + SK_SHIFT;
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+        const int v = lt + r * LBS_THREADS;
+        if (v >= NV) break;
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        if (m.sparse4) {
+            const float wv[4] = {wr[r].x, wr[r].y, wr[r].z, wr[r].w};
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                const float4* A4 = reinterpret_cast<const float4*>(sA + 12 * (int)((jr[r] >> (8 * sI)) & 0xffu));
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float4 a = A4[q];
+                    T[4 * q] = __builtin_fmaf(wv[sI], a.x, T[4 * q]);
+                    T[4 * q + 1] = __builtin_fmaf(wv[sI], a.y, T[4 * q + 1]);
+                    T[4 * q + 2] = __builtin_fmaf(wv[sI], a.z, T[4 * q + 2]);
+                    T[4 * q + 3] = __builtin_fmaf(wv[sI], a.w, T[4 * q + 3]);
+                }
+            }
+        } else {
+            for (int j = 0; j < NJ; ++j) {
+                const float wj = m.weights[v * NJ + j];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) T[e] = __builtin_fmaf(wj, sA[12 * j + e], T[e]);
+            }
+        }
+        float out[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) out[q] = T[4 * q + 0] * vp[r][0] + T[4 * q + 1] * vp[r][1] + T[4 * q + 2] * vp[r][2] + T[4 * q + 3];
+        if (hl == 1) {  // optimize_model.py:210-211, 222-228
+            out[0] = -out[0] + sShift[0];
+            out[1] = out[1] + sShift[1];
+            out[2] = out[2] + sShift[2];
+        }
+        float* dst = io.verts + ((size_t)hv * NV + v) * 3;
+        dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2];
+#pragma unroll
+        for (int t = 0; t < IHMR_NUM_TIPS; ++t)
+            if (v == m.tip_ids[t]) {  // fingertip joints are vertices (:201-202)
+                float* jd = wk.joints_raw + ((size_t)b * 42 + (hl ? 21 : 0) + NJ + t) * 3;
+                jd[0] = out[0]; jd[1] = out[1]; jd[2] = out[2];
+            }
+    }
 }
 
 // The reference's packed prediction vector final_params (B,122) = [cam 3 | R orient 3 | R pose 45 | L orient 3 |

@@ -884,7 +884,9 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
         SDF_TK(const long long tk0 = SDF_STAMP();)
         const unsigned ent_l = lane < SDF_ITEM ? glist[item * SDF_ITEM + lane] : 0xffffffffu;
         const int H = (int)((unsigned)__builtin_amdgcn_readlane((int)ent_l, 0) >> 16);   // entry 0 of an item is always valid
-        const int e0 = (half > 0 ? SDF_ITEM / 2 : 0) + wave * vpw;     // this wave's first entry of the item
+        // this wave's entries of the item: e0 + 4 q, q < vpw -- interleaved over the waves, so that the voxels of a partly filled item
+        // (a hand's few late voxels) spread over all four waves: one sphere pass each instead of two on the first wave
+        const int e0 = (half > 0 ? SDF_ITEM / 2 : 0) + wave;
         if (half > 0 && (unsigned)__builtin_amdgcn_readlane((int)ent_l, SDF_ITEM / 2) == 0xffffffffu) return;   // (padding; uniform)
         // 0: the hand's candidate lists are being (re)built -- by this search; 1: they are valid and these voxels have none; -1: no
         // candidate lists (single-shot callers)
@@ -904,7 +906,7 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
         const unsigned* fpk = ws.fpk[H >= ws.B ? 1 : 0];
         unsigned ent4[4];             // this wave's four list entries (uniform)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ent4[q] = q < vpw ? (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + q) : 0xffffffffu;
+        for (int q = 0; q < 4; ++q) ent4[q] = q < vpw ? (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + 4 * q) : 0xffffffffu;
         if (lane < 4) {
             w.vox[lane] = (unsigned short)((lane == 0 ? ent4[0] : (lane == 1 ? ent4[1] : (lane == 2 ? ent4[2] : ent4[3]))) & 0xffffu);
             w.best[lane] = (0x7f800000ull << 32) | 0xffffull;
@@ -1019,7 +1021,7 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
                     int lcnt;
                     const int lmine = __popc(lm);
                     int loff = wave_incl_scan(lmine, lcnt) - lmine;
-                    const int lidx = (mode == 0 ? lidx0 : __builtin_amdgcn_readfirstlane(slot_new) + vs0) + v;
+                    const int lidx = mode == 0 ? lidx0 + 4 * v : __builtin_amdgcn_readfirstlane(slot_new) + vs0 + v;
                     if (lcnt <= SDF_LCAP_L && lidx < SDF_LCAP_V) {
                         unsigned short* dst = ws.lists + ((size_t)H * SDF_LCAP_V + lidx) * SDF_LCAP_L;
                         constexpr int LQ = SDF_LCAP_L / SDF_LIST_K;     // element i at (i % K) * LQ + i / K: each of the K reader lanes gets a contiguous piece
@@ -1045,15 +1047,15 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
         int nj = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            j_ent0[k] = 2 * k < vpw ? (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + 2 * k) : 0xffffffffu;
-            j_ent1[k] = 2 * k < vpw ? (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + 2 * k + 1) : 0xffffffffu;
-            if (j_ent0[k] != 0xffffffffu) nj = k + 1;     // padding sits only at the tail of a hand's run
+            j_ent0[k] = 2 * k < vpw ? (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + 8 * k) : 0xffffffffu;
+            j_ent1[k] = 2 * k < vpw ? (unsigned)__builtin_amdgcn_readlane((int)ent_l, e0 + 8 * k + 4) : 0xffffffffu;
+            if (j_ent0[k] != 0xffffffffu) nj = k + 1;     // padding sits only at the tail of a hand's run: a wave's valid entries are a prefix of its four
         }
         const int lidx_base = mode == 0 ? item * SDF_ITEM - run_start + e0 : 0;
         SDF_WAVE_SYNC();
 #pragma unroll 1
         for (int k = 0; k < nj; ++k)
-            pair_pass(k == 0 ? j_ent0[0] : j_ent0[1], k == 0 ? j_ent1[0] : j_ent1[1], 2 * k, lidx_base + 2 * k);
+            pair_pass(k == 0 ? j_ent0[0] : j_ent0[1], k == 0 ? j_ent1[0] : j_ent1[1], 2 * k, lidx_base + 8 * k);
         flush();
         SDF_TK(tk[0] += 1; tk[1] += tk1 - tk0; tk[2] += (SDF_STAMP() - tk1) - (tk[4] + tk[5] - tk_r0);)
         SDF_CNT(st_full += (unsigned)(lane == 0 ? nmine : 0));
@@ -1065,7 +1067,7 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
             ws.phi[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = sqrtf(__uint_as_float((unsigned)(bst >> 32)));
             // list of the voxel (if it got one: lbits) and the nearest triangle, which starts its next evaluation (sdf_list_search)
             const unsigned tri = (unsigned)(bst & 0xffffu) < (unsigned)NF ? (unsigned)(bst & 0xffffu) : 0u;
-            const int lslot = (mode == 0 ? lidx_base : __builtin_amdgcn_readfirstlane(slot_new)) + lane;
+            const int lslot = mode == 0 ? lidx_base + 4 * lane : __builtin_amdgcn_readfirstlane(slot_new) + lane;
             if (mode >= 0 && lslot < SDF_LCAP_V)
                 ws.lmap[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = (unsigned)lslot | (tri << 16);
         }
