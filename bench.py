@@ -630,12 +630,25 @@ def main():
         ctr_bw = traffic / (main_ms * 1e-3) / 1e9 if (traffic and main_ms) else None
         frac_valu = (ach / FP32_PEAK_TFLOPS) if ach else None
         frac_hbm = (ach_bw / HBM_PEAK_GBS) if ach_bw else None
+        # vector-ALU ISSUE slots: the profile's SQ_INSTS_VALU of this kernel at this launch size x 4 cycles (a wave64 instruction holds
+        # its 16-lane SIMD for four cycles) / (1024 SIMDs x the cycles of this run's launch at the 2.4 GHz peak clock) -- how busy the
+        # vector pipes are with instructions of ANY kind, as opposed to `valu.frac` (useful flops against the packed-FMA peak)
+        issue = None
+        if traffic_src and main_ms:
+            sq = profile_rows(os.path.join(ROOT, traffic_src[:-len("_pmc_traffic.csv")]), "pmc_sq", "sdf_dist_kernel")
+            if sq and sq[0].get("SQ_INSTS_VALU_per_launch"):
+                n_inst = float(sq[0]["SQ_INSTS_VALU_per_launch"])
+                issue = dict(valu_wave_instructions_per_launch=n_inst, simds=1024, cycles_per_wave_instruction=4, clock_ghz=2.4,
+                             frac=n_inst * 4.0 / (1024.0 * main_ms * 1e-3 * 2.4e9),
+                             source="profiles/" + os.path.basename(traffic_src)[:-len("_pmc_traffic.csv")] + "_pmc_sq.csv",
+                             note="share of the vector pipes' issue slots the launch uses (a lower bound: the sustained clock is below "
+                                  "the peak clock): the kernel is bound by instruction issue + exposed latency, not by flops or bytes")
         # both roofs, the binding one (the larger fraction of its peak) is the headline
         hbm_binds = frac_hbm is not None and (frac_valu is None or frac_hbm > frac_valu)
         roofline = dict(bound="hbm" if hbm_binds else "valu",
                         achieved=ach_bw if hbm_binds else ach, peak=HBM_PEAK_GBS if hbm_binds else FP32_PEAK_TFLOPS,
                         unit="GB/s" if hbm_binds else "TFLOP/s", frac=frac_hbm if hbm_binds else frac_valu,
-                        valu=dict(achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=frac_valu),
+                        valu=dict(achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=frac_valu, issue_slots=issue),
                         hbm=dict(achieved=ach_bw, peak=HBM_PEAK_GBS, unit="GB/s", frac=frac_hbm,
                                  counter_traffic_rate=ctr_bw, counter_traffic_frac=(ctr_bw / HBM_PEAK_GBS) if ctr_bw else None,
                                  note="achieved = ALGORITHMIC bytes (every hand's triangle table once + per inside voxel its list and "
@@ -792,8 +805,8 @@ def main():
                         parallelism=f"dp{world} (independent samples, no collective)"),
             roofline=roofline, cpu_baseline=cpu, latency=latency, h2d_inclusive=h2d, large_batch=large, secondary_configs=second,
             # LBS + losses + Adam are nominally HBM work -- 78 KB of algorithmic traffic per sample and
-            # iteration -- and in practice bound by the six dependent kernel boundaries of an iteration
-            lbs_losses_adam=dict(bound="hbm", algorithmic_bytes_per_sample_iteration=78e3, kernel_launches_per_iteration=6,
+            # iteration -- and in practice bound by the dependent kernel boundaries of an iteration (3 / 3 / 4 / 7 launches by stage)
+            lbs_losses_adam=dict(bound="hbm", algorithmic_bytes_per_sample_iteration=78e3, kernel_launches_per_iteration=4.25,
                                  achieved=78e3 * B * world / (amortised * 1e-3) / 1e9, peak=6300.0, unit="GB/s",
                                  frac=78e3 * B * world / (amortised * 1e-3) / 1e9 / (6300.0 * world),
                                  note="whole-iteration rate at the bench's concurrency: the part is latency-, not bandwidth-bound"),

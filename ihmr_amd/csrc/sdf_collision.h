@@ -93,7 +93,9 @@ __host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)H * (SDF_N
 #define SDF_LCAP_L 192               // triangles per list (three 64-lane chunks; a voxel whose list would be longer gets none)
 #define SDF_LIST_K 8                 // lanes that share one voxel's list in sdf_list_search; list element i is stored at (i % K) * (L / K) + i / K
 #define SDF_LIST_ITEM (4 * (WAVE / SDF_LIST_K))   // voxels per work item of sdf_list_search (4 waves)
+#ifndef SDF_LIST_SLACK
 #define SDF_LIST_SLACK 0.04f         // lists stay valid while no vertex of the hand has moved further than this (normalised frame)
+#endif
 __host__ __device__ inline size_t sdf_list_bytes(int H) {
     return (size_t)H * ((size_t)NV3 * 4 + 16 + (size_t)SDF_NCOL * 4 + (size_t)SDF_NVOX * 4 + (size_t)SDF_LCAP_V * SDF_LCAP_L * 2) +
            sdf_xcd_cap(H) * sizeof(unsigned) + 1024;
@@ -1174,7 +1176,9 @@ __device__ __forceinline__ void sdf_list_item(const SdfWorkspace& ws, int item, 
                 const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
                 const float lim = ub + sp[k].w;
                 // cull iff |p - m| - radius > upper bound (exact: such a triangle cannot be the minimum); parked padding: never kept
-                km |= ((int)ids[k] != nr && !(d2 > lim * lim * 1.00001f)) ? (1u << k) : 0u;
+                // (both conditions evaluated, no short circuit: as `&&` this compiles to a branch with exec-mask bookkeeping per candidate)
+                const unsigned keep = (unsigned)!(d2 > lim * lim * 1.00001f) & (unsigned)((int)ids[k] != nr);
+                km |= keep << k;
             }
             // survivors -> the wave's queue: one scan over the per-lane counts
             int cnt;
