@@ -115,11 +115,11 @@ __device__ __forceinline__ int wave_incl_scan(int v, int& total) {
     v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, false);
     v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, false);
     v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, false);
-    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31),
-              t2 = __builtin_amdgcn_readlane(v, 47), t3 = __builtin_amdgcn_readlane(v, 63);
-    const int row = (int)(threadIdx.x & 63) >> 4;
-    v += row == 0 ? 0 : (row == 1 ? t0 : (row == 2 ? t0 + t1 : t0 + t1 + t2));
-    total = t0 + t1 + t2 + t3;
+    // across the four rows of 16: lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows 2 and 3 (two DPP adds; as four
+    // readlanes + a select on the row index the compiler built a branch ladder)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    total = __builtin_amdgcn_readlane(v, 63);
     return v;
 }
 

@@ -856,7 +856,7 @@ __device__ __forceinline__ void sdf_stage_table(const SdfWorkspace& ws, int H, c
 // work counters / phase stamps of one workgroup's pass over its work units (registers; flushed once at the end of the kernel)
 #define SDF_CNT(...) do { if (STATS) { __VA_ARGS__; } } while (0)      // (STATS: template parameter of the distance kernel)
 struct SdfAcc {
-    unsigned dist = 0, full = 0, build = 0, fresh = 0, ref = 0, sph = 0, vox = 0;      // (per workgroup and launch: 32 bits are plenty)
+    unsigned dist = 0, full = 0, build = 0, fresh = 0, ref = 0, sph = 0, vox = 0, refused = 0;      // (per workgroup and launch: 32 bits are plenty)
     SDF_TK(long long tk[7] = {0, 0, 0, 0, 0, 0, 0};)      // items, front, (full: sphere passes), (list: walk), refine, exact, -
 };
 
@@ -1024,6 +1024,7 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
                     const int lmine = __popc(lm);
                     int loff = wave_incl_scan(lmine, lcnt) - lmine;
                     const int lidx = mode == 0 ? lidx0 + 4 * v : __builtin_amdgcn_readfirstlane(slot_new) + vs0 + v;
+                    SDF_CNT(acc.refused += (unsigned)(lane == 0 && !(lcnt <= SDF_LCAP_L && lidx < SDF_LCAP_V) ? 1 : 0));
                     if (lcnt <= SDF_LCAP_L && lidx < SDF_LCAP_V) {
                         unsigned short* dst = ws.lists + ((size_t)H * SDF_LCAP_V + lidx) * SDF_LCAP_L;
                         constexpr int LQ = SDF_LCAP_L / SDF_LIST_K;     // element i at (i % K) * LQ + i / K: each of the K reader lanes gets a contiguous piece
@@ -1282,6 +1283,7 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
             atomicAdd(&ws.stats[6], (unsigned long long)acc.fresh);                          // voxels of hands with valid lists that have none
             atomicAdd(&ws.stats[7], (unsigned long long)acc.build);                          // voxels whose lists were (re)built
             atomicAdd(&ws.stats[8], (unsigned long long)acc.ref);                            // plane + circle tests
+            atomicAdd(&ws.stats[9], (unsigned long long)acc.refused);                        // voxels searched in full that got NO list (too long / no slot left)
         }
     }
 #ifdef SDF_STAMPS

@@ -219,7 +219,7 @@ class OptimizeModel:
         return dict(ray_tests=int(out[0]), dist_evals=int(out[1]), inside_voxels=int(out[2]), needed_voxels=int(out[3]))
 
     SDF_COUNTERS = ("ray_tests", "dist_evals", "inside_voxels", "needed_voxels", "sphere_tests", "voxels_from_lists",
-                    "voxels_without_list", "voxels_rebuilt", "plane_tests")
+                    "voxels_without_list", "voxels_rebuilt", "plane_tests", "lists_refused")
 
     def _drop_graphs(self):
         """Destroy every captured graph of this instance (they are re-captured on demand)."""

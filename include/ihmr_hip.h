@@ -210,7 +210,8 @@ int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
  * recorded afterwards (a stage graph captured while they are on keeps counting); enable = 0: synchronise, copy the sixteen counter
  * slots to out16 (host) and switch them off: {ray tests, exact distances, inside voxels, needed voxels, bounding-sphere tests,
  * voxels answered from their candidate lists, voxels of such hands handed to the full search, voxels whose lists were rebuilt,
- * plane + circle tests, 7 unused}. */
+ * plane + circle tests, voxels searched in full whose candidate list was refused (longer than the list capacity, or no slot left),
+ * 6 unused}. */
 int ihmr_opt_sdf_counters(const ihmr_opt_io* io, int B, unsigned long long* out16, int enable);
 
 /* ------------------------------------------------------------------ image encoder (ResNet-50 + heads) */
