@@ -913,15 +913,11 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
             w.vox[lane] = (unsigned short)((lane == 0 ? ent4[0] : (lane == 1 ? ent4[1] : (lane == 2 ? ent4[2] : ent4[3]))) & 0xffffu);
             w.best[lane] = (0x7f800000ull << 32) | 0xffffull;
         }
-        // list slots of this wave's voxels: by position in the hand's run while the hand rebuilds; fresh ones (one atomic per wave,
-        // requested now, used after the sphere passes) for voxels that appear later
-        int slot_new = 0;
-        if (mode == 1 && lane == 0) {
-            int nv = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) nv += ent4[q] != 0xffffffffu ? 1 : 0;
-            slot_new = atomicAdd(&ws.lnext[H], nv);
-        }
+        // list slots of this wave's voxels: by position in the hand's run while the hand rebuilds; a voxel that appears later takes a
+        // fresh one when -- and only when -- its list is written (most late voxels are refused a list for its length, every
+        // iteration anew: handing them slots up front would use the hand's 1024 up within ~200 iterations).  Lane q keeps the slot of
+        // the wave's q-th voxel.
+        int my_slot = SDF_LCAP_V;
         int npair = 0;
         SDF_TK(const long long tk1 = SDF_STAMP(), tk_r0 = tk[4] + tk[5];)
         auto flush = [&]() {
@@ -1023,7 +1019,13 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
                     int lcnt;
                     const int lmine = __popc(lm);
                     int loff = wave_incl_scan(lmine, lcnt) - lmine;
-                    const int lidx = mode == 0 ? lidx0 + 4 * v : __builtin_amdgcn_readfirstlane(slot_new) + vs0 + v;
+                    int lidx = mode == 0 ? lidx0 + 4 * v : SDF_LCAP_V;
+                    if (mode == 1 && lcnt <= SDF_LCAP_L) {
+                        int sl = 0;
+                        if (lane == 0) sl = atomicAdd(&ws.lnext[H], 1);
+                        lidx = __builtin_amdgcn_readfirstlane(sl);
+                    }
+                    if (lane == vs) my_slot = lidx;
                     SDF_CNT(acc.refused += (unsigned)(lane == 0 && !(lcnt <= SDF_LCAP_L && lidx < SDF_LCAP_V) ? 1 : 0));
                     if (lcnt <= SDF_LCAP_L && lidx < SDF_LCAP_V) {
                         unsigned short* dst = ws.lists + ((size_t)H * SDF_LCAP_V + lidx) * SDF_LCAP_L;
@@ -1070,7 +1072,7 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
             ws.phi[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = sqrtf(__uint_as_float((unsigned)(bst >> 32)));
             // list of the voxel (if it got one: lbits) and the nearest triangle, which starts its next evaluation (sdf_list_search)
             const unsigned tri = (unsigned)(bst & 0xffffu) < (unsigned)NF ? (unsigned)(bst & 0xffffu) : 0u;
-            const int lslot = mode == 0 ? lidx_base + 4 * lane : __builtin_amdgcn_readfirstlane(slot_new) + lane;
+            const int lslot = mode == 0 ? lidx_base + 4 * lane : my_slot;
             if (mode >= 0 && lslot < SDF_LCAP_V)
                 ws.lmap[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = (unsigned)lslot | (tri << 16);
         }
