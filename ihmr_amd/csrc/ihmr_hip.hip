@@ -427,7 +427,8 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     const int keep_mode = vposed_fixed ? LBS_SKIN_REUSE : LBS_SKIN_FULL;
     // The tail of an iteration -- sampling + losses, LBS backward of both hands, and in the stages that do not move the finger pose also the
     // optimizer step + next skeletons -- is ONE launch per sample (opt_tail_kernel): 4 launches per iteration instead of 6 (finger-pose
-    // stage, whose backward continues with a batch-wide GEMM: 7 instead of 8)
+    // stage, whose backward continues with a batch-wide GEMM: 7 instead of 8); in a stage that keeps v_posed the same launch also skins
+    // the next iteration's vertices: 3 launches (skin_mode < 0 below)
     const bool fused_tail = need_mask != 0 && !io->no_fused_tail;
     const bool pose_stage = (need_mask & 2) != 0;
     const size_t tail_lds = (size_t)2 * m->nseg * 12 * sizeof(float);

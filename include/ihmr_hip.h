@@ -138,9 +138,9 @@ typedef struct ihmr_opt_io {
     /* 1 = every iteration searches all 1538 triangles per voxel (the per-voxel candidate lists that ihmr_opt_run_stage carries from
        iteration to iteration are an exact acceleration; this switch exists to test exactly that) */
     int sdf_no_candidate_lists;
-    int no_fused_tail;          /* 1: every stage runs sampling + losses, the per-hand LBS backward and the optimizer step + skeletons as
-                                 * three launches -- the checker of the fused tail launch; results are identical either way
-                                 * (tests/test_gpu_parity.py) */
+    int no_fused_tail;          /* 1: every stage runs sampling + losses, the per-hand LBS backward, the optimizer step + skeletons and
+                                 * (translation / orientation stages) the skinning of the stored v_posed as separate launches -- the
+                                 * checker of the fused tail launch; results are identical either way (tests/test_gpu_parity.py) */
 } ihmr_opt_io;
 
 typedef struct ihmr_opt_weights { /* strategies/opt_default.py loss_weights */
