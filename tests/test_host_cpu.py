@@ -222,3 +222,30 @@ def test_committed_profiles_belong_to_the_committed_sources():
                 if _json.load(fh)["srchash"] == cur:
                     hits.append(f)
     assert any("_f7_" in f for f in hits) and any("baseline" in f for f in hits) and any("mlp" in f for f in hits), hits
+
+
+def test_committed_profile_carries_what_the_bench_line_quotes():
+    """The rows `bench.py` reads from the committed profile of the driver's launch size exist and are plausible: HBM bytes per launch
+    of the dominant kernel (`roofline.traffic`), its mean duration, and its vector-instruction count (`roofline.valu.issue_slots`)."""
+    import csv
+    import json as _json
+    from ihmr_amd import hip
+    cur = hip._source_hash()
+    prof = os.path.join(ROOT, "profiles")
+    metas = [f for f in os.listdir(prof) if f.endswith("_f7_meta.json")]
+    metas = [f for f in metas if _json.load(open(os.path.join(prof, f)))["srchash"] == cur]
+    assert metas, "no profile of the driver's launch size for these sources"
+    prefix = os.path.join(prof, metas[0][:-len("_meta.json")])
+
+    def row(suffix):
+        with open(f"{prefix}_{suffix}.csv", newline="") as fh:
+            rows = [r for r in csv.DictReader(fh) if r["kernel"].startswith("sdf_dist_kernel")]
+        assert rows, suffix
+        return max(rows, key=lambda r: int(r.get("launches") or r.get("calls")))
+
+    traffic = float(row("pmc_traffic")["hbm_bytes_per_launch"])
+    us = float(row("kernel_stats")["avg_us"])
+    inst = float(row("pmc_sq")["SQ_INSTS_VALU_per_launch"])
+    assert 2e7 < traffic < 5e8 and 10.0 < us < 200.0 and 1e6 < inst < 1e8
+    # issue slots at the peak clock (bench.py: roofline.valu.issue_slots): a fraction of one
+    assert 0.05 < inst * 4.0 / (1024.0 * us * 1e-6 * 2.4e9) < 1.0
