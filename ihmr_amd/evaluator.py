@@ -59,7 +59,7 @@ def get_single_verts_error(pred_verts, gt_verts, root_weights, scale_factor):
 
 
 class Evaluator:
-    def __init__(self, mano_models=None, data_list=None):
+    def __init__(self, mano_models=None, data_list=None, image_root=""):
         self.left_hand_faces = None if mano_models is None else mano_models["left"].faces
         self.right_hand_faces = None if mano_models is None else mano_models["right"].faces
         # wrist row of the joint regressor per hand (MPVPE root), (2,778): 0 = right, 1 = left
@@ -67,7 +67,9 @@ class Evaluator:
         if mano_models is not None and hasattr(mano_models["right"], "J_regressor"):
             jr = lambda m: np.asarray(m.J_regressor.detach().cpu().numpy() if hasattr(m.J_regressor, "detach") else m.J_regressor)[0]
             self.root_weights = np.stack([jr(mano_models["right"]), jr(mano_models["left"])]).astype(np.float32)
-        self.data_list = data_list or {}
+        self.data_list = data_list or {}        # list (the reference's dataset.data_list) or dict: data_idx -> metadata
+        self.image_root = image_root
+        self.save_verts = True
         self.pred_results = []
         self._device_parts = []        # (B,6) float64 device tensors + keep masks, summed lazily
         self._device_vert_parts = []   # (B,2) float64 [sum of per-vertex errors, count]
@@ -127,16 +129,36 @@ class Evaluator:
     def gather_pred(self, pred_results):
         self.pred_results += pred_results
 
-    def update(self, data_idxs, pred_results, hand_type="interacting", scale=1.0):
+    VERT_KEYS = tuple(f"{mode}_{side}_hand_verts" for mode in ("pred", "gt") for side in ("left", "right"))
+
+    def _meta(self, data_idx):
+        dl = self.data_list
+        if isinstance(dl, dict):
+            return dl.get(data_idx, {})
+        return dl[data_idx] if 0 <= data_idx < len(dl) else {}
+
+    def update(self, data_idxs, pred_results, save_verts=True, hand_type="interacting", scale=1.0):
+        """evaluator.py:38-97.  One record per sample: the exported arrays, the per-sample metadata with the reference's
+        defaults (``annot_type`` 'machine', ``hand_type`` 'interacting', ``hand_type_valid`` 1, ``scale`` 1 -- the two
+        keyword arguments override the latter defaults for data without a ``data_list``), with ``save_verts`` the meshes
+        present in ``pred_results`` stored as **float16** (``:66-72``), the two joint metrics, and for ``do_flip`` samples
+        the flip back to the original image (``:100-134``)."""
+        self.save_verts = save_verts
         for i, data_idx in enumerate(np.asarray(data_idxs).tolist()):
-            meta = self.data_list.get(data_idx, {}) if isinstance(self.data_list, dict) else {}
+            meta = self._meta(data_idx)
+            rel = meta.get("img_path", f"synthetic/{data_idx:08d}.jpg")
             single = dict(
-                data_idx=data_idx, img_path_relative=meta.get("img_path", f"synthetic/{data_idx:08d}.jpg"),
-                pred_cam_params=pred_results["pred_cam_params"][i], pred_shape_params=pred_results["pred_shape_params"][i],
+                data_idx=data_idx, pred_cam_params=pred_results["pred_cam_params"][i], pred_shape_params=pred_results["pred_shape_params"][i],
                 pred_pose_params=pred_results["pred_pose_params"][i], pred_hand_trans=pred_results["pred_hand_trans"][i],
-                pred_joints_3d=pred_results["pred_joints_3d"][i], gt_joints_3d=pred_results["gt_joints_3d"][i],
-                collision_loss_origin_scale=pred_results["collision_loss_origin_scale"][i],
-                hand_type=meta.get("hand_type", hand_type), scale=meta.get("scale", scale))
+                pred_joints_3d=pred_results["pred_joints_3d"][i], collision_loss_origin_scale=pred_results["collision_loss_origin_scale"][i],
+                gt_joints_3d=pred_results["gt_joints_3d"][i],
+                img_path=rel if not self.image_root else self.image_root.rstrip("/") + "/" + rel, img_path_relative=rel)
+            for key, default in (("annot_type", "machine"), ("hand_type", hand_type), ("hand_type_valid", 1.0), ("scale", scale)):
+                single[key] = meta.get(key, default)
+            if save_verts:
+                for key in self.VERT_KEYS:
+                    if key in pred_results:
+                        single[key] = np.asarray(pred_results[key][i]).astype(np.float16)
             gt = single["gt_joints_3d"]
             single["j3d_error"] = get_single_joints_error(single["pred_joints_3d"], gt[:, :3], gt[:, 3:], single["scale"])
             single["pa_no_rot_inter_j3d_error"] = get_single_pa_inter_joints_error(
@@ -148,7 +170,37 @@ class Evaluator:
                         single["v3d_error"] += get_single_verts_error(pred_results[f"pred_{side}_hand_verts"][i],
                                                                       pred_results[f"gt_{side}_hand_verts"][i],
                                                                       self.root_weights[h], single["scale"])
+            if "do_flip" in pred_results and pred_results["do_flip"][i]:
+                self._flip_back_data(single)
             self.pred_results.append(single)
+
+    def _flip_back_data(self, single):
+        """evaluator.py:100-134: a sample that the loader mirrored (left-only image turned into a right hand) goes back to
+        the original image -- camera x and translation x negated, the two hands' pose blocks swapped with the y / z
+        axis-angle components negated, joint halves swapped with x negated, the two 778-halves of the per-vertex
+        penetration depths swapped, and (with ``save_verts``) the stored meshes swapped and mirrored.  Acts in place on the
+        record's arrays like the reference (which are rows of the exported batch arrays); the metrics were taken before."""
+        single["pred_cam_params"][1] *= -1
+        single["pred_hand_trans"][0] *= -1
+        pose = single["pred_pose_params"].copy()
+        single["pred_pose_params"][:48], single["pred_pose_params"][48:] = pose[48:], pose[:48]
+        single["pred_pose_params"][1::3] *= -1
+        single["pred_pose_params"][2::3] *= -1
+        for key in ("pred_joints_3d", "gt_joints_3d"):
+            j = single[key].copy()
+            single[key][:21], single[key][21:] = j[21:], j[:21]
+            single[key][:, 0] *= -1
+        c = single["collision_loss_origin_scale"].copy()
+        single["collision_loss_origin_scale"][:778], single["collision_loss_origin_scale"][778:] = c[778:], c[:778]
+        if self.save_verts:
+            # the reference indexes all four mesh keys here and raises KeyError when one is missing; this build swaps what
+            # is stored (IHMR-OPT exports no GT meshes and never flips: do_flip is all zeros, optimize_model.py:433)
+            saved = {k: single[k].copy() for k in self.VERT_KEYS if k in single}
+            for key in saved:
+                other = key.replace("left", "right") if "left" in key else key.replace("right", "left")
+                if other in saved:
+                    single[key] = saved[other]
+                    single[key][:, 0] *= -1
 
     def remove_redunc(self):
         """evaluator.py:137-146: drop the padding duplicates (same image id)."""

@@ -313,6 +313,67 @@ def gen_metrics(ns):
     print("metrics.npz")
 
 
+def gen_evaluator(ns):
+    """The reference's own ``Evaluator.update`` (utils/evaluator.py:38-135: per-sample records, fp16 vertex storage with
+    ``save_verts``, the flip-back of ``do_flip`` samples, ``remove_redunc`` + the four metrics) on seeded predictions, and
+    the arguments its ``save_pred_obj`` (utils/opt_utils.py:45-54) hands to ``ry_utils.save_mesh_to_obj`` for the
+    reference's own OptimizeModel result stored in opt_traj.npz (the absent ``ry_utils`` is a stub that records them)."""
+    import importlib
+    import types
+    ev = importlib.import_module("utils.evaluator")
+    rng = np.random.RandomState(33)
+    B = 6
+    models = _mano_models(ns, 1)
+    data_list = [dict(img_path=f"cap0/seq{j // 2}/cam4/image{j}.jpg") for j in range(B)]
+    data_list[1].update(hand_type="right", scale=0.8)
+    data_list[2].update(hand_type="interacting", scale=1.25, annot_type="human")
+    data_list[5]["img_path"] = data_list[0]["img_path"]       # a padding duplicate (opt_dataset.py:49-51)
+    dataset = types.SimpleNamespace(name="synthetic", data_list=data_list, image_root="/data/root")
+    model = types.SimpleNamespace(inputSize=224, mano_models=models)
+    f32 = lambda *s, sc=1.0: (rng.normal(0, sc, s)).astype(np.float32)
+    gtj = np.concatenate([f32(B, 42, 3, sc=0.05), (rng.uniform(size=(B, 42, 1)) > 0.15).astype(np.float32)], axis=2)
+    gtj[3, 0, 3] = 0.0
+    pred = dict(pred_cam_params=f32(B, 3), pred_shape_params=f32(B, 20), pred_pose_params=f32(B, 96, sc=0.3),
+                pred_hand_trans=f32(B, 1, 3, sc=0.03), pred_joints_3d=(gtj[:, :, :3] + f32(B, 42, 3, sc=0.01)).astype(np.float32),
+                gt_joints_3d=gtj, collision_loss_origin_scale=np.abs(f32(B, 1556, sc=0.004)),
+                do_flip=np.array([0, 1, 0, 1, 0, 0], dtype=np.int32), pred_hand_type=np.ones((B, 2), dtype=np.int32),
+                pred_right_hand_verts=f32(B, 778, 3, sc=0.07), pred_left_hand_verts=f32(B, 778, 3, sc=0.07),
+                gt_right_hand_verts=f32(B, 778, 3, sc=0.07), gt_left_hand_verts=f32(B, 778, 3, sc=0.07))
+    out = {f"in_{k}": v.copy() for k, v in pred.items()}
+    out["in_img_path"] = np.array([d["img_path"] for d in data_list])
+    out["in_hand_type"] = np.array([d.get("hand_type", "") for d in data_list])
+    out["in_scale"] = np.array([d.get("scale", -1.0) for d in data_list])
+    e = ev.Evaluator(None, dataset, model)
+    e.update(list(range(B)), {k: v.copy() for k, v in pred.items()}, save_verts=True)
+    num_keys = ["pred_cam_params", "pred_shape_params", "pred_pose_params", "pred_hand_trans", "pred_joints_3d", "gt_joints_3d",
+                "collision_loss_origin_scale", "pred_right_hand_verts", "pred_left_hand_verts", "gt_right_hand_verts", "gt_left_hand_verts"]
+    for i, rec in enumerate(e.pred_results):
+        for k in num_keys:
+            out[f"rec{i}_{k}"] = rec[k]
+        out[f"rec{i}_j3d_error"] = np.array(rec["j3d_error"], dtype=np.float64)
+        out[f"rec{i}_pa_error"] = np.array(rec["pa_no_rot_inter_j3d_error"], dtype=np.float64)
+        out[f"rec{i}_meta"] = np.array([rec["img_path"], rec["img_path_relative"], rec["hand_type"], rec["annot_type"]])
+        out[f"rec{i}_scale"] = np.float64(rec["scale"])
+    e.remove_redunc()
+    out["n_after_remove_redunc"] = np.array(len(e.pred_results))
+    out["metrics"] = np.array([e.mpjpe_3d, e.inter_mpjpe_3d, e.collision_ave, e.collision_max], dtype=np.float64)
+    # without vertex storage: records carry no mesh, the flip-back skips them
+    e2 = ev.Evaluator(None, dataset, model)
+    e2.update(list(range(B)), {k: v.copy() for k, v in pred.items()}, save_verts=False)
+    out["nov_has_verts"] = np.array(["pred_right_hand_verts" in r for r in e2.pred_results])
+    out["nov_rec1_pred_joints_3d"] = e2.pred_results[1]["pred_joints_3d"]
+    # mesh export of the reference's own refinement result
+    traj = np.load(osp.join(HERE, "opt_traj.npz"))
+    calls = []
+    ns.opt_utils.ry_utils.save_mesh_to_obj = lambda path, verts, faces: calls.append((path, np.array(verts), np.array(faces)))
+    res = {k[4:]: traj[k] for k in traj.files if k.startswith("out_")}
+    ns.opt_utils.save_pred_obj("/res/dir", res, _mano_models(ns, 3), 7, 2, 30)
+    (path, verts, faces), = calls
+    out["obj_path"], out["obj_verts"], out["obj_faces"] = np.array(path), verts, faces
+    np.savez_compressed(osp.join(HERE, "evaluator.npz"), **out)
+    print("evaluator.npz", out["metrics"], path, verts.shape, faces.shape, faces.dtype)
+
+
 def make_mlp_batch(B, seed):
     """Synthetic IHMR-MLP batch (schema of data/mlp_dataset.py:185-208) from the OPT synthetic batch."""
     from ihmr_amd.assets import synthetic_mano
@@ -494,6 +555,6 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ns = import_reference()
-    which = sys.argv[1:] or ["losses", "select", "opt_traj", "opt_traj_ragged", "opt_traj_variants", "encoder", "mlp_head", "metrics", "mlp_test", "preprocess", "mlp_train", "encoder_train"]
+    which = sys.argv[1:] or ["losses", "select", "opt_traj", "opt_traj_ragged", "opt_traj_variants", "encoder", "mlp_head", "metrics", "evaluator", "mlp_test", "preprocess", "mlp_train", "encoder_train"]
     for w in which:
         globals()[f"gen_{w}"](ns)

@@ -544,6 +544,39 @@ def test_opt_replays_reference_trajectory():
     _check_against_reference("ref-traj", model, got, g)
 
 
+def test_mesh_export_of_device_result_matches_reference_save_pred_obj(tmp_path):
+    """SURVEY 8(f)4.  The reference's own ``save_pred_obj`` (utils/opt_utils.py:45-54) run on the reference's own refinement of
+    the opt_traj.npz batch recorded what it hands to the OBJ writer (tests/golden/evaluator.npz: obj_*).  Here the HIP
+    OptimizeModel refines the same batch on the device, the result is exported and written by this build's writer, and the FILE is
+    read back: the file name and every face index are identical integers (combined index = concat(faces_r, faces_l + 778),
+    1-based in the file), the vertices equal the exported device meshes to the writer's print precision and the reference's
+    vertices within the trajectory tolerance; the Evaluator stores the same meshes as float16 (evaluator.py:66-72)."""
+    import os.path as osp
+    from ihmr_amd import ry_utils
+    from ihmr_amd.evaluator import Evaluator
+    g, ge = _gold("opt_traj.npz"), _gold("evaluator.npz")
+    model, got = _run_golden_batch(g, None)
+    path = ry_utils.save_pred_obj(str(tmp_path), got, model.mano_models, 7, 2, 30)
+    assert osp.basename(path) == osp.basename(str(ge["obj_path"]))
+    v, f = [], []
+    for line in open(path):
+        t = line.split()
+        (v if t[0] == "v" else f).append([float(x) if t[0] == "v" else int(x) for x in t[1:]])
+    v, f = np.array(v), np.array(f, dtype=np.int64)
+    assert np.array_equal(f - 1, ge["obj_faces"]), "combined face index differs from the reference's"
+    assert np.array_equal(f[:1538] - 1, np.asarray(model.mano_models["right"].faces)) and f.min() == 1 and f.max() == 1556
+    mine = np.concatenate([got["pred_right_hand_verts"][0], got["pred_left_hand_verts"][0]], 0)
+    _report("OBJ vertices vs the exported device meshes", v, mine, atol=5.01e-7)
+    _report("OBJ vertices vs the reference's export", v, ge["obj_verts"], atol=1e-4)
+    ev = Evaluator(model.mano_models)
+    ev.update(np.arange(got["pred_cam_params"].shape[0]), got, save_verts=True)
+    rec = ev.pred_results[0]
+    assert rec["pred_right_hand_verts"].dtype == np.float16
+    assert np.array_equal(rec["pred_right_hand_verts"], got["pred_right_hand_verts"][0].astype(np.float16))
+    assert np.array_equal(rec["pred_left_hand_verts"], got["pred_left_hand_verts"][0].astype(np.float16))
+    assert np.abs(rec["pred_left_hand_verts"].astype(np.float32) - g["out_pred_left_hand_verts"][0]).max() < 1e-4 + 2.5e-4   # fp16 spacing at 0.25 m
+
+
 def test_opt_replays_reference_ragged_trajectory():
     """tests/golden/opt_traj_ragged.npz = the reference's own run on the ragged batch of tests/helpers.py:ragged_opt_batch
     (single-hand samples -> collision mask 0, right wrist missing -> root = joint 21, half weights -> no alignment,

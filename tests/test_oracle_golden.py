@@ -200,6 +200,83 @@ def test_metrics_match_reference():
         close(np.array(p), g[f"pa_err_{i}"], 1e-7, what="pa mpjpe")
 
 
+def _evaluator_inputs(g):
+    pred = {k[3:]: g[k].copy() for k in g if k.startswith("in_") and k not in ("in_img_path", "in_hand_type", "in_scale")}
+    data_list = []
+    for path, ht, sc in zip(g["in_img_path"], g["in_hand_type"], g["in_scale"]):
+        d = dict(img_path=str(path))
+        if str(ht):
+            d["hand_type"] = str(ht)
+        if float(sc) > 0:
+            d["scale"] = float(sc)
+        data_list.append(d)
+    data_list[2]["annot_type"] = "human"
+    return pred, data_list
+
+
+def test_evaluator_records_match_reference():
+    """The reference's own Evaluator.update (utils/evaluator.py:38-135) on seeded predictions: every field of every record --
+    incl. the fp16 meshes of ``save_verts`` and the flip-back of the two ``do_flip`` samples -- bit for bit, the duplicate
+    removal, and the four metrics."""
+    from ihmr_amd.evaluator import Evaluator
+    g = gold("evaluator.npz")
+    pred, data_list = _evaluator_inputs(g)
+    B = len(data_list)
+    ev = Evaluator(None, data_list, image_root="/data/root")
+    ev.update(list(range(B)), pred, save_verts=True)
+    keys = ["pred_cam_params", "pred_shape_params", "pred_pose_params", "pred_hand_trans", "pred_joints_3d", "gt_joints_3d",
+            "collision_loss_origin_scale", "pred_right_hand_verts", "pred_left_hand_verts", "gt_right_hand_verts", "gt_left_hand_verts"]
+    for i, rec in enumerate(ev.pred_results):
+        for k in keys:
+            assert rec[k].dtype == g[f"rec{i}_{k}"].dtype, (i, k, rec[k].dtype)
+            assert np.array_equal(rec[k], g[f"rec{i}_{k}"]), (i, k)
+        assert rec["pred_right_hand_verts"].dtype == np.float16
+        close(np.array(rec["j3d_error"]), g[f"rec{i}_j3d_error"], 1e-12, what="mpjpe")
+        close(np.array(rec["pa_no_rot_inter_j3d_error"]), g[f"rec{i}_pa_error"], 1e-9, what="pa mpjpe")
+        assert [rec["img_path"], rec["img_path_relative"], rec["hand_type"], rec["annot_type"]] == [str(x) for x in g[f"rec{i}_meta"]]
+        assert float(rec["scale"]) == float(g[f"rec{i}_scale"])
+    # a flipped sample really was flipped (guards against a golden without the branch)
+    assert not np.array_equal(g["rec1_pred_joints_3d"], g["in_pred_joints_3d"][1])
+    ev.remove_redunc()
+    assert len(ev.pred_results) == int(g["n_after_remove_redunc"]) == B - 1
+    close(np.array([ev.mpjpe_3d, ev.inter_mpjpe_3d, ev.collision_ave, ev.collision_max]), g["metrics"], 1e-12, rtol=1e-6, what="metrics")   # the reference averages the depths in float32, this build in float64
+    # save_verts=False: no mesh in the records, the flip-back of the rest unchanged
+    pred, _ = _evaluator_inputs(g)
+    ev2 = Evaluator(None, data_list, image_root="/data/root")
+    ev2.update(list(range(B)), pred, save_verts=False)
+    assert np.array_equal(np.array(["pred_right_hand_verts" in r for r in ev2.pred_results]), g["nov_has_verts"]) and not g["nov_has_verts"].any()
+    assert np.array_equal(ev2.pred_results[1]["pred_joints_3d"], g["nov_rec1_pred_joints_3d"])
+
+
+def read_obj(path):
+    v, f = [], []
+    for line in open(path):
+        t = line.split()
+        if t and t[0] == "v":
+            v.append([float(x) for x in t[1:]])
+        elif t and t[0] == "f":
+            f.append([int(x) for x in t[1:]])
+    return np.array(v), np.array(f, dtype=np.int64)
+
+
+def test_mesh_export_matches_reference_save_pred_obj(tmp_path):
+    """utils/opt_utils.py:45-54 run by the reference itself on its own OptimizeModel result (opt_traj.npz): the vertex block
+    and the combined face index it hands to the OBJ writer, and the file name.  This build's export of the same result, read
+    back from the file: faces identical integers, vertices to the writer's 1e-6 print precision."""
+    import types
+    from ihmr_amd import ry_utils
+    from ihmr_amd.assets import synthetic_mano
+    g, traj = gold("evaluator.npz"), gold("opt_traj.npz")
+    res = {k[4:]: traj[k] for k in traj if k.startswith("out_")}
+    models = dict(right=types.SimpleNamespace(faces=synthetic_mano(True)["faces"]), left=types.SimpleNamespace(faces=synthetic_mano(False)["faces"]))
+    path = ry_utils.save_pred_obj(str(tmp_path), res, models, 7, 2, 30)
+    assert osp.basename(path) == osp.basename(str(g["obj_path"]))
+    v, f = read_obj(path)
+    assert np.array_equal(f - 1, g["obj_faces"]) and g["obj_faces"].dtype == np.int64
+    assert v.shape == g["obj_verts"].shape == (1556, 3)
+    close(v, g["obj_verts"], 5.01e-7, what="OBJ vertices")
+
+
 # ------------------------------------------------------------------------------------------ seam KATs (unpinned)
 def test_mano_oracle_known_answers(mano_arrays):
     from oracle.mano_ref import ManoRef, rodrigues_smplx
