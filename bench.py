@@ -49,6 +49,31 @@ def cpu_model_string():
     return platform.processor() or "unknown"
 
 
+def cpu_topology():
+    """(physical cores, hardware threads) of this host: distinct (physical id, core id) pairs of /proc/cpuinfo and os.cpu_count()."""
+    threads = os.cpu_count() or 1
+    cores = set()
+    try:
+        with open("/proc/cpuinfo") as fh:
+            phys = core = None
+            for line in fh:
+                k, _, v = line.partition(":")
+                k = k.strip()
+                if k == "physical id":
+                    phys = v.strip()
+                elif k == "core id":
+                    core = v.strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+            if phys is not None and core is not None:
+                cores.add((phys, core))
+    except OSError:
+        pass
+    return (len(cores) or threads), threads
+
+
 def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=32, iters_per_stage=8):
     """The oracle (kind "port": same op graph as the reference -- torch LBS + losses + torch.optim.Adam,
     dense 32^3 voxel SDF in C/OpenMP) on the first `n_samples` samples of the same batch for
@@ -83,7 +108,11 @@ def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=32, iters_per_stage=8):
         runs[threads] = dict(seconds=t_total, forward_backward_evaluations=evals, images_per_s=n_samples / (t_total / evals * full_iters),
                              ms_per_refine_iter=1000.0 * t_total / evals)
     best = max(runs, key=lambda k: runs[k]["images_per_s"])
-    return dict(value=runs[best]["images_per_s"], unit="images/s", cores=cores, cpu_model=cpu_model_string(), kind="port",
+    phys, hw = cpu_topology()
+    # `cores` = the threads the timed leg actually used (the driver contract's field): torch at `best` threads; the dense voxel SDF
+    # (C/OpenMP, > 95 % of the time) on every hardware thread of the host
+    return dict(value=runs[best]["images_per_s"], unit="images/s", cores=cores, physical_cores=phys, hardware_threads=hw,
+                threads_used=dict(torch=best, openmp_sdf=cores), cpu_model=cpu_model_string(), kind="port",
                 torch_threads=best, by_torch_threads={str(k): v for k, v in runs.items()},
                 sample=f"{n_samples} samples x {4 * iters_per_stage} refine iterations (+1 forward) measured in {runs[best]['seconds']:.1f}s, "
                        f"extrapolated linearly to {full_iters - 1} iterations",
@@ -114,6 +143,152 @@ def parity_vs_oracle(batch_cpu, oracle_out, rank):
                 selection_agreement=agree, mean_penetration_depth_m=dict(hip=pen_h, oracle=pen_o, abs_diff=abs(pen_h - pen_o)),
                 mpjpe_m=dict(hip=mp(got), oracle=mp(ref), abs_diff=abs(mp(got) - mp(ref))), tolerance_m=1e-4,
                 within_tolerance=bool(err("pred_joints_3d") < 1e-4 and verts < 1e-4 and err("collision_loss_origin_scale") < 1e-4 and agree == 1.0))
+
+
+RIDGE_FLOP_PER_BYTE = FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)     # 19.7: below it a kernel is priced against HBM
+
+# Per-unit models of the three kernels (DESIGN.md section 5.3 spells the arithmetic out).  Bytes: what the algorithm has to move
+# once, not what the implementation moves (that is `traffic`, from the counters).
+HAND_TABLE_BYTES = 1538 * (16 + 4) + 778 * 16                 # a hand's triangle records (circle 16 B + packed normal 4 B) + normalised vertices
+HAND_VERT_BYTES = 778 * 12
+KERNEL_SLOTS = (("sdf_dist_kernel", 1), ("sdf_prep_kernel", 0), ("opt_tail_kernel", 2))      # (name prefix in the profiles, ihmr_kernel_timer slot)
+
+
+def kernel_models(kernel, hands, st):
+    """(algorithmic bytes, executed-or-modelled flops) of ONE launch of `kernel` over `hands` hands; st = per-launch work counters."""
+    samples = hands / 2.0
+    if kernel == "sdf_dist_kernel":
+        # every hand's tables once + per inside voxel its work-list entry, map word, candidate list (384 B) and result;
+        # flops = what the kernel executed: 11 per bounding-sphere test, 30 per plane + circle test, 75 per exact distance
+        return (hands * HAND_TABLE_BYTES + st["inside_voxels"] * (4 + 4 + 384 + 4),
+                11.0 * st["sphere_tests"] + 30.0 * st["plane_tests"] + 75.0 * st["dist_evals"])
+    if kernel == "sdf_prep_kernel":
+        # reads both hands' vertices (own: box + normalisation, other: needed-voxel mask) and the lists' reference pose + bitmap
+        # (9.3 + 4 KB); writes the hand's tables and box; per needed voxel 4 B (phi = 0 or a work-list entry);
+        # flops: ~20 per vertex pair (normalisation, voxel index), ~130 per triangle record, 14 per (triangle, column) ray test
+        # + 20 per hit-mask evaluation (counted together in ray_tests: (u, v) tests + needed voxels of the hit columns)
+        return (hands * (2 * HAND_VERT_BYTES + 9336 + 4096 + HAND_TABLE_BYTES + 16) + st["needed_voxels"] * 4,
+                hands * (778 * 20.0 + 1538 * 130.0) + st["ray_tests"] * 17.0)
+    # opt_tail_kernel, per sample: sampling reads both hands' vertices + one phi value per needed voxel, writes the 1556 depths
+    # twice (per-vertex value, origin scale) and d L / d vertices (2 x 9.3 KB, read back by the LBS backward in the same launch:
+    # counted once); LBS backward reads v_posed of both hands; the translation / orientation form also skins the next vertices
+    # (v_posed in, vertices out).  flops: 60 per sampled vertex (trilinear value + gradient), LBS backward over the four non-zero
+    # weights (778 x 4 x 24 x 2 per hand), skinning 778 x 4 x 24 per hand
+    skin = 0.5            # the translation / orientation stages (half the iterations of opt_default) also skin: vertices out
+    return (samples * (2 * HAND_VERT_BYTES + 2 * 1556 * 4 + 2 * HAND_VERT_BYTES + 2 * HAND_VERT_BYTES + skin * 2 * HAND_VERT_BYTES) + st["needed_voxels"] * 4,
+            samples * (1556 * 60.0 + 2 * 778 * 4 * 24 * 2.0 + skin * 2 * 778 * 4 * 24))
+
+
+def kernel_rooflines(args, B, plan, instance, inputs, hip):
+    import ctypes as C
+    sizes_run = {}
+    for q in plan(args.steps):
+        for g in q:
+            sizes_run[g] = sizes_run.get(g, 0) + 1
+    g_main = max(sizes_run, key=lambda g: g * sizes_run[g])       # the launch size that carried most of the timed region's work
+    per_kernel = {k: dict(by_launch_size=[], tot_ms=0.0, tot_bytes=0.0, tot_flops=0.0, tot_full=0.0) for k, _ in KERNEL_SLOTS}
+    for g in sorted(sizes_run):
+        mdl = instance(0, g)
+        timer = hip.KernelTimer()
+        hip.lib().ihmr_set_kernel_timer(C.byref(timer))
+        graphs = mdl.use_graphs
+        mdl.use_graphs = False   # event records cannot sit inside a captured graph
+        mdl.set_input(inputs[g]); mdl.init_optimize(); mdl.optimize(0, 1)
+        torch.cuda.synchronize()
+        hip.lib().ihmr_flush_kernel_timer()
+        hip.lib().ihmr_set_kernel_timer(None)
+        # work EXECUTED per launch, from the kernels' own counters (DESIGN.md "Measurement"): the same refinement once more,
+        # untimed (the counters are global atomics), one sdf_prep_kernel + one sdf_dist_kernel launch per iteration
+        n_launch = max(int(timer.n[hip.TIMED_SDF_DIST]), 1)
+        stats = None
+        if not args.no_work_counters:
+            mdl.set_input(inputs[g]); mdl.init_optimize()
+            mdl.sdf_counters_start()
+            mdl.optimize(0, 1)
+            cnt = mdl.sdf_counters_stop()
+            stats = dict(sphere_tests=cnt["sphere_tests"] / n_launch, plane_tests=cnt["plane_tests"] / n_launch, dist_evals=cnt["dist_evals"] / n_launch,
+                         voxels_from_lists=cnt["voxels_from_lists"] / n_launch,
+                         voxels_full_search=(cnt["voxels_without_list"] + cnt["voxels_rebuilt"]) / n_launch,
+                         inside_voxels=cnt["inside_voxels"] / n_launch, needed_voxels=cnt["needed_voxels"] / n_launch,
+                         ray_tests=cnt["ray_tests"] / n_launch)
+        mdl.use_graphs = graphs
+        for kernel, slot in KERNEL_SLOTS:
+            ms = timer.launch_ms(slot)
+            if ms is None or ms <= 0:
+                continue
+            ab, fl = kernel_models(kernel, 2.0 * g * B, stats) if stats else (None, None)
+            e = dict(batches_per_launch=g, launch_sequences_in_timed_region=sizes_run[g], avg_launch_ms=ms, launches_timed=int(timer.n[slot]),
+                     algorithmic_bytes_per_launch=ab, flops_per_launch=fl)
+            if kernel == "sdf_dist_kernel":
+                e["work_per_launch"] = stats
+                e["full_search_flops_per_launch"] = (1538 * 11.0 * stats["inside_voxels"] + 75.0 * stats["dist_evals"]) if stats else None
+            pk = per_kernel[kernel]
+            pk["by_launch_size"].append(e)
+            if stats:
+                pk["tot_ms"] += ms * sizes_run[g]; pk["tot_bytes"] += ab * sizes_run[g]; pk["tot_flops"] += fl * sizes_run[g]
+                if kernel == "sdf_dist_kernel":
+                    pk["tot_full"] += e["full_search_flops_per_launch"] * sizes_run[g]
+    prefix, meta = committed_profile(g_main, "opt") if (B == 64 and args.epoch == 49) else (None, None)
+    kernels = []
+    for kernel, _ in KERNEL_SLOTS:
+        pk = per_kernel[kernel]
+        t = pk["tot_ms"] * 1e-3
+        ach_bw = pk["tot_bytes"] / t / 1e9 if t > 0 else None
+        ach_fl = pk["tot_flops"] / t / 1e12 if t > 0 else None
+        ai = pk["tot_flops"] / pk["tot_bytes"] if pk["tot_bytes"] > 0 else None
+        main_ms = next((p["avg_launch_ms"] for p in pk["by_launch_size"] if p["batches_per_launch"] == g_main), None)
+        # counters of the committed profile of THIS code (source hash checked) at the main launch size: HBM bytes, vector instructions
+        traffic = prof_us = n_inst = share = None
+        if prefix is not None:
+            tr, ks, sq = profile_rows(prefix, "pmc_traffic", kernel), profile_rows(prefix, "kernel_stats", kernel), profile_rows(prefix, "pmc_sq", kernel)
+            traffic = float(tr[0]["hbm_bytes_per_launch"]) if tr else None
+            prof_us = float(ks[0]["avg_us"]) if ks else None
+            share = sum(float(r["percent"]) for r in ks) if ks and "percent" in ks[0] else None
+            n_inst = float(sq[0]["SQ_INSTS_VALU_per_launch"]) if sq and sq[0].get("SQ_INSTS_VALU_per_launch") else None
+        issue = None
+        if n_inst and main_ms:
+            # vector-ALU ISSUE slots: SQ_INSTS_VALU x 4 cycles (a wave64 instruction holds its 16-lane SIMD for four cycles) /
+            # (1024 SIMDs x the cycles of this run's launch at the 2.4 GHz peak clock): how busy the vector pipes are with
+            # instructions of ANY kind (a lower bound: the sustained clock is below the peak clock)
+            issue = dict(valu_wave_instructions_per_launch=n_inst, simds=1024, cycles_per_wave_instruction=4, clock_ghz=2.4,
+                         frac=n_inst * 4.0 / (1024.0 * main_ms * 1e-3 * 2.4e9))
+        ctr_bw = traffic / (main_ms * 1e-3) / 1e9 if (traffic and main_ms) else None
+        main_bytes = next((p["algorithmic_bytes_per_launch"] for p in pk["by_launch_size"] if p["batches_per_launch"] == g_main), None)
+        kernels.append(dict(
+            kernel=kernel, bound="hbm" if (ai is None or ai < RIDGE_FLOP_PER_BYTE) else "valu", arithmetic_intensity_flop_per_byte=ai,
+            hbm=dict(achieved=ach_bw, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach_bw / HBM_PEAK_GBS) if ach_bw else None),
+            valu=dict(achieved=ach_fl, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=(ach_fl / FP32_PEAK_TFLOPS) if ach_fl else None),
+            issue_slots=issue, traffic=traffic, traffic_unit="bytes/launch",
+            traffic_over_algorithmic=(traffic / main_bytes) if (traffic and main_bytes) else None,
+            counter_traffic_rate_gbs=ctr_bw, profile_avg_launch_us=prof_us, share_of_gpu_time_pct=share,
+            avg_launch_ms_main_size=main_ms, by_launch_size=pk["by_launch_size"]))
+    dom = kernels[0]                              # sdf_dist_kernel: the largest share of GPU time in profiles/
+    dpk = per_kernel["sdf_dist_kernel"]
+    ach_full = dpk["tot_full"] / (dpk["tot_ms"] * 1e-3) / 1e12 if dpk["tot_ms"] > 0 and dpk["tot_full"] > 0 else None
+    src = ("profiles/" + os.path.basename(prefix)) if prefix else None
+    return dict(
+        # headline = the dominant kernel against the roof its arithmetic intensity selects (AI = flops / algorithmic bytes against the
+        # ridge 157.3 TFLOP/s / 8 TB/s = 19.7 flop/B) -- fixed by the model, NOT "whichever fraction is larger"
+        bound=dom["bound"], kernel="sdf_dist_kernel",
+        achieved=dom[dom["bound"]]["achieved"], peak=dom[dom["bound"]]["peak"], unit=dom[dom["bound"]]["unit"], frac=dom[dom["bound"]]["frac"],
+        traffic=dom["traffic"], traffic_unit="bytes/launch", traffic_batches_per_launch=g_main,
+        traffic_source=(src + "_pmc_traffic.csv") if src and dom["traffic"] else None,
+        ridge_flop_per_byte=RIDGE_FLOP_PER_BYTE, valu=dict(dom["valu"], issue_slots=dom["issue_slots"]), hbm=dom["hbm"],
+        kernels=kernels, profile=src,
+        full_search_equivalent=dict(achieved=ach_full, frac=(ach_full / FP32_PEAK_TFLOPS) if ach_full else None,
+                                    note="sdf_dist_kernel priced with the work of searching all 1538 triangles for every inside voxel "
+                                         "(the kernel without its candidate lists; rounds 1 and early 2 were priced this way)"),
+        history_basis="`frac` of earlier rounds is NOT one series: r1 = executed flops / the fp32 MFMA-VALU peak priced as a FULL search "
+                      "(bound 'mfma', 0.139), r2 = executed flops of the culled search / the vector peak (bound 'valu', 0.054), r3 = "
+                      "algorithmic bytes / HBM peak because that fraction was the larger one (bound 'hbm', 0.178; on r2's basis 0.043).  "
+                      "From r4 on the roof is fixed by arithmetic intensity (all three kernels: HBM) and `valu` / `issue_slots` are always "
+                      "given beside it; compare rounds through kernels[].avg_launch_ms_main_size and `value`.",
+        traffic_note="HBM bytes per launch from the committed rocprofv3 PMC summary of this command at --streams 1, the same launch size and "
+                     "the SAME library source hash (counters cannot be read from inside the process); null when no profile of the loaded "
+                     "library is committed",
+        note="times = HIP events around each kernel's in-loop launches on their stream, single-stream graph-less passes, one per launch "
+             "size of the timed region, aggregated by the number of launch sequences of that size; algorithmic bytes / flops per launch "
+             "from the collision kernels' own work counters x the per-unit models of DESIGN.md section 5.3")
 
 
 def committed_profile(batches_per_launch=None, tag=None):
@@ -339,7 +514,7 @@ def secondary(config, with_cpu=True):
         # work from its own counters in a second pass
         import ctypes as C
         from ihmr_amd import hip
-        timer = hip.KernelTimer(0.0, 0, 0.0, 0.0, 0)
+        timer = hip.KernelTimer()
         core_graphs = m._core.use_graphs
         m._core.use_graphs = False
         hip.lib().ihmr_set_kernel_timer(C.byref(timer))
@@ -347,13 +522,13 @@ def secondary(config, with_cpu=True):
         hip.lib().ihmr_flush_kernel_timer(); hip.lib().ihmr_set_kernel_timer(None)
         m._core.sdf_counters_start(); m.set_input(batch); m._test_eager(); cnt = m._core.sdf_counters_stop()
         m._core.use_graphs = core_graphs
-        nl = max(int(timer.n_sdf_eval), 1)
-        k_ms = (timer.ms_sdf_eval - timer.ms_event_pair) / nl
+        nl = max(int(timer.n[hip.TIMED_SDF_DIST]), 1)
+        k_ms = timer.launch_ms(hip.TIMED_SDF_DIST)
         flops = (11.0 * cnt["sphere_tests"] + 30.0 * cnt["plane_tests"] + 75.0 * cnt["dist_evals"]) / nl
         abytes = 2.0 * B * (1538 * (16 + 4) + 778 * 16) + cnt["inside_voxels"] / nl * 8
         traffic, tsrc, prof_us = pmc_traffic("sdf_dist_kernel", None, "mlp")
         ach, bw = flops / (k_ms * 1e-3) / 1e12, abytes / (k_ms * 1e-3) / 1e9
-        hbm_binds = bw / HBM_PEAK_GBS > ach / FP32_PEAK_TFLOPS
+        hbm_binds = flops / abytes < RIDGE_FLOP_PER_BYTE        # the roof is fixed by arithmetic intensity
         out = dict(metric="images/sec, IHMR-MLP refinement head batch=128 inference", value=B / dt, unit="images/s", n_gpus=1, ms_per_step=dt * 1e3,
                    dtype="f32", data="synthetic", higher_is_better=True,
                    config=dict(workload="BASELINE.json configs[2]: MLPModel.test() (6 stages: 8 MANO + SDF evaluations, 6 MLPs) + export, batch 128; "
@@ -561,113 +736,13 @@ def main():
                    note="inputs start in pinned host memory: the 15 input tensors of every step (~40 KB per 64 samples) are copied "
                         "inside the step, as in the reference's loop body (optimize.py:61-71)")
 
-    # ---- dominant kernel (sdf_dist_kernel): HIP events on the launch stream in separate single-stream, graph-less passes of
-    #      the same workload, one per launch size the timed region actually ran (with several sequences in flight the kernels
-    #      share the GPU and a per-launch time is meaningless); work and algorithmic bytes from the kernels' own counters
+    # ---- the three large kernels of an iteration (sdf_dist_kernel, sdf_prep_kernel, opt_tail_kernel: ~80 % of the GPU time): HIP
+    #      events on the launch stream in separate single-stream, graph-less passes of the same workload, one per launch size the
+    #      timed region actually ran (with several sequences in flight the kernels share the GPU and a per-launch time is
+    #      meaningless); work and algorithmic bytes from the collision kernels' own counters in a second, untimed pass
     roofline = None
     if rank == 0:
-        sizes_run = {}
-        for q in plan(args.steps):
-            for g in q:
-                sizes_run[g] = sizes_run.get(g, 0) + 1
-        per_size, tot_flops, tot_ms, tot_full, tot_bytes = [], 0.0, 0.0, 0.0, 0.0
-        for g in sorted(sizes_run):
-            mdl = instance(0, g)
-            timer = hip.KernelTimer(0.0, 0, 0.0, 0.0, 0)
-            hip.lib().ihmr_set_kernel_timer(C.byref(timer))
-            graphs = mdl.use_graphs
-            mdl.use_graphs = False   # event records cannot sit inside a captured graph
-            mdl.set_input(inputs[g]); mdl.init_optimize(); mdl.optimize(0, 1)
-            torch.cuda.synchronize()
-            hip.lib().ihmr_flush_kernel_timer()
-            hip.lib().ihmr_set_kernel_timer(None)
-            # work EXECUTED per launch, from the kernels' own counters (DESIGN.md "Measurement"): the same refinement once more,
-            # untimed (the counters are global atomics), one sdf_prep_kernel + one sdf_dist_kernel launch per iteration
-            stats, flops, abytes = None, None, None
-            n_launch = max(int(timer.n_sdf_eval), 1)
-            if not args.no_work_counters:
-                mdl.set_input(inputs[g]); mdl.init_optimize()
-                mdl.sdf_counters_start()
-                mdl.optimize(0, 1)
-                cnt = mdl.sdf_counters_stop()
-                stats = dict(sphere_tests=cnt["sphere_tests"] / n_launch, plane_tests=cnt["plane_tests"] / n_launch, dist_evals=cnt["dist_evals"] / n_launch,
-                             voxels_from_lists=cnt["voxels_from_lists"] / n_launch,
-                             voxels_full_search=(cnt["voxels_without_list"] + cnt["voxels_rebuilt"]) / n_launch,
-                             inside_voxels=cnt["inside_voxels"] / n_launch, needed_voxels=cnt["needed_voxels"] / n_launch,
-                             ray_tests=cnt["ray_tests"] / n_launch)
-                # flops of ONE launch: 11 per bounding-sphere test (|p - m|^2: 8, cull test: 3), 30 per plane + circle test and 75
-                # per exact point-triangle distance -- what the kernel executed; a full search of every inside voxel (the kernel
-                # without its candidate lists, round 1's model) would execute 1538 sphere tests per inside voxel
-                flops = 11.0 * stats["sphere_tests"] + 30.0 * stats["plane_tests"] + 75.0 * stats["dist_evals"]
-                # algorithmic bytes of ONE launch: every hand's tables once (sphere record 16 B + packed
-                # normal 4 B per triangle, 1538 triangles; 16 B per vertex, 778 vertices) + per inside voxel its work-list
-                # entry, map word, candidate list (384 B) and the result
-                abytes = 2.0 * g * B * (1538 * (16 + 4) + 778 * 16) + stats["inside_voxels"] * (4 + 4 + 384 + 4)
-            mdl.use_graphs = graphs
-            # launch duration = event-bracketed time of the in-loop launch minus the cost of an (empty) event pair recorded right
-            # before it (no warm repeats -- they measured 77.5 us against 76.5 us in-loop, and the kernel now pulls its
-            # work from a cursor that one launch spends)
-            avg_ms = (timer.ms_sdf_eval - timer.ms_event_pair) / n_launch
-            ach = flops / (avg_ms * 1e-3) / 1e12 if (avg_ms > 0 and flops) else None
-            per_size.append(dict(batches_per_launch=g, launch_sequences_in_timed_region=sizes_run[g], avg_launch_ms=avg_ms,
-                                 launches_timed=int(timer.n_sdf_eval),
-                                 algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=abytes, work_per_launch=stats, achieved=ach,
-                                 full_search_flops_per_launch=(1538 * 11.0 * stats["inside_voxels"] + 75.0 * stats["dist_evals"]) if stats else None,
-                                 frac=(ach / FP32_PEAK_TFLOPS) if ach else None))
-            if avg_ms > 0 and flops:
-                tot_flops += flops * sizes_run[g]
-                tot_ms += avg_ms * sizes_run[g]
-                tot_bytes += abytes * sizes_run[g]
-                tot_full += (1538 * 11.0 * stats["inside_voxels"] + 75.0 * stats["dist_evals"]) * sizes_run[g]
-        # HBM traffic: the committed PMC summary of THIS code (source hash checked) at the launch size that carried most of the
-        # timed region's work
-        g_main = max(sizes_run, key=lambda g: g * sizes_run[g])
-        traffic, traffic_src, prof_us = pmc_traffic("sdf_dist_kernel", g_main) if (B == 64 and args.epoch == 49) else (None, None, None)
-        main_ms = next((p["avg_launch_ms"] for p in per_size if p["batches_per_launch"] == g_main), None)
-        ach = tot_flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None
-        ach_full = tot_full / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 and tot_full > 0 else None
-        ach_bw = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 and tot_bytes > 0 else None
-        ctr_bw = traffic / (main_ms * 1e-3) / 1e9 if (traffic and main_ms) else None
-        frac_valu = (ach / FP32_PEAK_TFLOPS) if ach else None
-        frac_hbm = (ach_bw / HBM_PEAK_GBS) if ach_bw else None
-        # vector-ALU ISSUE slots: the profile's SQ_INSTS_VALU of this kernel at this launch size x 4 cycles (a wave64 instruction holds
-        # its 16-lane SIMD for four cycles) / (1024 SIMDs x the cycles of this run's launch at the 2.4 GHz peak clock) -- how busy the
-        # vector pipes are with instructions of ANY kind, as opposed to `valu.frac` (useful flops against the packed-FMA peak)
-        issue = None
-        if traffic_src and main_ms:
-            sq = profile_rows(os.path.join(ROOT, traffic_src[:-len("_pmc_traffic.csv")]), "pmc_sq", "sdf_dist_kernel")
-            if sq and sq[0].get("SQ_INSTS_VALU_per_launch"):
-                n_inst = float(sq[0]["SQ_INSTS_VALU_per_launch"])
-                issue = dict(valu_wave_instructions_per_launch=n_inst, simds=1024, cycles_per_wave_instruction=4, clock_ghz=2.4,
-                             frac=n_inst * 4.0 / (1024.0 * main_ms * 1e-3 * 2.4e9),
-                             source="profiles/" + os.path.basename(traffic_src)[:-len("_pmc_traffic.csv")] + "_pmc_sq.csv",
-                             note="share of the vector pipes' issue slots the launch uses (a lower bound: the sustained clock is below "
-                                  "the peak clock): the kernel is bound by instruction issue + exposed latency, not by flops or bytes")
-        # both roofs, the binding one (the larger fraction of its peak) is the headline
-        hbm_binds = frac_hbm is not None and (frac_valu is None or frac_hbm > frac_valu)
-        roofline = dict(bound="hbm" if hbm_binds else "valu",
-                        achieved=ach_bw if hbm_binds else ach, peak=HBM_PEAK_GBS if hbm_binds else FP32_PEAK_TFLOPS,
-                        unit="GB/s" if hbm_binds else "TFLOP/s", frac=frac_hbm if hbm_binds else frac_valu,
-                        valu=dict(achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=frac_valu, issue_slots=issue),
-                        hbm=dict(achieved=ach_bw, peak=HBM_PEAK_GBS, unit="GB/s", frac=frac_hbm,
-                                 counter_traffic_rate=ctr_bw, counter_traffic_frac=(ctr_bw / HBM_PEAK_GBS) if ctr_bw else None,
-                                 note="achieved = ALGORITHMIC bytes (every hand's triangle table once + per inside voxel its list and "
-                                      "result) / launch time; counter_traffic_rate = the PMC bytes of the profile / this run's launch time"),
-                        traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
-                        traffic_batches_per_launch=g_main, profile_avg_launch_us=prof_us,
-                        traffic_note="HBM bytes per launch from the committed rocprofv3 PMC summary of this command at --streams 1, the same "
-                                     "launch size and the SAME library source hash (counters cannot be read from inside the process); null "
-                                     "when no profile of the loaded library is committed",
-                        kernel="sdf_dist_kernel", by_launch_size=per_size,
-                        full_search_equivalent=dict(achieved=ach_full, frac=(ach_full / FP32_PEAK_TFLOPS) if ach_full else None,
-                                                    note="the same launches priced with the work of searching all 1538 triangles for every "
-                                                         "inside voxel (the kernel without its candidate lists; rounds 1 and early 2 were "
-                                                         "priced this way): comparable across rounds, not what the kernel executes"),
-                        note="largest share of GPU time in the rocprofv3 kernel summary (profiles/).  Pure fp32 VALU kernel (compares, "
-                             "selects, FMAs; no GEMM shape): priced against the 157.3 TFLOP/s fp32 vector peak AND against HBM.  "
-                             "valu.achieved = flops the kernel executed (its own counters: 11 per bounding-sphere test, 75 per exact "
-                             "point-triangle distance) / HIP-event time of the in-loop launch, aggregated over the launch sizes the "
-                             "timed region ran (by_launch_size), each timed in a single-stream pass")
+        roofline = kernel_rooflines(args, B, plan, instance, inputs, hip)
 
     # ---- single-batch latency: ONE batch of --batch samples, one stream, nothing else in flight.
     #      ms/refine-iter = stage-loop wall time / iterations (excludes set_input and the export); images/s = batch /

@@ -39,6 +39,7 @@ struct ihmr_mano {
     float* weights;       // [778][16]
     float4* w4_w;         // [778] the (up to) four non-zero skinning weights of a vertex in joint order, zero padded ...
     uint32_t* w4_j;       // [778] ... and their joints, one byte each (padding: joint 0 with weight 0)
+    int tail_fits;        // opt_tail_kernel's static + dynamic LDS fits this device (set by ihmr_mano_create; 0: three separate launches)
     int sparse4;          // every vertex has at most four non-zero weights (MANO's own weights do): the skinning loops run over w4_*
     float* pose_mean;     // [48]
     int32_t* parents;     // [16]

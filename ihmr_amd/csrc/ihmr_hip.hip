@@ -19,8 +19,28 @@
 #include "train_conv.h"
 
 static ihmr_kernel_timer* g_timer = nullptr;
-struct TimedPair { hipEvent_t e0, e1, a, b, c; int reps; };   // (e0,e1): an empty pair right before, the cost of the events themselves; (a,b): the in-loop launch; (b,c): the repeats
+// bench.py's per-kernel timer: (a,b) brackets one in-loop launch of kernel slot `k` (k < 0: an EMPTY pair, the cost of two event records)
+struct TimedPair { hipEvent_t a, b; int k; };
 static std::vector<TimedPair> g_pending;
+static int timed_mark(hipEvent_t* ev, hipStream_t st) {
+    HIP_TRY(hipEventCreate(ev));
+    HIP_TRY(hipEventRecord(*ev, st));
+    return 0;
+}
+// events around a group of back-to-back launches: timed_begin (empty pair + first mark), timed_next(k) after each launch
+static int timed_begin(hipEvent_t* cur, hipStream_t st) {
+    hipEvent_t e0, e1;
+    if (int rc = timed_mark(&e0, st)) return rc;
+    if (int rc = timed_mark(&e1, st)) return rc;
+    g_pending.push_back(TimedPair{e0, e1, -1});
+    return timed_mark(cur, st);
+}
+static int timed_next(hipEvent_t* cur, int k, hipStream_t st) {
+    hipEvent_t e;
+    if (int rc = timed_mark(&e, st)) return rc;
+    g_pending.push_back(TimedPair{*cur, e, k});
+    return timed_mark(cur, st);      // (a fresh start mark: every event belongs to exactly one pair)
+}
 
 // ------------------------------------------------------------------------------------------ model
 template <typename T>
@@ -139,13 +159,26 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
     m->nseg = (int)seg_q.size() - 1;
     if (m->nseg > LBS_SEG_CAP) { ihmr_mano_destroy(m); return -1; }
     // lbs_bwd1 keeps the per-segment partial sums in dynamic LDS (48 B per segment on top of ~36 KB static): dense
-    // weight matrices (up to ~960 segments) go past the default 64 KB per workgroup, so raise the cap to what is needed
+    // weight matrices (up to ~960 segments) go past the default 64 KB per workgroup, so raise the cap to what is needed --
+    // for every instantiation that is launched with dynamic LDS, and checked: a kernel whose static + dynamic LDS does not fit
+    // the device is never launched (m->tail_fits = 0: ihmr_opt_run_stage falls back to the three separate launches)
     {
         const int dyn = m->nseg * 12 * (int)sizeof(float);
-        (void)hipFuncSetAttribute((const void*)lbs_bwd1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
-        (void)hipFuncSetAttribute((const void*)lbs_bwd1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
-        (void)hipFuncSetAttribute((const void*)opt_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * dyn);
-        (void)hipFuncSetAttribute((const void*)opt_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * dyn);
+        hipError_t e1 = hipFuncSetAttribute((const void*)lbs_bwd1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+        hipError_t e2 = hipFuncSetAttribute((const void*)lbs_bwd1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+        if (e1 != hipSuccess || e2 != hipSuccess) { ihmr_mano_destroy(m); return (int)(e1 != hipSuccess ? e1 : e2); }
+        int dev = 0, lds_max = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+        const void* tails[3] = {(const void*)opt_tail_kernel<true, true>, (const void*)opt_tail_kernel<true>, (const void*)opt_tail_kernel<false>};
+        m->tail_fits = 1;
+        for (const void* k : tails) {
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, k) != hipSuccess || (long)fa.sharedSizeBytes + 2 * dyn > (long)lds_max ||
+                hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * dyn) != hipSuccess)
+                m->tail_fits = 0;
+        }
+        (void)hipGetLastError();
     }
     if (rc) return rc;
     *out = m;
@@ -211,6 +244,13 @@ static void lbs_forward_launch(const ihmr_mano* m, bool two_hand, const float* o
     }
 }
 
+static int g_bwd2_streaming = 0;     // checker switch: ihmr_debug_force_lbs_bwd2_streaming
+extern "C" int ihmr_debug_force_lbs_bwd2_streaming(int force) {
+    const int prev = g_bwd2_streaming;
+    g_bwd2_streaming = force ? 1 : 0;
+    return prev;
+}
+
 static void lbs_backward_launch(const ihmr_mano* m, bool two_hand, int N, int B, const float* d_verts, const float* d_joints,
                                 float* d_orient, float* d_pose, float* d_betas, float* d_trans, int need_mask, const LbsWork& wk,
                                 hipStream_t st, bool bwd1_done = false) {
@@ -223,8 +263,9 @@ static void lbs_backward_launch(const ihmr_mano* m, bool two_hand, int N, int B,
         hipLaunchKernelGGL(lbs_bwd1_kernel<false>, dim3(N), dim3(LBS_THREADS), part_lds, st, *m, wk, B, d_verts, d_joints, d_orient,
                            d_betas, d_trans, need_mask);
     if (need_mask & 2) {
-        // LDS-tiled form from 64 hands on (one batch of 64 samples = 128 hands: 2 x 25 workgroups are too few; the streaming form stays there)
-        if (N >= LBS_B2_MIN_HANDS) hipLaunchKernelGGL(lbs_bwd2_lds_kernel, dim3((N + 63) / 64, LBS_KG), dim3(320), 0, st, *m, wk, N);
+        // LDS-tiled form from LBS_B2_MIN_HANDS = 256 hands on (one batch of 64 samples = 128 hands: 2 x 25 workgroups are too few; the
+        // streaming form stays there); the same bits either way
+        if (N >= LBS_B2_MIN_HANDS && !g_bwd2_streaming) hipLaunchKernelGGL(lbs_bwd2_lds_kernel, dim3((N + 63) / 64, LBS_KG), dim3(320), 0, st, *m, wk, N);
         else hipLaunchKernelGGL(lbs_bwd2_kernel, dim3(5, (N + 31) / 32, LBS_KG), dim3(64), 0, st, *m, wk, N);
         if (two_hand) hipLaunchKernelGGL(lbs_bwd3_kernel<true>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
         else hipLaunchKernelGGL(lbs_bwd3_kernel<false>, dim3(N), dim3(64), 0, st, wk, N, B, d_pose);
@@ -259,6 +300,9 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
     // small launches: the 1024-thread form (half the chain per thread), see sdf_collision.h
     const bool small = 2 * B <= SDF_PREP_SMALL_MAX_HANDS;
     ws.fpk[0] = fpk_r; ws.fpk[1] = fpk_l; ws.B = B;
+    const bool timed = g_timer != nullptr;
+    hipEvent_t tcur;
+    if (timed) { if (int rc = timed_begin(&tcur, st)) return rc; }
     if (dense)
         hipLaunchKernelGGL((sdf_prep_kernel<true, SDF_PREP_THREADS_LARGE>), dim3(2 * B), dim3(SDF_PREP_THREADS_LARGE), 0, st, vl, B, faces_r_soa,
                            faces_l_soa, ws, g_collect_stats);
@@ -268,35 +312,21 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
     else
         hipLaunchKernelGGL((sdf_prep_kernel<false, SDF_PREP_THREADS_LARGE>), dim3(2 * B), dim3(SDF_PREP_THREADS_LARGE), 0, st, vl, B, faces_r_soa,
                            faces_l_soa, ws, g_collect_stats);
-    TimedPair tp;
-    const bool timed = g_timer != nullptr;
-    if (timed) {
-        HIP_TRY(hipEventCreate(&tp.e0));
-        HIP_TRY(hipEventCreate(&tp.e1));
-        HIP_TRY(hipEventCreate(&tp.a));
-        HIP_TRY(hipEventCreate(&tp.b));
-        HIP_TRY(hipEventCreate(&tp.c));
-        HIP_TRY(hipEventRecord(tp.e0, st));
-        HIP_TRY(hipEventRecord(tp.e1, st));
-        HIP_TRY(hipEventRecord(tp.a, st));
-    }
     // persistent grid: as many workgroups as the GPU holds at once; they pull work units from a queue (sdf_collision.h)
-    static int dist_blocks = 0;
+    static int dist_blocks_dev[64] = {0};         // per device id (a process may drive GPUs with different CU counts)
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    int& dist_blocks = dist_blocks_dev[dev & 63];
     if (dist_blocks == 0) {
-        int dev = 0, cus = 0;
-        HIP_TRY(hipGetDevice(&dev));
+        int cus = 0;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         dist_blocks = SDF_DIST_WG_PER_CU * (cus > 0 ? cus : 256);
     }
+    if (timed) { if (int rc = timed_next(&tcur, IHMR_TIMED_SDF_PREP, st)) return rc; }
     if (g_collect_stats) hipLaunchKernelGGL(sdf_dist_kernel<true>, dim3(dist_blocks), dim3(SDF_THREADS), 0, st, ws);
     else hipLaunchKernelGGL(sdf_dist_kernel<false>, dim3(dist_blocks), dim3(SDF_THREADS), 0, st, ws);
-    if (timed) {
-        // timed pass: (a,b) brackets the launch the refinement really runs (a second launch would find the work cursor spent)
-        HIP_TRY(hipEventRecord(tp.b, st));
-        HIP_TRY(hipEventRecord(tp.c, st));
-        tp.reps = 0;
-        g_pending.push_back(tp);
-    }
+    // (the launch the refinement really runs is the one that is timed: a second launch would find the work cursor spent)
+    if (timed) { if (int rc = timed_next(&tcur, IHMR_TIMED_SDF_DIST, st)) return rc; (void)hipEventDestroy(tcur); }
     if (loss)
         hipLaunchKernelGGL(sdf_sample_kernel, dim3(B), dim3(SDF_SAMPLE_THREADS), 0, st, vl, ws, robustifier, loss, per_vert, origin,
                            dval, B);
@@ -429,7 +459,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     // optimizer step + next skeletons -- is ONE launch per sample (opt_tail_kernel): 4 launches per iteration instead of 6 (finger-pose
     // stage, whose backward continues with a batch-wide GEMM: 7 instead of 8); in a stage that keeps v_posed the same launch also skins
     // the next iteration's vertices: 3 launches (skin_mode < 0 below)
-    const bool fused_tail = need_mask != 0 && !io->no_fused_tail;
+    const bool fused_tail = need_mask != 0 && !io->no_fused_tail && m->tail_fits;
     const bool pose_stage = (need_mask & 2) != 0;
     const size_t tail_lds = (size_t)2 * m->nseg * 12 * sizeof(float);
     for (int it = 0; it < sg->n_iters; ++it) {
@@ -448,6 +478,9 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
             if (rc) return rc;
             SdfWorkspace ws = opt_sdf_ws(io, wk, B, it == 0 ? 2 : 1);
             VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
+            hipEvent_t tcur;
+            const bool timed = g_timer != nullptr;
+            if (timed) { if (int rc2 = timed_begin(&tcur, st)) return rc2; }
             if (vposed_fixed && it + 1 < sg->n_iters)
                 hipLaunchKernelGGL((opt_tail_kernel<true, true>), dim3(B), dim3(SDF_SAMPLE_THREADS), tail_lds, st, *m, *io, wk, B, *w, vl, ws, need_cam, need_mask,
                                    next, ws.inside_count);
@@ -457,6 +490,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
             else
                 hipLaunchKernelGGL(opt_tail_kernel<false>, dim3(B), dim3(SDF_SAMPLE_THREADS), tail_lds, st, *m, *io, wk, B, *w, vl, ws, need_cam, need_mask,
                                    next, ws.inside_count);
+            if (timed) { if (int rc2 = timed_next(&tcur, IHMR_TIMED_OPT_TAIL, st)) return rc2; (void)hipEventDestroy(tcur); }
             if (pose_stage)
                 lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
                                     wk.lbs, st, /*bwd1_done=*/true);
@@ -865,20 +899,15 @@ extern "C" int ihmr_set_kernel_timer(ihmr_kernel_timer* t) {
 
 extern "C" int ihmr_flush_kernel_timer(void) {
     for (auto& p : g_pending) {
-        float ms = 0.f, ms_rep = 0.f, ms_empty = 0.f;
-        HIP_TRY(hipEventSynchronize(p.c));
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(p.b));
         HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
-        HIP_TRY(hipEventElapsedTime(&ms_rep, p.b, p.c));
-        HIP_TRY(hipEventElapsedTime(&ms_empty, p.e0, p.e1));
         if (g_timer) {
-            g_timer->ms_sdf_eval += ms; g_timer->n_sdf_eval += 1; g_timer->ms_event_pair += ms_empty;
-            g_timer->ms_sdf_repeat += ms_rep; g_timer->n_sdf_repeat += p.reps;
+            if (p.k < 0) { g_timer->ms_event_pair += ms; g_timer->n_event_pair += 1; }
+            else if (p.k < IHMR_TIMED_KERNELS) { g_timer->ms[p.k] += ms; g_timer->n[p.k] += 1; }
         }
-        (void)hipEventDestroy(p.e0);
-        (void)hipEventDestroy(p.e1);
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
-        (void)hipEventDestroy(p.c);
     }
     g_pending.clear();
     return 0;

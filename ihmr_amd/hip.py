@@ -37,7 +37,8 @@ EXPORTED_SYMBOLS = [
     "ihmr_opt_forward_graph_create", "ihmr_graph_launch", "ihmr_graph_destroy", "ihmr_opt_set_params", "ihmr_eval_metrics", "ihmr_eval_mpvpe", "ihmr_conv_igemm", "ihmr_maxpool3x3s2",
     "ihmr_avgpool_relu", "ihmr_preprocess_images", "ihmr_mlp_train_grad", "ihmr_transpose", "ihmr_relu_backward", "ihmr_colsum",
     "ihmr_adam_step", "ihmr_bn_workspace_bytes", "ihmr_bn_train_forward", "ihmr_bn_train_backward", "ihmr_conv_wgrad",
-    "ihmr_dilate2", "ihmr_interleave2", "ihmr_pack_dgrad_weight", "ihmr_maxpool3x3s2_backward", "ihmr_avgpool_relu_backward", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer", "ihmr_version",
+    "ihmr_dilate2", "ihmr_interleave2", "ihmr_pack_dgrad_weight", "ihmr_maxpool3x3s2_backward", "ihmr_avgpool_relu_backward", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer",
+    "ihmr_debug_force_lbs_bwd2_streaming", "ihmr_version",
 ]
 
 
@@ -74,9 +75,18 @@ class TrainWeights(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("joints_2d", "mano_pose", "mano_shape", "hand_trans", "shape_reg", "shape_residual")]
 
 
+TIMED_SDF_PREP, TIMED_SDF_DIST, TIMED_OPT_TAIL, TIMED_KERNELS = 0, 1, 2, 4
+
+
 class KernelTimer(C.Structure):
-    _fields_ = [("ms_sdf_eval", C.c_double), ("n_sdf_eval", C.c_long), ("ms_sdf_repeat", C.c_double), ("ms_event_pair", C.c_double),
-                ("n_sdf_repeat", C.c_long)]
+    """``ihmr_kernel_timer`` (include/ihmr_hip.h): summed HIP-event time and launch count per timed kernel + the empty event pairs."""
+    _fields_ = [("ms", C.c_double * TIMED_KERNELS), ("n", C.c_long * TIMED_KERNELS), ("ms_event_pair", C.c_double), ("n_event_pair", C.c_long)]
+
+    def launch_ms(self, k):
+        """Mean duration of kernel slot k's launches (event time minus the cost of an empty event pair)."""
+        if self.n[k] <= 0:
+            return None
+        return self.ms[k] / self.n[k] - (self.ms_event_pair / self.n_event_pair if self.n_event_pair > 0 else 0.0)
 
 
 def sources():

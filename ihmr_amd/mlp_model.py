@@ -82,11 +82,13 @@ class MLPModel(MLPTrainMixin):
         self.img_feat_all = torch.zeros(num_data, 1024, device=dev)
         self.prev_final = torch.zeros(num_data, 122, device=dev)
         self.prev_loss = torch.zeros(num_data, 3, device=dev)          # columns = LOSS_SLOT
+        self._test_graph = None     # a captured test() holds the OLD tables' addresses, column slices and thresholds
 
     # mlp_model.py:370-405 (inference part)
     def add_new_network(self, stage_id):
         dim = sum(PARAM_DIMS[p] for p in self.strategy[stage_id]["update_params"])
         self.sub_network_list.append(InterHandSubNetwork(self.opt, self.opt.total_params_dim + 1024, dim).to(self.device))
+        self._test_graph = None
         if self.isTrain:                                   # mlp_model.py:402-405: a fresh Adam(lr) for the new sub-network
             self._make_trainer(stage_id)
 
@@ -96,6 +98,7 @@ class MLPModel(MLPTrainMixin):
             print(f"{path} does not exist !!!")
             return False
         self.sub_network_list[stage_id].load_state_dict(torch.load(path, map_location="cpu"))
+        self._test_graph = None
         return True
 
     def eval(self):
@@ -149,7 +152,7 @@ class MLPModel(MLPTrainMixin):
     def test(self):
         if not self.use_test_graph or self.trainers:
             return self._test_eager()
-        sig = (len(self.strategy), len(self.sub_network_list), tuple(id(n) for n in self.sub_network_list))
+        sig = self._test_signature()
         if self._test_graph is None or self._graph_sig != sig:
             self._test_eager()                               # untimed first pass: lazy allocations, the core's own graphs
             torch.cuda.synchronize()
@@ -162,6 +165,13 @@ class MLPModel(MLPTrainMixin):
                 self._core.use_graphs = core_graphs
             self._test_graph, self._graph_sig = graph, sig
         self._test_graph.replay()
+
+    def _test_signature(self):
+        """Everything a captured test() has baked in: the sub-networks, the addresses of the four "prev" tables, the strategy's
+        contents (update columns, filter percentages, select losses) and the loss weights."""
+        strat = tuple((tuple(st["update_params"]), tuple((n, str(p)) for n, p in st["filter_loss"]), st["select_loss"]) for st in self.strategy)
+        tables = tuple(t.data_ptr() for t in (self.data_idxs_all, self.img_feat_all, self.prev_final, self.prev_loss))
+        return (strat, tables, tuple(sorted(self._w.items())), tuple(id(n) for n in self.sub_network_list))
 
     def _test_eager(self):
         # mlp_model.py:204-216: [cam | pose 96 | shape 20 | trans] in the reference's order

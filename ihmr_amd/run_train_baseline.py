@@ -33,10 +33,11 @@ def main(argv=None):
     ap.add_argument("--save", action="store_true")
     args = ap.parse_args(argv)
     rank, world = D.init_dist()
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()   # (a one-rank group under torch.distributed.run too)
     if world == 1:
         torch.cuda.set_device(0)
     B = args.batchSize
-    opt = types.SimpleNamespace(isTrain=True, dist=world > 1, process_rank=rank if world > 1 else -1, batchSize=B, inputSize=224, input_nc=3,
+    opt = types.SimpleNamespace(isTrain=True, dist=grouped, process_rank=rank if grouped else -1, batchSize=B, inputSize=224, input_nc=3,
                                 num_joints=42, total_params_dim=122, cam_params_dim=3, pose_params_dim=96, shape_params_dim=20,
                                 trans_params_dim=3, model_root="", mean_param_file="mean_mano_params.pkl", checkpoints_dir="./checkpoints",
                                 lr=args.lr, lr_decay_type=args.lr_decay_type, total_epoch=args.total_epoch,
@@ -68,7 +69,7 @@ def main(argv=None):
                         loss_first=first, loss_last=last))
         if rank == 0:
             print(json.dumps(log[-1]))
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():     # (also a one-rank group under torch.distributed.run)
         torch.distributed.destroy_process_group()
     return log
 

@@ -35,11 +35,12 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     rank, world = D.init_dist()
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()   # (a one-rank group under torch.distributed.run too)
     if world == 1:
         torch.cuda.set_device(0)
     B = args.batchSize
     torch.manual_seed(args.seed)                              # same initial sub-network weights on every rank and in every run (they are broadcast anyway)
-    opt = types.SimpleNamespace(isTrain=True, dist=world > 1, process_rank=rank if world > 1 else -1, batchSize=B, inputSize=224,
+    opt = types.SimpleNamespace(isTrain=True, dist=grouped, process_rank=rank if grouped else -1, batchSize=B, inputSize=224,
                                 input_nc=3, num_joints=42, total_params_dim=122, cam_params_dim=3, pose_params_dim=96,
                                 shape_params_dim=20, trans_params_dim=3, model_root="", checkpoints_dir="./checkpoints",
                                 strategy="mlp_default", total_epoch=1)
@@ -95,7 +96,7 @@ def main(argv=None):
                         samples_per_s=world * B * steps / dt, loss_first=first, loss_last=last, kept=kept, of=n_batches * B))
         if rank == 0:
             print(json.dumps(log[-1]))
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():     # (also a one-rank group under torch.distributed.run)
         torch.distributed.destroy_process_group()
     return log
 

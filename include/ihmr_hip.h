@@ -338,15 +338,25 @@ int ihmr_preprocess_images(const uint8_t* pixels, const int64_t* offsets, const 
                            int B, int final_size, float* img_out, uint8_t* img_u8, const float* joints_in,
                            float* joints_out, void* stream);
 
-/* per-kernel timing hook for bench.py: when non-NULL, the library records hipEvents around the
- * dominant kernel (sdf_dist_kernel) on `stream` and accumulates here; host pointer, read after ihmr_flush_kernel_timer().
- * While a timer is set, every call brackets its launch of the kernel with a pair of events (ms_sdf_eval, n_sdf_eval: the
- * launch the refinement really runs).  ms_event_pair: an EMPTY event pair recorded right before each timed call, i.e. what two
- * event records cost by themselves; (ms_sdf_eval - ms_event_pair) / n_sdf_eval is the launch duration.  (ms_sdf_repeat /
- * n_sdf_repeat: unused since the kernel pulls its work from a cursor that one launch spends; kept for the struct layout.) */
-typedef struct ihmr_kernel_timer { double ms_sdf_eval; long n_sdf_eval; double ms_sdf_repeat; double ms_event_pair; long n_sdf_repeat; } ihmr_kernel_timer;
+/* per-kernel timing hook for bench.py: when non-NULL, the library records hipEvents on the launch stream around the three
+ * large kernels of a refinement iteration and accumulates here (host pointer, read after ihmr_flush_kernel_timer()):
+ * slot IHMR_TIMED_SDF_PREP = sdf_prep_kernel, IHMR_TIMED_SDF_DIST = sdf_dist_kernel (every collision evaluation), IHMR_TIMED_OPT_TAIL =
+ * the per-sample tail launch of a fused-loop iteration (opt_tail_kernel, any instantiation).  ms[k] / n[k]: summed event-to-event
+ * time and number of timed launches; ms_event_pair / n_event_pair: EMPTY event pairs recorded right before each timed group, i.e.
+ * what two event records cost by themselves -- (ms[k] / n[k] - ms_event_pair / n_event_pair) is the launch duration.  Event
+ * records cannot sit inside a stream capture: the caller runs a graph-less pass. */
+#define IHMR_TIMED_SDF_PREP 0
+#define IHMR_TIMED_SDF_DIST 1
+#define IHMR_TIMED_OPT_TAIL 2
+#define IHMR_TIMED_KERNELS 4
+typedef struct ihmr_kernel_timer { double ms[IHMR_TIMED_KERNELS]; long n[IHMR_TIMED_KERNELS]; double ms_event_pair; long n_event_pair; } ihmr_kernel_timer;
 int ihmr_set_kernel_timer(ihmr_kernel_timer* t);
 int ihmr_flush_kernel_timer(void);
+
+/* checker switch (tests only): force = 1 makes the finger-pose backward use the streaming form of its pose-gradient GEMM
+ * (lbs_bwd2_kernel) at every launch size; 0 restores the default (the LDS-tiled form lbs_bwd2_lds_kernel from 256 hands on).  The two
+ * forms produce the same bits (tests/test_gpu_parity.py::test_lbs_bwd2_forms_are_bit_identical).  Returns the previous value. */
+int ihmr_debug_force_lbs_bwd2_streaming(int force);
 
 const char* ihmr_version(void);
 

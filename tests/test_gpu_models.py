@@ -62,6 +62,57 @@ def test_mlp_model_matches_reference_golden_and_oracle(mano_arrays):
     _report("mlp collision_loss vs reference", res["collision_loss"], g["out_collision_loss"], atol=1e-4, rtol=1e-4)
 
 
+def test_mlp_test_graph_is_recaptured_when_its_baked_in_state_changes(mano_arrays):
+    """test() is replayed from one captured graph; what the capture bakes in (the "prev" tables' addresses, the strategy's update
+    columns / filter percentages / select losses) may change between calls: a second set_update_info() -- new tables, another
+    dataset size, a strategy of the same LENGTH with other contents -- must not replay the stale graph.  Every call is compared
+    with an eager instance (use_test_graph=False) driven the same way, bit for bit."""
+    import copy
+    from helpers import seeded_state_dict
+    from ihmr_amd.mlp_model import MLPModel
+    from ihmr_amd.strategies import make_mlp_strategy
+    g = dict(np.load(os.path.join(GOLD, "mlp_test.npz")))
+    batch = {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("in_")}
+    B = batch["init_cam"].shape[0]
+    s1 = make_mlp_strategy()
+    s2 = copy.deepcopy(s1)
+    for st in s2:                                   # same length, same update sizes; other thresholds and select losses
+        st["filter_loss"] = [(n, "+50" if n == "collision_loss" else "-3") for n, _ in st["filter_loss"]]
+        st["select_loss"] = "collision_loss" if st["select_loss"] != "collision_loss" else "joints_3d_loss_p"
+    models = [MLPModel(_opt(B)), MLPModel(_opt(B, use_test_graph=False))]
+    for m in models:
+        m.set_update_info(s1, 10)
+        for sid in range(len(s1)):
+            m.add_new_network(sid)
+            m.sub_network_list[sid].load_state_dict(seeded_state_dict(m.sub_network_list[sid], 900 + sid, last_scale=0.02))
+        m.eval()
+
+    def run_both(tag):
+        outs = []
+        for m in models:
+            m.set_input(batch); m.test(); torch.cuda.synchronize()
+            outs.append((m.get_pred_result(), torch.stack(m.kept_history).cpu().numpy(), m.prev_final.cpu().numpy(), m.prev_loss.cpu().numpy()))
+        (a, ka, pa, la), (b, kb, pb, lb) = outs
+        assert np.array_equal(ka, kb), tag
+        assert np.array_equal(pa, pb) and np.array_equal(la, lb), tag
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (tag, k)
+        return ka
+
+    k1 = run_both("first capture")
+    run_both("replay")
+    assert models[0]._test_graph is not None and models[1]._test_graph is None
+    old = models[0].prev_final.data_ptr()
+    keep_alive = [models[0].prev_final, models[0].prev_loss, models[0].img_feat_all, models[0].data_idxs_all]   # force NEW addresses
+    for m in models:
+        m.set_update_info(s2, 23)                   # other dataset size, other strategy contents
+    assert models[0]._test_graph is None and models[0].prev_final.data_ptr() != old and models[0].prev_final.shape[0] == 23
+    k2 = run_both("after the second set_update_info")
+    run_both("replay of the new capture")
+    assert not np.array_equal(k1, k2), "the second strategy must change some keep / reject decisions for this test to mean anything"
+    del keep_alive
+
+
 def test_mlp_model_batch128_matches_oracle(mano_arrays):
     """BASELINE.json's IHMR-MLP configuration (batch 128 = 256 hands through the fused forward / collision launches, the
     Linear layers at M = 128): all six stages of MLPModel.test() against the oracle's MLPRef.test() -- per-stage

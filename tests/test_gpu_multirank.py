@@ -40,6 +40,34 @@ def test_run_optimize_two_ranks_equals_one_process():
         assert abs(two[k] - one[k]) <= 1e-12 * max(1.0, abs(one[k])), (k, two[k], one[k])
 
 
+def test_bench_with_eight_ranks_runs_config_5_code_path():
+    """BASELINE.json configs[4] (bash/optimize.sh:11,22-23: 512 samples over the 8 processes of one node) without an 8-GPU node:
+    EIGHT ranks launched as the driver launches them, sharing the one GPU over gloo -- per-rank seeds, the barrier + MAX
+    reduction of the step time over 8 ranks, rank-0-only output with the whole job's batch."""
+    lines = _run(["bench.py", "--gpus", "8", "--steps", "8", "--warmup", "3"], nproc=8, timeout=1500)
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 512 and d["steps"] == 8 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"].startswith("dp8") and d["value"] > 0 and d["cpu_baseline"] is None
+    assert abs(d["value"] - 512 * 8 / (d["ms_per_step"] * 8 / 1000.0)) < 1e-6 * d["value"]     # whole-job images / max-over-ranks time
+
+
+def test_run_optimize_eight_ranks_with_padding_equals_one_process():
+    """500 samples at batch 64 on 8 ranks: the list is padded to 512 with 12 copies of sample 0 (opt_dataset.py:38-51), every rank
+    refines one batch of 64, the padding is masked out of the metric sums (evaluator.py:137-146) and ONE float64 all-reduce
+    combines them -- equal to the single-process run over the same 500 samples to 1e-12."""
+    from ihmr_amd import dist as D
+    from ihmr_amd import run_optimize
+    pads = [int(D.shard_indices(500, 64, r, 8)[1].sum()) for r in range(8)]
+    assert pads == [0] * 7 + [12] and all(len(D.shard_indices(500, 64, r, 8)[0]) == 64 for r in range(8))
+    args = ["--num_samples", "500", "--batchSize", "64", "--opt_epoch", "9"]
+    eight = _run(["-m", "ihmr_amd.run_optimize"] + args, nproc=8, timeout=1500)[-1]
+    one = run_optimize.main(args)
+    assert eight["world"] == 8 and eight["num_samples"] == 500
+    for k in ("mpjpe_3d", "inter_mpjpe_3d", "collision_ave", "collision_max"):
+        assert abs(eight[k] - one[k]) <= 1e-12 * max(1.0, abs(one[k])), (k, eight[k], one[k])
+
+
 def test_training_loops_with_two_ranks():
     log = _run(["-m", "ihmr_amd.run_train_mlp", "--num_samples", "64", "--batchSize", "32", "--epochs", "4", "--stages", "1"])
     assert log[-1]["steps"] == 8 and log[-1]["loss_last"] < log[-1]["loss_first"]

@@ -990,6 +990,35 @@ def test_fused_tail_launch_does_not_change_a_bit(mano_arrays, B, optimizer):
         assert np.array_equal(a[k], b[k]), f"{k}: the fused tail launch changed the result"
 
 
+def test_lbs_bwd2_forms_are_bit_identical(mano_arrays):
+    """The pose-gradient GEMM of the finger-pose stage has two forms: `lbs_bwd2_kernel` (operands streamed; up to 255 hands per launch)
+    and `lbs_bwd2_lds_kernel` (operands staged through LDS; from 256 hands on, i.e. every launch of the headline bench).  The same
+    k -> MFMA-step assignment and the same fixed-order sum of the split-K partials: the same bits.  B = 160 (320 hands, a ragged
+    tail for the 64-hand tiles of the LDS form) through all four stages with either form (`ihmr_debug_force_lbs_bwd2_streaming`):
+    the raw pose gradient of the last iteration, the optimizer state, every snapshot loss, the selection and the exports."""
+    from ihmr_amd import hip
+    from ihmr_amd.optimize_model import OptimizeModel
+    B = 160
+    _, batch = _two_hand_verts(mano_arrays, B, 4242)
+    outs = []
+    try:
+        for force in (0, 1):
+            hip.lib().ihmr_debug_force_lbs_bwd2_streaming(force)
+            m = OptimizeModel(_make_opt(B, epoch=5, save_mid_freq=2))     # (a fresh instance: the stage graphs are captured under the switch)
+            m.set_input(batch); m.init_optimize(); m.optimize()
+            torch.cuda.synchronize()
+            outs.append((m.get_pred_result(), torch.stack(m.selected_history).cpu().numpy(), m.buf["adam_m"].cpu().numpy(),
+                         m.buf["adam_v"].cpu().numpy(), m.buf["snap_loss"].cpu().numpy()))
+    finally:
+        hip.lib().ihmr_debug_force_lbs_bwd2_streaming(0)
+    (a, sa, ma, va, la), (b, sb, mb, vb, lb) = outs
+    assert np.abs(ma).max() > 0
+    assert np.array_equal(sa, sb) and np.array_equal(ma, mb) and np.array_equal(va, vb) and np.array_equal(la, lb)
+    for k in ("pred_cam_params", "pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "pred_left_hand_verts",
+              "pred_joints_3d", "collision_loss", "collision_loss_origin_scale"):
+        assert np.array_equal(a[k], b[k]), f"{k}: the two forms of the pose-gradient GEMM differ"
+
+
 def test_candidate_lists_are_used_and_accounted_for(mano_arrays):
     """The work counters of the fused loop: inside a stage most inside voxels are answered from their candidate lists, every inside
     voxel is evaluated exactly once per iteration (list search + full search = inside voxels), the list search tests far fewer
