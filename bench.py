@@ -158,7 +158,8 @@ def kernel_models(kernel, hands, st):
     """(algorithmic bytes, executed-or-modelled flops) of ONE launch of `kernel` over `hands` hands; st = per-launch work counters."""
     samples = hands / 2.0
     if kernel == "sdf_dist_kernel":
-        # every hand's tables once + per inside voxel its work-list entry, map word, candidate list (384 B) and result;
+        # every hand's tables once + per EVALUATED inside voxel (`inside_voxels`: what the prep kernel hands over -- a static hand hands
+        # over only its new voxels) its work-list entry, map word, candidate list (384 B) and result;
         # flops = what the kernel executed: 11 per bounding-sphere test, 30 per plane + circle test, 75 per exact distance
         return (hands * HAND_TABLE_BYTES + st["inside_voxels"] * (4 + 4 + 384 + 4),
                 11.0 * st["sphere_tests"] + 30.0 * st["plane_tests"] + 75.0 * st["dist_evals"])
@@ -208,7 +209,7 @@ def kernel_rooflines(args, B, plan, instance, inputs, hip):
             cnt = mdl.sdf_counters_stop()
             stats = dict(sphere_tests=cnt["sphere_tests"] / n_launch, plane_tests=cnt["plane_tests"] / n_launch, dist_evals=cnt["dist_evals"] / n_launch,
                          voxels_from_lists=cnt["voxels_from_lists"] / n_launch,
-                         voxels_full_search=(cnt["voxels_without_list"] + cnt["voxels_rebuilt"]) / n_launch,
+                         voxels_full_search=cnt["voxels_full_search"] / n_launch,
                          inside_voxels=cnt["inside_voxels"] / n_launch, needed_voxels=cnt["needed_voxels"] / n_launch,
                          ray_tests=cnt["ray_tests"] / n_launch)
         mdl.use_graphs = graphs

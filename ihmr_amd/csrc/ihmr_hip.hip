@@ -357,6 +357,7 @@ extern "C" int ihmr_sdf_collision_ex(const int32_t* faces_right, const int32_t* 
     if (options) {
         ws.align_corners = options->align_corners ? 1 : 0;
         if (options->loss_divisor > 0.f) ws.loss_div = options->loss_divisor;
+        ws.swap_xz = options->swap_xz ? 1 : 0;
     }
     int32_t* soa = (int32_t*)((char*)workspace + sdf_ws_bytes(2 * B));
     uint32_t* pk = (uint32_t*)(soa + 6 * NFP);
@@ -401,24 +402,28 @@ static const ParamStep kNoStep{0, 0.f, 0.f, 1.f, -1, 0, 0};
 // skin_mode: LBS_SKIN_REUSE = the workspace holds v_posed of the current pose and shape parameters (see lbs_skin_kernel); < 0: no skin launch
 // lists: temporal candidate lists of the collision kernels -- 0 off (single-shot callers), 1 reuse while valid, 2 rebuild now
 // the collision workspace of the fused loop with the switches of this call (lists: 0 off, 1 reuse while valid, 2 rebuild now)
-static SdfWorkspace opt_sdf_ws(const ihmr_opt_io* io, const OptWork& wk, int B, int lists) {
+// static_mask: bit 0 / 1 = the right / left hands have had bit-identical vertices since the stage's first iteration (SdfWorkspace::static_mask)
+static SdfWorkspace opt_sdf_ws(const ihmr_opt_io* io, const OptWork& wk, int B, int lists, int static_mask = 0) {
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B, true);
     ws.list_mode = (lists != 0 && !io->sdf_no_candidate_lists) ? 1 : 0;
     ws.force_rebuild = lists == 2 ? 1 : 0;
+    ws.static_stage = (ws.list_mode && !io->sdf_no_static_reuse) ? static_mask : 0;
+    ws.static_mask = ws.force_rebuild ? 0 : ws.static_stage;
     ws.align_corners = io->sdf_align_corners ? 1 : 0;
     if (io->sdf_loss_divisor > 0.f) ws.loss_div = io->sdf_loss_divisor;
+    ws.swap_xz = io->sdf_swap_xz ? 1 : 0;
     return ws;
 }
 
 // head = the Adam + skeleton launch, skin = the skinning launch, tail = the sampling + loss launch (a caller that fuses them into other launches skips them)
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
                        const ihmr_opt_weights& w, const ParamStep& prev, hipStream_t st, int need_cam = 0, int skin_mode = LBS_SKIN_FULL,
-                       int lists = 0, bool head = true, bool tail = true) {
+                       int lists = 0, bool head = true, bool tail = true, int static_mask = 0) {
     if (head)
         hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B, true).inside_count);
     // (skin_mode < 0: the tail launch of the previous iteration has skinned the stored v_posed with the new skeletons, opt_tail_kernel<true, true>)
     if (skin_mode >= 0) lbs_skin_launch<true>(m, skin_mode, 2 * B, B, io->verts, wk.joints_raw, wk.lbs, st);
-    SdfWorkspace ws = opt_sdf_ws(io, wk, B, lists);
+    SdfWorkspace ws = opt_sdf_ws(io, wk, B, lists, static_mask);
     VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
     int rc = sdf_launch(vl, m->faces, m_left ? m_left->faces : m->faces, m->faces_pk, m_left ? m_left->faces_pk : m->faces_pk, B, ws, 0.f,
                         nullptr, nullptr, nullptr, nullptr, false, st);
@@ -460,6 +465,11 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     // stage, whose backward continues with a batch-wide GEMM: 7 instead of 8); in a stage that keeps v_posed the same launch also skins
     // the next iteration's vertices: 3 launches (skin_mode < 0 below)
     const bool fused_tail = need_mask != 0 && !io->no_fused_tail && m->tail_fits;
+    // Hands whose vertices cannot change during this stage (SdfWorkspace::static_mask): the right hand when none of its own blocks is
+    // refined; the left hand when neither its own blocks, nor the translation, nor the right hand's shape (the left hand is shifted by
+    // trans + J_r[0] - J_l[0], optimize_model.py:217-224) is.  opt_default's translation stage: the right hands.
+    const int static_mask = ((pm & (IHMR_PB_ORIENT_R | IHMR_PB_POSE_R | IHMR_PB_SHAPE_R)) ? 0 : 1) |
+                            ((pm & (IHMR_PB_ORIENT_L | IHMR_PB_POSE_L | IHMR_PB_SHAPE_L | IHMR_PB_TRANS | IHMR_PB_SHAPE_R)) ? 0 : 2);
     const bool pose_stage = (need_mask & 2) != 0;
     const size_t tail_lds = (size_t)2 * m->nseg * 12 * sizeof(float);
     for (int it = 0; it < sg->n_iters; ++it) {
@@ -474,9 +484,9 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
             // first skeletons) and in the finger-pose stage; otherwise the tail of iteration it - 1 has done it
             // ... and in a stage that keeps v_posed (translation, orientation) the tail has skinned the next vertices as well: 3 launches
             int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? LBS_SKIN_FULL : (vposed_fixed ? -1 : keep_mode), it == 0 ? 2 : 1,
-                                 /*head=*/it == 0 || pose_stage, /*tail=*/false);
+                                 /*head=*/it == 0 || pose_stage, /*tail=*/false, static_mask);
             if (rc) return rc;
-            SdfWorkspace ws = opt_sdf_ws(io, wk, B, it == 0 ? 2 : 1);
+            SdfWorkspace ws = opt_sdf_ws(io, wk, B, it == 0 ? 2 : 1, static_mask);
             VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
             hipEvent_t tcur;
             const bool timed = g_timer != nullptr;
@@ -495,7 +505,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
                 lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
                                     wk.lbs, st, /*bwd1_done=*/true);
         } else {
-            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? LBS_SKIN_FULL : keep_mode, it == 0 ? 2 : 1);   // applies the step of iteration it - 1 first
+            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? LBS_SKIN_FULL : keep_mode, it == 0 ? 2 : 1, true, true, static_mask);   // applies the step of iteration it - 1 first
             if (rc) return rc;
             if (need_mask)
                 lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,

@@ -403,7 +403,9 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
     if (tid >= OPT_SAMPLE_WORKERS) opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS, need_cam);
     const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
     const float gs = w.collision * mask / (ws.loss_div * (float)(io.norm_batch > 0 ? io.norm_batch : B));
-    sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, io.coll_per_vert, io.coll_origin_scale, nullptr, wk.g_verts, B, gs,
+    // (inside the loop nobody reads the per-vertex depths: the 12 KB per sample and iteration are not written -- the forward that
+    // closes optimize(), opt_sample_loss_kernel, writes the ones that are exported)
+    sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, nullptr, nullptr, nullptr, wk.g_verts, B, gs,
                      io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
     __syncthreads();         // g_verts / g_joints of this sample: written above by this workgroup, read below by it
     // ---- phase 2: LBS backward of both hands

@@ -39,6 +39,10 @@
 #ifndef SDF_ITEM_RUN
 #define SDF_ITEM_RUN 2
 #endif
+// round-4 measures, each exact (the same bits) and switchable at compile time for A/B builds (scripts/ab.sh):
+#ifndef SDF_REFUSED_BITS
+#define SDF_REFUSED_BITS 1         // voxels refused a candidate list are remembered: searched in full without the list-building half
+#endif
 #define SDF_ITEM 16                // inside voxels per work item of the distance kernel (one hand per item); power of two
 
 // Per-hand, per-iteration tables (written by the prep kernel, read by the distance kernel):
@@ -60,7 +64,9 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     float4* vn4;               // [H][SDF_NV4]
     const unsigned* fpk[2];    // [NFP] packed faces a | b << 10 | c << 20 of the right / left hand (constants of the model)
     int B;                     // hands [0, B) are right hands, [B, 2B) left hands
-    float* phi;                // [H][32768]  (only the voxels a sample reads are defined)
+    float* phi;                // [H][32768]  (only the INSIDE voxels a sample reads are defined; the dense-grid diagnostic defines all)
+    unsigned* inside_bits;     // [H][1024]   bit i of word (k,j): voxel (k,j,i) is read by a sample AND inside the mesh, i.e. phi holds its distance;
+                               //             every other voxel is 0 by definition and is never written or read (round 4: was 128-byte rows of zeros)
     unsigned* inside_list;     // [xcd_cap] inside voxels of the whole batch: (hand << 16) | voxel id, 16-aligned run per hand
     int* inside_count;         // [SDF_NCTR] [0] entries in inside_list, [1] in inside_list_a; [SDF_CURSOR] the distance kernel's work cursor, on a
                                //            128-byte line of its own (the counters are read while the cursor is hammered)
@@ -73,16 +79,31 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     float* hdisp;              // [H]        how far the hand has moved from the reference pose of its lists (this iteration; 0 while rebuilding)
     int* lnext;                // [H]        next free candidate-list slot of the hand (voxels that appear after a rebuild take one)
     unsigned* lbits;           // [H][1024]  bit i of word (k,j): voxel (k,j,i) has a candidate list (cleared when the hand starts over)
+    unsigned* rbits;           // [H][1024]  ... was REFUSED a list (too long) since the hand started over: searched in full every iteration, without
+                               //            the list-building half of that search (its entry in inside_list carries SDF_ENT_REFUSED)
     unsigned* lmap;            // [H][32768] voxel -> its list | (the triangle that was nearest the last time it was evaluated) << 16
                                //            (defined where lbits is set)
     unsigned short* lists;     // [H][SDF_LCAP_V][SDF_LCAP_L] triangle ids
     unsigned* inside_list_a;   // [xcd_cap] inside voxels of the hands whose lists are valid (aligned run per hand; inside_count[1])
+    // STATIC hands (fused loop; static_mask bit hnd: the hands of that side have had bit-identical vertices since the first iteration of
+    // the stage -- the right hands of a stage that moves only the translation): the hand's grid is a fixed function, so what an
+    // earlier iteration of the stage found out about a voxel stays true, bit for bit.  known: the voxel's inside / outside status
+    // has been determined, inside_k: it is inside (phi holds its distance).  Only voxels that are needed for the first time go
+    // through the ray test (and, if inside, through the full search); box, normalised vertices and triangle records are those of
+    // the first iteration.
+    unsigned* known;           // [H][1024]
+    unsigned* inside_k;        // [H][1024]
+    int static_mask;           // ... this launch treats these sides as static (the stage's iterations after the first)
+    int static_stage;          // ... the stage will (its first iteration records `known` / `inside_k` for them)
     int list_mode, force_rebuild;
     // conventions of the upstream module that nothing in the reference pins (ihmr_sdf_options; defaults = DESIGN.md section 4)
     int align_corners;         // grid_sample(align_corners): 0 = False (the default of the reference's pinned torch 1.6.0)
     float loss_div;            // loss[b] = sum of the 1556 sampled values / loss_div (4 = num_hands^2 of the parent project)
+    int swap_xz;               // 1: a query's x addresses the field's z axis and vice versa (an upstream grid stored phi[x][y][z] and handed
+                               //    to grid_sample as it is); 0 (default): phi[z][y][x], the layout grid_sample's (x, y, z) addresses
 };
 
+#define SDF_ENT_REFUSED 0x80000000u  // inside_list entry: (hand << 16) | voxel, hand < 32768; 0xffffffff = padding
 #define SDF_NCTR 64
 #define SDF_CURSOR 32
 #define SDF_NZERO 3                  // counters that have to be zero before the prep kernel: sdf_zero_counter(c, i), i < SDF_NZERO
@@ -97,7 +118,7 @@ __host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)H * (SDF_N
 #define SDF_LIST_SLACK 0.04f         // lists stay valid while no vertex of the hand has moved further than this (normalised frame)
 #endif
 __host__ __device__ inline size_t sdf_list_bytes(int H) {
-    return (size_t)H * ((size_t)NV3 * 4 + 16 + (size_t)SDF_NCOL * 4 + (size_t)SDF_NVOX * 4 + (size_t)SDF_LCAP_V * SDF_LCAP_L * 2) +
+    return (size_t)H * ((size_t)NV3 * 4 + 16 + (size_t)4 * SDF_NCOL * 4 + (size_t)SDF_NVOX * 4 + (size_t)SDF_LCAP_V * SDF_LCAP_L * 2) +
            sdf_xcd_cap(H) * sizeof(unsigned) + 1024;
 }
 __host__ __device__ inline size_t sdf_ws_bytes(int H, bool lists = false) {
@@ -107,6 +128,7 @@ __host__ __device__ inline size_t sdf_ws_bytes(int H, bool lists = false) {
     n += (size_t)H * NFP * sizeof(unsigned);        // nrm
     n += (size_t)H * SDF_NV4 * sizeof(float4);      // vn4
     n += (size_t)H * SDF_NVOX * sizeof(float);
+    n += (size_t)H * SDF_NCOL * sizeof(unsigned);   // inside_bits
     n += sdf_xcd_cap(H) * sizeof(unsigned);
     n += 128 + SDF_NCTR * 4 + 256;
     return (n + 255) & ~(size_t)255;
@@ -122,11 +144,13 @@ static inline SdfWorkspace sdf_carve(void* ws, int H, bool lists = false) {
     w.fpk[0] = w.fpk[1] = nullptr;
     w.B = H / 2;
     w.phi = (float*)p; p += (size_t)H * SDF_NVOX * sizeof(float);
+    w.inside_bits = (unsigned*)p; p += (size_t)H * SDF_NCOL * sizeof(unsigned);
     w.stats = (unsigned long long*)p; p += 128;
     w.inside_count = (int*)p; p += SDF_NCTR * 4;
     w.xcd_cap = (int)sdf_xcd_cap(H);
     w.inside_list = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
-    w.vn_ref = nullptr; w.hmode = nullptr; w.run_start = nullptr; w.hdisp = nullptr; w.lnext = nullptr; w.lbits = nullptr; w.lmap = nullptr; w.lists = nullptr;
+    w.vn_ref = nullptr; w.hmode = nullptr; w.run_start = nullptr; w.hdisp = nullptr; w.lnext = nullptr; w.lbits = nullptr; w.rbits = nullptr; w.lmap = nullptr; w.lists = nullptr; w.known = nullptr; w.inside_k = nullptr;
+    w.static_mask = 0; w.static_stage = 0;
     w.inside_list_a = nullptr;
     w.list_mode = 0; w.force_rebuild = 1;
     if (lists) {
@@ -138,6 +162,9 @@ static inline SdfWorkspace sdf_carve(void* ws, int H, bool lists = false) {
         w.lnext = (int*)p; p += (size_t)H * 4;
         p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         w.lbits = (unsigned*)p; p += (size_t)H * SDF_NCOL * 4;
+        w.rbits = (unsigned*)p; p += (size_t)H * SDF_NCOL * 4;
+        w.known = (unsigned*)p; p += (size_t)H * SDF_NCOL * 4;
+        w.inside_k = (unsigned*)p; p += (size_t)H * SDF_NCOL * 4;
         w.inside_list_a = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
         w.lmap = (unsigned*)p; p += (size_t)H * SDF_NVOX * 4;
         p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
@@ -145,6 +172,7 @@ static inline SdfWorkspace sdf_carve(void* ws, int H, bool lists = false) {
     }
     w.align_corners = 0;
     w.loss_div = 4.0f;
+    w.swap_xz = 0;
     return w;
 }
 
@@ -322,16 +350,22 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     float oq[VPT][3];
     struct F3 { float x, y, z; };        // a vertex as ONE 12-byte load (rows of 3 floats, 4-byte aligned)
+    const bool lists_on = !DENSE && ws.list_mode != 0;
+    // a STATIC hand (see SdfWorkspace::static_mask; uniform over the workgroup): its own vertices are not even read
+    const bool stat = lists_on && !ws.force_rebuild && ((ws.static_mask >> hnd) & 1);
 #pragma unroll
     for (int rep = 0; rep < VPT; ++rep) {
         oq[rep][0] = oq[rep][1] = oq[rep][2] = 0.f;
         const int v = tid + rep * PT;
         if (v < NV) {
-            const F3 o = reinterpret_cast<const F3*>(own)[v], q = reinterpret_cast<const F3*>(other)[v];
+            const F3 q = reinterpret_cast<const F3*>(other)[v];
             oq[rep][0] = q.x; oq[rep][1] = q.y; oq[rep][2] = q.z;
-            vn[3 * v] = o.x; vn[3 * v + 1] = o.y; vn[3 * v + 2] = o.z;
-            mn[0] = fminf(mn[0], o.x); mn[1] = fminf(mn[1], o.y); mn[2] = fminf(mn[2], o.z);
-            mx[0] = fmaxf(mx[0], o.x); mx[1] = fmaxf(mx[1], o.y); mx[2] = fmaxf(mx[2], o.z);
+            if (!stat) {
+                const F3 o = reinterpret_cast<const F3*>(own)[v];
+                vn[3 * v] = o.x; vn[3 * v + 1] = o.y; vn[3 * v + 2] = o.z;
+                mn[0] = fminf(mn[0], o.x); mn[1] = fminf(mn[1], o.y); mn[2] = fminf(mn[2], o.z);
+                mx[0] = fmaxf(mx[0], o.x); mx[1] = fmaxf(mx[1], o.y); mx[2] = fmaxf(mx[2], o.z);
+            }
         }
     }
     // face indices of this lane's (up to four) triangles (packed: one load each): issued early, consumed after the box is known
@@ -344,21 +378,26 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     }
     // state of the temporal candidate lists, requested now and used much later: the hand's reference pose (this thread's vertices)
     // and which voxels of this thread's two columns have a list
-    const bool lists_on = !DENSE && ws.list_mode != 0;
     float rf[VPT][3];
-    unsigned lb2[CPT];
+    unsigned lb2[CPT], rb2[CPT];
 #pragma unroll
     for (int rep = 0; rep < VPT; ++rep) {
         const int v = tid + rep * PT;
         rf[rep][0] = rf[rep][1] = rf[rep][2] = 0.f;
-        if (lists_on && !ws.force_rebuild && v < NV) {
+        if (lists_on && !ws.force_rebuild && !stat && v < NV) {
             const F3 r = reinterpret_cast<const F3*>(ws.vn_ref + (size_t)H * NV3)[v];
             rf[rep][0] = r.x; rf[rep][1] = r.y; rf[rep][2] = r.z;
         }
     }
 #pragma unroll
     for (int rep = 0; rep < CPT; ++rep)
-        lb2[rep] = (lists_on && !ws.force_rebuild) ? ws.lbits[(size_t)H * SDF_NCOL + CPT * tid + rep] : 0u;
+    {
+        lb2[rep] = (lists_on && !ws.force_rebuild && !stat) ? ws.lbits[(size_t)H * SDF_NCOL + CPT * tid + rep] : 0u;
+        rb2[rep] = (lists_on && !ws.force_rebuild && !stat) ? ws.rbits[(size_t)H * SDF_NCOL + CPT * tid + rep] : 0u;
+    }
+
+    float4 sbox = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (stat) sbox = *reinterpret_cast<const float4*>(ws.box + H * 4);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float a = wave_reduce_min(mn[k]), c = wave_reduce_max(mx[k]);
@@ -386,20 +425,22 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         cz = (lo[2] + hi[2]) * 0.5f;
         sc = 0.6f * fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));  // (1 + 0.2) * 0.5 * max extent
     }
+    if (stat) { cx = sbox.x; cy = sbox.y; cz = sbox.z; sc = sbox.w; }      // (the box of the stage's first iteration: the same vertices)
     SDF_TK(pk_[1] = SDF_STAMP();)
-    if (tid < 4) ws.box[H * 4 + tid] = tid == 0 ? cx : (tid == 1 ? cy : (tid == 2 ? cz : sc));
+    if (!stat && tid < 4) ws.box[H * 4 + tid] = tid == 0 ? cx : (tid == 1 ? cy : (tid == 2 ? cz : sc));
     // ---- normalise own vertices into [-1,1]^3; which voxels will the other hand's vertices read?
 #pragma unroll
     for (int rep = 0; rep < VPT; ++rep) {
         const int v = tid + rep * PT;
         if (v >= NV) break;
-        {
+        if (!stat) {
             const float nx = (vn[3 * v] - cx) / sc, ny = (vn[3 * v + 1] - cy) / sc, nz = (vn[3 * v + 2] - cz) / sc;
             vn[3 * v] = nx; vn[3 * v + 1] = ny; vn[3 * v + 2] = nz;
             ws.vn4[(size_t)H * SDF_NV4 + v] = make_float4(nx, ny, nz, 0.f);     // the exact distance gathers triangle corners from here
         }
         if (!DENSE) {
-            const float qx = (oq[rep][0] - cx) / sc, qy = (oq[rep][1] - cy) / sc, qz = (oq[rep][2] - cz) / sc;
+            const float qx0 = (oq[rep][0] - cx) / sc, qy = (oq[rep][1] - cy) / sc, qz0 = (oq[rep][2] - cz) / sc;
+            const float qx = ws.swap_xz ? qz0 : qx0, qz = ws.swap_xz ? qx0 : qz0;
             const float ix = sdf_unnorm(qx, ws.align_corners), iy = sdf_unnorm(qy, ws.align_corners), iz = sdf_unnorm(qz, ws.align_corners);
             const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
             // completely outside the grid (or non-finite): contributes nothing
@@ -432,7 +473,8 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     //      iteration of a stage: the parameters may have jumped), the hand starts over: reference frame := now, map cleared.
     SDF_TK(pk_[2] = SDF_STAMP();)
     bool lists_reused = false;
-    if (lists_on) {
+    if (stat && tid == 0) ws.hmode[H] = -1;        // (its new voxels are searched in full, without candidate lists)
+    if (lists_on && !stat) {
         float* ref = ws.vn_ref + (size_t)H * NV3;
         float dmax = 0.f;
         if (!ws.force_rebuild) {
@@ -465,13 +507,60 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
                 if (v < NV) { ref[3 * v] = vn[3 * v]; ref[3 * v + 1] = vn[3 * v + 1]; ref[3 * v + 2] = vn[3 * v + 2]; }
             }
 #pragma unroll
-            for (int rep = 0; rep < CPT; ++rep) ws.lbits[(size_t)H * SDF_NCOL + tid + rep * PT] = 0u;
+            for (int rep = 0; rep < CPT; ++rep) { ws.lbits[(size_t)H * SDF_NCOL + tid + rep * PT] = 0u; ws.rbits[(size_t)H * SDF_NCOL + tid + rep * PT] = 0u; }
         }
         if (tid == 0) ws.hmode[H] = reuse ? 1 : 0;
         if (!reuse) {
 #pragma unroll
-            for (int rep = 0; rep < CPT; ++rep) lb2[rep] = 0u;
+            for (int rep = 0; rep < CPT; ++rep) { lb2[rep] = 0u; rb2[rep] = 0u; }
         }
+    }
+    // ---- a static hand: which needed voxels are needed for the FIRST time in this stage?  Only those go through the ray test (their
+    //      masks replace `needed` there: `nmask`); none (common once the other hand has settled): the test is skipped altogether.
+    unsigned* const newm = reinterpret_cast<unsigned*>(cur);      // (cur is free until the publish phase)
+    const unsigned* const nmask = stat ? newm : needed;
+    bool stat_skip = false;
+    unsigned kn2[CPT], ik2[CPT];       // this thread's columns: voxels whose status is known / known to be inside (static hands)
+#pragma unroll
+    for (int rep = 0; rep < CPT; ++rep) kn2[rep] = ik2[rep] = 0u;
+    if (stat) {
+#pragma unroll
+        for (int rep = 0; rep < CPT; ++rep) {
+            kn2[rep] = ws.known[(size_t)H * SDF_NCOL + CPT * tid + rep];
+            ik2[rep] = ws.inside_k[(size_t)H * SDF_NCOL + CPT * tid + rep];
+        }
+        unsigned anyn = 0u;
+#pragma unroll
+        for (int rep = 0; rep < CPT; ++rep) {
+            const unsigned nw = needed[CPT * tid + rep] & ~kn2[rep];
+            newm[CPT * tid + rep] = nw;
+            anyn |= nw;
+        }
+        const unsigned long long bal = __ballot(anyn != 0u);
+        if (lane == 0) scratch[wave] = bal != 0ull ? 1 : 0;
+        SDF_LDS_BARRIER();
+        int any = 0;
+#pragma unroll
+        for (int w = 0; w < PT / WAVE; ++w) any |= scratch[w];
+        stat_skip = any == 0;
+        if (!stat_skip) {
+            // the hand's normalised vertices as the first iteration stored them (the bits a recomputation would give)
+#pragma unroll
+            for (int rep = 0; rep < VPT; ++rep) {
+                const int v = tid + rep * PT;
+                if (v < NV) {
+                    const float4 p4 = ws.vn4[(size_t)H * SDF_NV4 + v];
+                    vn[3 * v] = p4.x; vn[3 * v + 1] = p4.y; vn[3 * v + 2] = p4.z;
+                }
+            }
+            // columns that hold a new voxel
+#pragma unroll
+            for (int rep = 0; rep < CPT; ++rep) {
+                const unsigned long long anyc = __ballot(newm[tid + rep * PT] != 0u);
+                if (lane == 0) { rowany[2 * (wave + (PT / WAVE) * rep)] = (unsigned)anyc; rowany[2 * (wave + (PT / WAVE) * rep) + 1] = (unsigned)(anyc >> 32); }
+            }
+        }
+        SDF_LDS_BARRIER();          // (scratch is free again; vn / rowany visible)
     }
     // ---- lane = triangle: records for the distance kernel + ray parity of the needed voxels it can hit
     SDF_TK(pk_[3] = SDF_STAMP();)
@@ -480,7 +569,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     unsigned long long st_tests = 0;
     // (two loops over the lane's triangles -- records, then ray parity: together they would not fit the 64 registers of 8 waves / SIMD)
 #pragma unroll 1
-    for (int it = 0; it < TRI_IT; ++it) {
+    for (int it = 0; it < (stat ? 0 : TRI_IT); ++it) {        // (a static hand keeps its records)
         const int f = tid + it * PT;
         if (f >= NFP) break;
         const int fa = fidx[it][0], fb = fidx[it][1], fc = fidx[it][2];
@@ -540,7 +629,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     //      covers 30 columns, most cover 0-2, and every iteration is a dependent LDS round trip).  So the lanes only ENUMERATE their
     //      pairs (a store per column) into an LDS queue, and the pairs are then dealt evenly: thread p takes pairs p, p + PT, ...,
     //      re-derives the triangle's constants (same expressions: the same bits) and does the (u,v) test and the hit mask.
-    {
+    if (!stat_skip) {
         const unsigned* fpk = ws.fpk[hnd];
         int cnt[TRI_IT], kr[TRI_IT];       // per triangle: needed columns in its box, k range packed (+ the j mask below)
         unsigned jmk[TRI_IT];
@@ -611,7 +700,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
                 const int j = col & (SDF_G - 1), k = col >> 5;
                 const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
                 const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
-                const unsigned need = needed[col];
+                const unsigned need = nmask[col];
                 const float sy = py - a[1], sz = pz - a[2];
                 const float uu = __builtin_fmaf(sz, e2y, -(sy * e2z)) * inv;
                 const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y));
@@ -630,21 +719,43 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     // ---- publish: a thread owns CPT adjacent columns; phi = 0 for the outside voxels a sample reads, inside voxels
     //      into the batch-wide lists
     float* phi = ws.phi + (size_t)H * SDF_NVOX;
-    unsigned need2[CPT], inside2[CPT];
+    unsigned need2[CPT], inside2[CPT], pub2[CPT];     // needed / inside (= phi defined) / to be evaluated by the distance kernel now
 #pragma unroll
     for (int rep = 0; rep < CPT; ++rep) {
         const int col = CPT * tid + rep;
         need2[rep] = needed[col];
-        inside2[rep] = parity[col] & need2[rep];
-        // phi = 0 for the outside voxels a sample reads: the column's whole 128-byte row is zeroed (eight 16-byte stores, no loop over
-        // the bits: the inside voxels are overwritten by the distance kernel, which runs after this one, and nobody reads the rest)
-        if (need2[rep] & ~inside2[rep]) {
+        if (stat) {           // what earlier iterations of the stage found + the voxels tested just now
+            const unsigned nw = stat_skip ? 0u : newm[col];
+            pub2[rep] = parity[col] & nw;
+            kn2[rep] |= nw;
+            ik2[rep] |= pub2[rep];
+            inside2[rep] = ik2[rep] & need2[rep];
+        } else {
+            inside2[rep] = parity[col] & need2[rep];
+            pub2[rep] = inside2[rep];
+            kn2[rep] = need2[rep];
+            ik2[rep] = inside2[rep];
+        }
+        // the dense-grid diagnostic hands the whole grid out: phi = 0 for its outside voxels (the column's 128-byte row is zeroed, the
+        // inside voxels are overwritten by the distance kernel).  The samplers never read an outside voxel: inside_bits below.
+        if (DENSE && (need2[rep] & ~inside2[rep])) {
             float4* row = reinterpret_cast<float4*>(phi + col * SDF_G);
 #pragma unroll
             for (int q = 0; q < SDF_G / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // inside voxels with a candidate list (low half) / without (high half): one scan for both
-        cur[col] = __popc(inside2[rep] & lb2[rep]) | (__popc(inside2[rep] & ~lb2[rep]) << 16);
+        cur[col] = __popc(pub2[rep] & lb2[rep]) | (__popc(pub2[rep] & ~lb2[rep]) << 16);
+    }
+    // which voxels hold a distance: one word per column, a thread's CPT adjacent words in one store
+    if (CPT == 2) *reinterpret_cast<uint2*>(ws.inside_bits + (size_t)H * SDF_NCOL + 2 * tid) = make_uint2(inside2[0], inside2[CPT - 1]);
+    else ws.inside_bits[(size_t)H * SDF_NCOL + tid] = inside2[0];
+    // a hand that is static in the stage's later iterations starts from what its first iteration knows; a static hand adds what it learnt
+    if (lists_on && (stat ? !stat_skip : (((ws.static_stage >> hnd) & 1) != 0))) {
+#pragma unroll
+        for (int rep = 0; rep < CPT; ++rep) {
+            ws.known[(size_t)H * SDF_NCOL + CPT * tid + rep] = kn2[rep];
+            ws.inside_k[(size_t)H * SDF_NCOL + CPT * tid + rep] = ik2[rep];
+        }
     }
     const unsigned blk_both = (unsigned)block_excl_scan_1024<PT>(cur, scratch);
     // Two batch-wide lists, each with an aligned run per hand (tail padded with an invalid marker) so that a work item belongs to
@@ -655,7 +766,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     if (tid == 0) {              // (the two reservations from different waves: their round trips overlap)
         blk_inside = n_a + n_b;
         blk_base = n_b > 0 ? atomicAdd(&ws.inside_count[0], pad_b) : 0;
-        if (lists_on) {
+        if (lists_on && !stat) {
             ws.run_start[H] = blk_base;
             if (!lists_reused) ws.lnext[H] = n_b;      // a rebuild hands out slots 0 .. n_b - 1 by position in the run
         }
@@ -671,13 +782,13 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         const int col = CPT * tid + rep;
         const unsigned both = (unsigned)cur[col];
         int oa = (int)(both & 0xffffu), ob = (int)(both >> 16);
-        unsigned rem = inside2[rep];
+        unsigned rem = pub2[rep];
         while (rem) {
             const int i = __ffs((int)rem) - 1;
             rem &= rem - 1;
             const unsigned ent = ((unsigned)H << 16) | (unsigned)(col * SDF_G + i);
             if ((lb2[rep] >> i) & 1u) run_a[oa++] = ent;
-            else run_b[ob++] = ent;
+            else run_b[ob++] = ent | (((rb2[rep] >> i) & 1u) ? SDF_ENT_REFUSED : 0u);
         }
     }
     SDF_TK(if (tid == 0 && H < 4096) { pk_[6] = SDF_STAMP(); for (int k = 0; k < 6; ++k) g_sdf_prep[H][k] += pk_[k + 1] - pk_[k]; g_sdf_prep[H][6] += (long long)blk_inside; g_sdf_prep[H][7] += 1; })
@@ -885,7 +996,7 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
     {
         SDF_TK(const long long tk0 = SDF_STAMP();)
         const unsigned ent_l = lane < SDF_ITEM ? glist[item * SDF_ITEM + lane] : 0xffffffffu;
-        const int H = (int)((unsigned)__builtin_amdgcn_readlane((int)ent_l, 0) >> 16);   // entry 0 of an item is always valid
+        const int H = (int)(((unsigned)__builtin_amdgcn_readlane((int)ent_l, 0) & ~SDF_ENT_REFUSED) >> 16);   // entry 0 of an item is always valid
         // this wave's entries of the item: e0 + 4 q, q < vpw -- interleaved over the waves, so that the voxels of a partly filled item
         // (a hand's few late voxels) spread over all four waves: one sphere pass each instead of two on the first wave
         const int e0 = (half > 0 ? SDF_ITEM / 2 : 0) + wave;
@@ -937,6 +1048,9 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
         // ---- the full search for a pair of voxels (packed fp32): table read once for both
         auto pair_pass = [&](unsigned ent0, unsigned ent1r, int vs0, int lidx0) {
             const int nvox = ent1r != 0xffffffffu ? 2 : 1;
+            // a voxel that was refused a list since the hand started over (too many triangles within the list bound: a voxel deep inside the
+            // other hand) would be refused again: the pair skips the list-building half of the search (pmode -1) when all of it is such
+            const int pmode = (SDF_REFUSED_BITS && (ent0 & SDF_ENT_REFUSED) && (nvox == 1 || (ent1r & SDF_ENT_REFUSED))) ? -1 : mode;
             const int id0 = (int)(ent0 & 0xffffu), id1 = (int)((nvox == 2 ? ent1r : ent0) & 0xffffu);
             const sdf_v2f PX = {(float)(2 * (id0 & 31) + 1) / (float)SDF_G - 1.0f, (float)(2 * (id1 & 31) + 1) / (float)SDF_G - 1.0f};
             const sdf_v2f PY = {(float)(2 * ((id0 >> 5) & 31) + 1) / (float)SDF_G - 1.0f,
@@ -960,7 +1074,7 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
             // the slots' upper bound for the refine pass (no triangle id yet: any exact distance will be below it)
             if (lane < nvox) w.best[vs0 + lane] = ((unsigned long long)__float_as_uint(lane ? ub_b * ub_b : ub_a * ub_a) << 32) | 0xffffull;
             unsigned keep_a = 0, keep_b = 0, list_a = 0, list_b = 0;
-            if (mode >= 0) {   // lists are being built: the same cull with the bound widened by twice the motion the list has to cover
+            if (pmode >= 0) {   // lists are being built: the same cull with the bound widened by twice the motion the list has to cover
 #pragma unroll
                 for (int t = 0; t < NFP / WAVE; ++t) {
                     const float r = sph_s[lane + WAVE * t].w;
@@ -1012,7 +1126,7 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
                         SDF_CNT(st_dist += 1);
                     }
                 }
-                if (mode >= 0) {
+                if (pmode >= 0) {
                     // the voxel's candidate list: every triangle whose bounding sphere comes within the (widened) bound; its slot =
                     // the voxel's position in the hand's run (known without atomics) or a fresh one.  Too long a list, or too many voxels: none.
                     unsigned lm = v ? list_b : list_a;
@@ -1027,7 +1141,12 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
                     }
                     if (lane == vs) my_slot = lidx;
                     SDF_CNT(acc.refused += (unsigned)(lane == 0 && !(lcnt <= SDF_LCAP_L && lidx < SDF_LCAP_V) ? 1 : 0));
-                    if (lcnt <= SDF_LCAP_L && lidx < SDF_LCAP_V) {
+                    if (!(lcnt <= SDF_LCAP_L && lidx < SDF_LCAP_V)) {
+                        if (lane == 0) {
+                            const int vid = v ? id1 : id0;
+                            atomicOr(&ws.rbits[(size_t)H * SDF_NCOL + (vid >> 5)], 1u << (vid & 31));
+                        }
+                    } else {
                         unsigned short* dst = ws.lists + ((size_t)H * SDF_LCAP_V + lidx) * SDF_LCAP_L;
                         constexpr int LQ = SDF_LCAP_L / SDF_LIST_K;     // element i at (i % K) * LQ + i / K: each of the K reader lanes gets a contiguous piece
                         while (lm) {
@@ -1286,6 +1405,7 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
             atomicAdd(&ws.stats[7], (unsigned long long)acc.build);                          // voxels whose lists were (re)built
             atomicAdd(&ws.stats[8], (unsigned long long)acc.ref);                            // plane + circle tests
             atomicAdd(&ws.stats[9], (unsigned long long)acc.refused);                        // voxels searched in full that got NO list (too long / no slot left)
+            atomicAdd(&ws.stats[10], (unsigned long long)acc.full);                          // voxels searched in full, whatever the reason
         }
     }
 #ifdef SDF_STAMPS
@@ -1334,36 +1454,56 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
     }
     __builtin_amdgcn_sched_barrier(0);
     float pv[SDF_SAMPLE_NIT][8], ixs[SDF_SAMPLE_NIT][3];
+    unsigned ibw[SDF_SAMPLE_NIT][4];
     bool inr[SDF_SAMPLE_NIT];
 #pragma unroll
     for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
         const float cx = bx[it].x, cy = bx[it].y, cz = bx[it].z, sc = bx[it].w;
-        const float ix = sdf_unnorm((qv[it][0] - cx) / sc, ws.align_corners), iy = sdf_unnorm((qv[it][1] - cy) / sc, ws.align_corners),
-                    iz = sdf_unnorm((qv[it][2] - cz) / sc, ws.align_corners);
+        const float nx0 = (qv[it][0] - cx) / sc, nz0 = (qv[it][2] - cz) / sc;
+        const float ix = sdf_unnorm(ws.swap_xz ? nz0 : nx0, ws.align_corners), iy = sdf_unnorm((qv[it][1] - cy) / sc, ws.align_corners),
+                    iz = sdf_unnorm(ws.swap_xz ? nx0 : nz0, ws.align_corners);
         ixs[it][0] = ix; ixs[it][1] = iy; ixs[it][2] = iz;
         const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
         inr[it] = on[it] && x0 >= -1.0f && x0 <= (float)(SDF_G - 1) && y0 >= -1.0f && y0 <= (float)(SDF_G - 1) && z0 >= -1.0f &&
                   z0 <= (float)(SDF_G - 1);
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) pv[it][c8] = 0.f;
+        ibw[it][0] = ibw[it][1] = ibw[it][2] = ibw[it][3] = 0u;
         if (inr[it]) {
-            const int i0 = (int)x0, j0 = (int)y0, k0 = (int)z0;
-            const float* phi = ws.phi + (size_t)(hn[it] * B + b) * SDF_NVOX;
-            // the two x-neighbours of a cell are adjacent in memory: one load for the pair when both are inside the grid
-            // (4-byte aligned 8-byte load: the hardware takes dword-aligned global accesses of any width), single loads at
-            // the border of the grid
+            // which of the cell's eight corners hold a distance at all (inside the mesh): one bitmap word per (k, j) row -- a 4 KB table
+            // per hand; most query vertices lie outside the other hand and read nothing else
+            const int j0 = (int)y0, k0 = (int)z0;
+            const unsigned* ib = ws.inside_bits + (size_t)(hn[it] * B + b) * SDF_NCOL;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 const int j = j0 + (c4 & 1), k = k0 + (c4 >> 1);
-                const bool row_in = j >= 0 && j < SDF_G && k >= 0 && k < SDF_G;
+                if (j >= 0 && j < SDF_G && k >= 0 && k < SDF_G) ibw[it][c4] = ib[k * SDF_G + j];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        if (inr[it]) {
+            const int i0 = (int)floorf(ixs[it][0]), j0 = (int)floorf(ixs[it][1]), k0 = (int)floorf(ixs[it][2]);
+            const float* phi = ws.phi + (size_t)(hn[it] * B + b) * SDF_NVOX;
+            // the two x-neighbours of a cell are adjacent in memory: one load for the pair when both are inside the grid
+            // (4-byte aligned 8-byte load: the hardware takes dword-aligned global accesses of any width), single loads at
+            // the border of the grid; a voxel outside the mesh is 0 without a load
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int j = j0 + (c4 & 1), k = k0 + (c4 >> 1);
+                const unsigned wbits = ibw[it][c4];
+                const bool b0 = i0 >= 0 && ((wbits >> (i0 & 31)) & 1u), b1 = i0 + 1 < SDF_G && ((wbits >> ((i0 + 1) & 31)) & 1u);
                 const float* row = phi + (k * SDF_G + j) * SDF_G;
-                if (row_in && i0 >= 0 && i0 + 1 < SDF_G) {
+                if (b0 && b1) {
                     typedef float sdf_f2u __attribute__((ext_vector_type(2), aligned(4)));
                     const sdf_f2u two = *reinterpret_cast<const sdf_f2u*>(row + i0);
                     pv[it][2 * c4] = two.x; pv[it][2 * c4 + 1] = two.y;
-                } else {
-                    pv[it][2 * c4] = (row_in && i0 >= 0) ? row[i0] : 0.f;
-                    pv[it][2 * c4 + 1] = (row_in && i0 + 1 < SDF_G) ? row[i0 + 1] : 0.f;
+                } else if (b0) {
+                    pv[it][2 * c4] = row[i0];
+                } else if (b1) {
+                    pv[it][2 * c4 + 1] = row[i0 + 1];
                 }
             }
         }
@@ -1398,6 +1538,7 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
         // chain: ix = ((x+1)*G - 1)/2 (or (x+1)/2*(G-1)), x = (q - c)/s  =>  d ix / d q = G / (2 s)  (or (G-1) / (2 s))
         const float chain = (0.5f * (float)(ws.align_corners ? SDF_G - 1 : SDF_G)) / sc;
         gx *= chain; gy *= chain; gz *= chain;
+        if (ws.swap_xz) { const float t = gx; gx = gz; gz = t; }       // back to the query vertex's own axes
         if (robustifier > 0.f) {
             const float r = val / robustifier, fr = r * r;
             const float dfr = 2.0f * r / robustifier;       // d fr / d val
@@ -1405,8 +1546,10 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
             val = fr / (fr + 1.0f);
             gx *= dout; gy *= dout; gz *= dout;
         }
-        per_vert[(size_t)b * 2 * NV + e] = val;
-        origin[(size_t)b * 2 * NV + e] = val * sc;
+        if (per_vert) {
+            per_vert[(size_t)b * 2 * NV + e] = val;
+            origin[(size_t)b * 2 * NV + e] = val * sc;
+        }
         if (dval) {
             float* d = dval + ((size_t)b * 2 * NV + e) * 3;
             d[0] = gx; d[1] = gy; d[2] = gz;

@@ -54,12 +54,13 @@ class OptIO(C.Structure):
         "hand_type_array",
         "verts", "joints_3d", "joints_2d", "loss_batch", "coll_per_vert", "coll_origin_scale",
         "snap_params", "snap_loss", "selected", "adam_m", "adam_v", "workspace")] + [
-        ("norm_batch", C.c_int), ("sdf_align_corners", C.c_int), ("sdf_loss_divisor", C.c_float), ("sdf_no_candidate_lists", C.c_int),
+        ("norm_batch", C.c_int), ("sdf_align_corners", C.c_int), ("sdf_loss_divisor", C.c_float), ("sdf_swap_xz", C.c_int),
+        ("sdf_no_candidate_lists", C.c_int), ("sdf_no_static_reuse", C.c_int),
         ("no_fused_tail", C.c_int)]
 
 
 class SdfOptions(C.Structure):
-    _fields_ = [("align_corners", C.c_int), ("loss_divisor", C.c_float)]
+    _fields_ = [("align_corners", C.c_int), ("loss_divisor", C.c_float), ("swap_xz", C.c_int)]
 
 
 class OptStage(C.Structure):

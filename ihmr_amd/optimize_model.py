@@ -149,11 +149,13 @@ class OptimizeModel:
             selected=torch.zeros(B, device=dev, dtype=torch.int32), adam_m=z(B, hip.OPT_NPARAM), adam_v=z(B, hip.OPT_NPARAM),
             workspace=torch.empty(hip.lib().ihmr_opt_workspace_bytes(B), device=dev, dtype=torch.uint8),
         )
-        # conventions of the collision module (include/ihmr_hip.h: ihmr_sdf_options): opt.sdf_align_corners / opt.sdf_loss_divisor
+        # conventions of the collision module (include/ihmr_hip.h: ihmr_sdf_options): opt.sdf_align_corners / opt.sdf_loss_divisor / opt.sdf_swap_xz
         self.io = hip.OptIO(**{k: v.data_ptr() for k, v in self.buf.items()}, norm_batch=self.norm_batch,
                             sdf_align_corners=int(bool(getattr(self.opt, "sdf_align_corners", False))),
                             sdf_loss_divisor=float(getattr(self.opt, "sdf_loss_divisor", 0.0) or 0.0),
+                            sdf_swap_xz=int(bool(getattr(self.opt, "sdf_swap_xz", False))),
                             sdf_no_candidate_lists=int(bool(getattr(self.opt, "sdf_no_candidate_lists", False))),
+                            sdf_no_static_reuse=int(bool(getattr(self.opt, "sdf_no_static_reuse", False))),
                             no_fused_tail=int(bool(getattr(self.opt, "no_fused_tail", False))))
         self.mano_params_weight = z(B, 2)
         self.init = {}
@@ -219,7 +221,7 @@ class OptimizeModel:
         return dict(ray_tests=int(out[0]), dist_evals=int(out[1]), inside_voxels=int(out[2]), needed_voxels=int(out[3]))
 
     SDF_COUNTERS = ("ray_tests", "dist_evals", "inside_voxels", "needed_voxels", "sphere_tests", "voxels_from_lists",
-                    "voxels_without_list", "voxels_rebuilt", "plane_tests", "lists_refused")
+                    "voxels_without_list", "voxels_rebuilt", "plane_tests", "lists_refused", "voxels_full_search")
 
     def _drop_graphs(self):
         """Destroy every captured graph of this instance (they are re-captured on demand)."""

@@ -30,7 +30,7 @@ class _SdfFunction(torch.autograd.Function):
         dval = torch.empty(B, 1556, 3, device=dev)
         ws = module._workspace(B, dev)
         import ctypes as C
-        options = hip.SdfOptions(int(bool(module.align_corners)), float(module.loss_divisor))
+        options = hip.SdfOptions(int(bool(module.align_corners)), float(module.loss_divisor), int(bool(module.swap_xz)))
         hip.check(hip.lib().ihmr_sdf_collision_ex(hip.ptr(module.faces_right), hip.ptr(module.faces_left), hip.ptr(hv), B,
                                                   float(module.robustifier or 0.0), C.byref(options), hip.ptr(loss), hip.ptr(per_vert),
                                                   hip.ptr(origin), hip.ptr(dval), hip.ptr(ws), hip.stream_ptr()),
@@ -59,8 +59,8 @@ class _SdfFunction(torch.autograd.Function):
 
 
 class SDFLoss(nn.Module):
-    def __init__(self, faces_right, faces_left, robustifier=None, grid_size=32, align_corners=False, loss_divisor=4.0):
-        """``align_corners`` / ``loss_divisor``: the two conventions of the (absent, unpinned) upstream module that a maintainer
+    def __init__(self, faces_right, faces_left, robustifier=None, grid_size=32, align_corners=False, loss_divisor=4.0, swap_xz=False):
+        """``align_corners`` / ``loss_divisor`` / ``swap_xz`` (axis order of the grid as ``grid_sample`` sees it): the three conventions of the (absent, unpinned) upstream module that a maintainer
         holding the real package can switch to pin this seam (``include/ihmr_hip.h: ihmr_sdf_options``)."""
         super().__init__()
         assert grid_size == 32, "the kernels are built for the 32^3 grid of the upstream module"
@@ -68,7 +68,7 @@ class SDFLoss(nn.Module):
         loss_divisor = float(loss_divisor)
         if not loss_divisor > 0.0:
             raise ValueError(f"SDFLoss(loss_divisor={loss_divisor}): must be > 0 (4 = num_hands^2 of the parent project, 1 = plain sum)")
-        self.align_corners, self.loss_divisor = bool(align_corners), loss_divisor
+        self.align_corners, self.loss_divisor, self.swap_xz = bool(align_corners), loss_divisor, bool(swap_xz)
         self.register_buffer("faces_right", torch.tensor(np.asarray(faces_right).astype(np.int32)))
         self.register_buffer("faces_left", torch.tensor(np.asarray(faces_left).astype(np.int32)))
         self.robustifier = robustifier

@@ -76,15 +76,18 @@ size_t ihmr_sdf_workspace_bytes(int B);
 int ihmr_sdf_collision(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
                        float robustifier, float* loss, float* per_vert, float* origin_scale, float* dval,
                        void* workspace, void* stream);
-/* The upstream module (github.com/penincillin/SDF_ihmr, unpinned commit) is absent, and the reference pins neither of these
- * two conventions; both default to what DESIGN.md section 4 decides and can be switched by a maintainer who holds the real
+/* The upstream module (github.com/penincillin/SDF_ihmr, unpinned commit) is absent, and the reference pins none of these
+ * three conventions; all default to what DESIGN.md section 4 decides and can be switched by a maintainer who holds the real
  * package (INTEGRATION.md "Pinning seam B"):
  *   align_corners  the `align_corners` of the trilinear grid_sample of phi (0 = False, the default of torch 1.6.0)
  *   loss_divisor   loss[b] = sum of the 1556 sampled values / loss_divisor (4 = num_hands^2, the parent project's normalisation;
  *                  1 = plain sum); <= 0 = default.
+ *   swap_xz        axis order of the grid as grid_sample sees it: 0 = phi[z][y][x] (a query's (x, y, z) addresses the voxel whose
+ *                  centre is (x, y, z)); 1 = the grid was stored phi[x][y][z] and sampled unchanged, i.e. a query's x addresses the
+ *                  field's z axis and its z the x axis.
  * (The position of the voxel centres -- cell-centred, p = -1 + (2i+1)/32 -- is NOT switchable: the exact inside / outside
  * arithmetic of the ray test is derived for it.) */
-typedef struct ihmr_sdf_options { int align_corners; float loss_divisor; } ihmr_sdf_options;
+typedef struct ihmr_sdf_options { int align_corners; float loss_divisor; int swap_xz; } ihmr_sdf_options;
 int ihmr_sdf_collision_ex(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
                           float robustifier, const ihmr_sdf_options* options, float* loss, float* per_vert, float* origin_scale,
                           float* dval, void* workspace, void* stream);
@@ -135,9 +138,15 @@ typedef struct ihmr_opt_io {
     /* conventions of the collision module (ihmr_sdf_options above): 0 / 0 = defaults */
     int sdf_align_corners;
     float sdf_loss_divisor;
+    int sdf_swap_xz;
     /* 1 = every iteration searches all 1538 triangles per voxel (the per-voxel candidate lists that ihmr_opt_run_stage carries from
        iteration to iteration are an exact acceleration; this switch exists to test exactly that) */
     int sdf_no_candidate_lists;
+    /* 1 = a hand whose vertices cannot change during a stage (the right hand of a stage that refines only the translation) is
+       re-evaluated from scratch every iteration instead of keeping what the stage's earlier iterations found out about its voxels
+       (an exact acceleration as well: the same vertices give the same grid; this switch exists to test that).  Implied by
+       sdf_no_candidate_lists. */
+    int sdf_no_static_reuse;
     int no_fused_tail;          /* 1: every stage runs sampling + losses, the per-hand LBS backward, the optimizer step + skeletons and
                                  * (translation / orientation stages) the skinning of the stored v_posed as separate launches -- the
                                  * checker of the fused tail launch; results are identical either way (tests/test_gpu_parity.py) */

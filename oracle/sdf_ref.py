@@ -88,11 +88,13 @@ def hand_boxes(hand_verts: torch.Tensor, scale_factor: float = SCALE_FACTOR):
 
 
 class SDFLossRef(nn.Module):
-    def __init__(self, faces_right, faces_left, robustifier=None, grid_size=GRID, align_corners=False, loss_divisor=float(NUM_HANDS ** 2)):
+    def __init__(self, faces_right, faces_left, robustifier=None, grid_size=GRID, align_corners=False, loss_divisor=float(NUM_HANDS ** 2),
+                 swap_xz=False):
         """``align_corners`` / ``loss_divisor``: the conventions nothing in the reference pins (defaults: torch 1.6.0's
-        grid_sample default; the parent project's ``/ valid_people ** 2``); switchable to mirror ``ihmr_sdf_options``."""
+        grid_sample default; the parent project's ``/ valid_people ** 2``); ``swap_xz``: the grid tensor handed to grid_sample is
+        phi[x][y][z] instead of phi[z][y][x], i.e. a query's x addresses the field's z axis; switchable to mirror ``ihmr_sdf_options``."""
         super().__init__()
-        self.align_corners, self.loss_divisor = bool(align_corners), float(loss_divisor)
+        self.align_corners, self.loss_divisor, self.swap_xz = bool(align_corners), float(loss_divisor), bool(swap_xz)
         self.register_buffer("faces_right", torch.tensor(np.asarray(faces_right).astype(np.int32)))
         self.register_buffer("faces_left", torch.tensor(np.asarray(faces_left).astype(np.int32)))
         self.grid_size = grid_size
@@ -110,6 +112,8 @@ class SDFLossRef(nn.Module):
         per_vert, origin = [], []
         for h in (0, 1):
             q = (hand_verts[:, 1 - h] - centre[:, h]) / scale[:, h]  # (B,778,3)
+            if self.swap_xz:
+                q = q.flip(-1)
             val = F.grid_sample(phi[h][:, None].to(hand_verts.dtype), q.view(B, -1, 1, 1, 3), mode="bilinear",
                                 padding_mode="zeros", align_corners=self.align_corners).view(B, -1)
             if self.robustifier:

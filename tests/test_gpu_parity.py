@@ -886,11 +886,13 @@ def test_opt_batch512_matches_oracle_and_is_permutation_equivariant(mano_arrays)
 
 
 # ----------------------------------------------------------------------------------- seam B conventions (ihmr_sdf_options)
-@pytest.mark.parametrize("align_corners,loss_divisor", [(False, 4.0), (True, 4.0), (False, 1.0), (True, 1.0)])
-def test_sdf_convention_switches_match_oracle(mano_arrays, align_corners, loss_divisor):
-    """The two conventions of the absent upstream collision module that nothing in the reference pins -- grid_sample's
-    `align_corners` and the normalisation of the per-sample loss -- are explicit parameters on both sides (oracle:
-    SDFLossRef(align_corners=, loss_divisor=); product: SDFLoss(...) -> ihmr_sdf_collision_ex, and opt.sdf_* ->
+@pytest.mark.parametrize("align_corners,loss_divisor,swap_xz", [(False, 4.0, False), (True, 4.0, False), (False, 1.0, False), (True, 1.0, False),
+                                                                (False, 4.0, True), (True, 1.0, True)])
+def test_sdf_convention_switches_match_oracle(mano_arrays, align_corners, loss_divisor, swap_xz):
+    """The three conventions of the absent upstream collision module that nothing in the reference pins -- grid_sample's
+    `align_corners`, the normalisation of the per-sample loss and the axis order of the grid as grid_sample sees it (`swap_xz`) --
+    are explicit parameters on both sides (oracle:
+    SDFLossRef(align_corners=, loss_divisor=, swap_xz=); product: SDFLoss(...) -> ihmr_sdf_collision_ex, and opt.sdf_* ->
     ihmr_opt_io for the fused loop); every combination is compared: values, loss and gradient through seam B, and the
     fused loop's collision term + one Adam step of every stage."""
     import functools
@@ -902,26 +904,26 @@ def test_sdf_convention_switches_match_oracle(mano_arrays, align_corners, loss_d
     right, left = mano_arrays
     B = 4
     hv, batch = _two_hand_verts(mano_arrays, B, 5)
-    ref_mod = SDFLossRef(right["faces"], left["faces"], align_corners=align_corners, loss_divisor=loss_divisor)
+    ref_mod = SDFLossRef(right["faces"], left["faces"], align_corners=align_corners, loss_divisor=loss_divisor, swap_xz=swap_xz)
     hv_ref = hv.clone().requires_grad_(True)
     l_ref, pv_ref, os_ref = ref_mod(hv_ref, return_per_vert_loss=True, return_origin_scale_loss=True)
     w = torch.linspace(0.5, 1.5, B)
     (l_ref * w).sum().backward()
-    mod = SDFLoss(right["faces"], left["faces"], align_corners=align_corners, loss_divisor=loss_divisor).to(_dev())
+    mod = SDFLoss(right["faces"], left["faces"], align_corners=align_corners, loss_divisor=loss_divisor, swap_xz=swap_xz).to(_dev())
     hv_g = hv.clone().to(_dev()).requires_grad_(True)
     l, pv, os_ = mod(hv_g, return_per_vert_loss=True, return_origin_scale_loss=True)
     (l * w.to(_dev())).sum().backward()
-    assert int((pv_ref > 0).sum()) > 50
+    assert int((pv_ref > 0).sum()) > (10 if swap_xz else 50)
     _report("conv per_vert", pv.detach().cpu(), pv_ref.detach(), atol=1e-6)
     _report("conv origin_scale [m]", os_.detach().cpu(), os_ref.detach(), atol=1e-7)
     _report("conv loss", l.detach().cpu(), l_ref.detach(), atol=1e-5, rtol=1e-6)
     _report("conv d/dverts", hv_g.grad.cpu(), hv_ref.grad, atol=1e-4 * float(hv_ref.grad.abs().max()))
     # fused loop
     opt = _make_opt(B, epoch=1, save_mid_freq=1)
-    opt.sdf_align_corners, opt.sdf_loss_divisor = align_corners, loss_divisor
+    opt.sdf_align_corners, opt.sdf_loss_divisor, opt.sdf_swap_xz = align_corners, loss_divisor, swap_xz
     model = OptimizeModel(opt)
     orc = OptimizeRef(right, left, B, make_opt_strategy(1), save_mid_freq=1,
-                      sdf_loss_cls=functools.partial(SDFLossRef, align_corners=align_corners, loss_divisor=loss_divisor))
+                      sdf_loss_cls=functools.partial(SDFLossRef, align_corners=align_corners, loss_divisor=loss_divisor, swap_xz=swap_xz))
     orc.set_input(batch); orc.init_optimize(); orc.optimize()
     model.set_input(batch); model.init_optimize(); model.optimize()
     torch.cuda.synchronize()
@@ -959,6 +961,44 @@ def test_candidate_lists_do_not_change_a_bit(mano_arrays, B, epoch):
     for k in ("pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "pred_left_hand_verts",
               "pred_joints_3d", "collision_loss", "collision_loss_origin_scale"):
         assert np.array_equal(a[k], b[k]), f"{k}: the candidate lists changed the result"
+    assert float(a["collision_loss_origin_scale"].max()) > 0
+
+
+@pytest.mark.parametrize("B,epoch", [(16, 39), (64, 14)])
+def test_static_hand_reuse_does_not_change_a_bit(mano_arrays, B, epoch):
+    """A hand whose vertices cannot change during a stage keeps, from the stage's second iteration on, its box, normalised vertices
+    and triangle records, and what earlier iterations found out about its voxels (inside / outside, distance): only voxels that the
+    other hand reaches for the first time are tested and searched.  The same vertices give the same grid, so `opt.sdf_no_static_reuse`
+    (everything from scratch every iteration) must agree bit for bit.  Stages: opt_default (translation stage: the right hands are
+    static) + three that opt_default never runs -- right orientation alone (the left hands are static), left finger pose alone
+    (the right hands are static while the other side rebuilds its candidate lists), camera + translation (right static, camera
+    gradient on) -- regular and ragged batch, graphs replayed twice over stale state."""
+    from helpers import ragged_opt_batch
+    from ihmr_amd.optimize_model import OptimizeModel
+    from ihmr_amd.strategies import make_opt_strategy
+    _, batch = _two_hand_verts(mano_arrays, B, 3100 + B)
+    if B == 16:
+        batch = ragged_opt_batch(batch)
+    base = make_opt_strategy(epoch)
+    extra = []
+    for params, like in ((["pred_right_orient"], 1), (["pred_left_pose_params"], 2), (["pred_cam_params", "pred_hand_trans"], 0)):
+        st = dict(base[like]); st["update_params"] = params
+        extra.append(st)
+    outs = []
+    for off in (False, True):
+        opt = _make_opt(B, epoch=epoch, save_mid_freq=5)
+        opt.sdf_no_static_reuse = off
+        m = OptimizeModel(opt)
+        m.strategy = base + extra
+        for rep in range(2):
+            m.set_input(batch); m.init_optimize(); m.optimize()
+            torch.cuda.synchronize()
+        outs.append((m.get_pred_result(), torch.stack(m.selected_history).cpu().numpy(), m.buf["snap_loss"].cpu().numpy(), m.buf["adam_m"].cpu().numpy()))
+    (a, sa, la, ma), (b, sb, lb, mb) = outs
+    assert np.array_equal(sa, sb) and np.array_equal(la, lb) and np.array_equal(ma, mb)
+    for k in ("pred_cam_params", "pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "pred_left_hand_verts",
+              "pred_joints_3d", "collision_loss", "collision_loss_origin_scale"):
+        assert np.array_equal(a[k], b[k]), f"{k}: the static-hand reuse changed the result"
     assert float(a["collision_loss_origin_scale"].max()) > 0
 
 
@@ -1020,25 +1060,33 @@ def test_lbs_bwd2_forms_are_bit_identical(mano_arrays):
 
 
 def test_candidate_lists_are_used_and_accounted_for(mano_arrays):
-    """The work counters of the fused loop: inside a stage most inside voxels are answered from their candidate lists, every inside
-    voxel is evaluated exactly once per iteration (list search + full search = inside voxels), the list search tests far fewer
-    spheres than the 1538 of a full search, and with the lists switched off nothing goes through them."""
+    """The work counters of the fused loop (`inside_voxels` = the voxels handed to the distance kernel): inside a stage most of them are
+    answered from their candidate lists, every one is evaluated exactly once per iteration (list search + full search), the list search
+    tests far fewer spheres than the 1538 of a full search; with the lists switched off nothing goes through them; and in the
+    translation stage the static right hands hand over only voxels that are new (far fewer evaluations than with `sdf_no_static_reuse`)."""
     from ihmr_amd.optimize_model import OptimizeModel
     B = 16
     _, batch = _two_hand_verts(mano_arrays, B, 77)
-    for off in (False, True):
+    evaluated = {}
+    for mode in ("default", "no_static_reuse", "no_lists"):
         opt = _make_opt(B, epoch=19, save_mid_freq=5)
-        opt.sdf_no_candidate_lists = off
+        opt.sdf_no_candidate_lists = mode == "no_lists"
+        opt.sdf_no_static_reuse = mode == "no_static_reuse"
         m = OptimizeModel(opt)
         m.set_input(batch); m.init_optimize()
         m.sdf_counters_start()
         m.run_stage(m.strategy[0])
         c = m.sdf_counters_stop()
+        evaluated[mode] = c["inside_voxels"]
         assert c["inside_voxels"] > 0
-        if off:
+        assert c["voxels_from_lists"] + c["voxels_full_search"] == c["inside_voxels"]
+        if mode == "no_lists":
             assert c["voxels_from_lists"] == 0 and c["voxels_without_list"] == 0 and c["voxels_rebuilt"] == 0
             assert c["sphere_tests"] == 1538 * c["inside_voxels"]
         else:
-            assert c["voxels_from_lists"] + c["voxels_without_list"] + c["voxels_rebuilt"] == c["inside_voxels"]
             assert c["voxels_from_lists"] > c["inside_voxels"] // 2
             assert c["sphere_tests"] < 1538 * c["inside_voxels"] // 2
+        if mode == "no_static_reuse":
+            assert c["voxels_from_lists"] + c["voxels_without_list"] + c["voxels_rebuilt"] == c["inside_voxels"]
+    assert evaluated["no_static_reuse"] == evaluated["no_lists"]
+    assert evaluated["default"] < 0.75 * evaluated["no_static_reuse"], evaluated

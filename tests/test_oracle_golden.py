@@ -611,3 +611,15 @@ def test_sdf_oracle_convention_switches(mano_arrays):
     close(b[0], 4.0 * a[0], 1e-6, what="divisor")
     close(b[1], a[1], 0, what="per-vertex values do not depend on the divisor")
     assert float((c[1] - a[1]).abs().max()) > 1e-4, "align_corners must change the sampled values"
+    # swap_xz: the query's x and z exchange roles -- the same as sampling the default module at queries mirrored in their own normalised
+    # frame; checked against a direct statement: phi transposed in (x, z) and sampled with the default order gives the same values
+    import torch.nn.functional as F
+    d = sdf_ref.SDFLossRef(right["faces"], left["faces"], swap_xz=True)(hv, return_per_vert_loss=True, return_origin_scale_loss=True)
+    centre, scale = sdf_ref.hand_boxes(hv, sdf_ref.SCALE_FACTOR)
+    vn = (hv - centre) / scale
+    phi_r = sdf_ref.sdf_grid(vn[:, 0].contiguous(), torch.tensor(right["faces"].astype(np.int32)), 32)        # [z][y][x]
+    q = (hv[:, 1] - centre[:, 0]) / scale[:, 0]
+    direct = F.grid_sample(phi_r.permute(0, 3, 2, 1)[:, None].contiguous(), q.view(1, -1, 1, 1, 3), mode="bilinear", padding_mode="zeros",
+                           align_corners=False).view(1, -1)
+    close(d[1][:, :778], direct, 1e-7, what="swap_xz = the [x][y][z] tensor sampled as it is")
+    assert float((d[1] - a[1]).abs().max()) > 1e-4
