@@ -12,6 +12,7 @@
 #include "mano_lbs.h"
 #include "sdf_collision.h"
 #include "preprocess.h"
+#include "mlp_infer.h"
 #include "refine.h"
 #include "encoder.h"
 #include "evaluate.h"
@@ -418,7 +419,7 @@ static SdfWorkspace opt_sdf_ws(const ihmr_opt_io* io, const OptWork& wk, int B, 
 // head = the Adam + skeleton launch, skin = the skinning launch, tail = the sampling + loss launch (a caller that fuses them into other launches skips them)
 static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, const OptWork& wk, int B,
                        const ihmr_opt_weights& w, const ParamStep& prev, hipStream_t st, int need_cam = 0, int skin_mode = LBS_SKIN_FULL,
-                       int lists = 0, bool head = true, bool tail = true, int static_mask = 0) {
+                       int lists = 0, bool head = true, bool tail = true, int static_mask = 0, const MlpSelect* sel = nullptr) {
     if (head)
         hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, prev, sdf_carve(wk.sdf_ws, 2 * B, true).inside_count);
     // (skin_mode < 0: the tail launch of the previous iteration has skinned the stored v_posed with the new skeletons, opt_tail_kernel<true, true>)
@@ -429,7 +430,9 @@ static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
                         nullptr, nullptr, nullptr, nullptr, false, st);
     if (rc) return rc;
     // collision sampling (loss_batch[2], masked by hand type; gradient -> g_verts) and the joint losses in one launch
-    if (tail) hipLaunchKernelGGL(opt_sample_loss_kernel, dim3(B), dim3(SDF_SAMPLE_THREADS), 0, st, *io, wk, B, w, vl, ws, need_cam);
+    MlpSelect no_sel;
+    memset(&no_sel, 0, sizeof(no_sel));
+    if (tail) hipLaunchKernelGGL(opt_sample_loss_kernel, dim3(B), dim3(SDF_SAMPLE_THREADS), 0, st, *io, wk, B, w, vl, ws, need_cam, sel ? *sel : no_sel);
     return (int)hipGetLastError();
 }
 
@@ -521,6 +524,81 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
 extern "C" int ihmr_opt_set_params(const ihmr_opt_io* io, const float* final_params, int B, void* stream) {
     if (!io || !final_params || B <= 0) return -1;
     hipLaunchKernelGGL(opt_unpack_params_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, *io, final_params, B);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ IHMR-MLP inference glue (mlp_infer.h)
+extern "C" size_t ihmr_mlp_workspace_bytes(int B) { return ((size_t)B * (512 + 256 + 128) * sizeof(float) + 256 + 255) & ~(size_t)255; }
+
+static int mlp_fill_select(MlpSelect& s, const ihmr_mlp_tables* t, const ihmr_mlp_stage* stage, int mode, void* workspace) {
+    memset(&s, 0, sizeof(s));
+    s.mode = mode;
+    if (mode == 2) {
+        if (!stage || stage->n_filter < 0 || stage->n_filter > 4 || stage->select_loss < 0 || stage->select_loss > 2) return -1;
+        s.n_filter = stage->n_filter;
+        for (int f = 0; f < stage->n_filter; ++f) {
+            if (stage->filter_loss[f] < 0 || stage->filter_loss[f] > 2) return -1;
+            s.filter_loss[f] = stage->filter_loss[f];
+            s.filter_factor[f] = stage->filter_factor[f];
+        }
+        s.select_loss = stage->select_loss;
+    }
+    s.idx = (const long long*)t->idx; s.new_params = t->new_params; s.img_feat = t->img_feat;
+    s.data_idxs_all = t->data_idxs_all; s.img_feat_all = t->img_feat_all; s.prev_final = t->prev_final; s.prev_loss = t->prev_loss;
+    s.final_out = t->final_params; s.kept = t->kept;
+    s.barrier = (unsigned*)workspace;
+    return 0;
+}
+
+extern "C" int ihmr_mlp_stage_head(const ihmr_mlp_net* net, const ihmr_mlp_tables* t, const ihmr_opt_io* io, int B, void* workspace,
+                                   void* stream) {
+    if (!net || !t || !io || !workspace || B <= 0 || net->k_out <= 0 || net->k_out > 122) return -1;
+    MlpHeadArgs a;
+    memset(&a, 0, sizeof(a));
+    a.idx = (const long long*)t->idx; a.feat_all = t->img_feat_all; a.prev_final = t->prev_final;
+    for (int l = 0; l < 4; ++l) { a.w[l] = net->w[l]; a.b[l] = net->b[l]; a.ldw[l] = net->ldw[l]; if (!a.w[l] || !a.b[l]) return -1; }
+    if (a.ldw[0] < 512 || a.ldw[1] < 256 || a.ldw[2] < 128 || a.ldw[3] < ((net->k_out + 15) & ~15)) return -1;
+    a.kout = net->k_out;
+    for (int j = 0; j < net->k_out; ++j) {
+        if (net->col[j] < 0 || net->col[j] >= 122) return -1;
+        a.col[j] = (unsigned char)net->col[j];
+    }
+    a.barrier = (unsigned*)workspace;
+    float* h = (float*)((char*)workspace + 256);
+    a.h[0] = h; a.h[1] = h + (size_t)B * 512; a.h[2] = a.h[1] + (size_t)B * 256;
+    a.new_params = t->new_params;
+    a.B = B;
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    // one workgroup per CU at most (all of them resident: the kernel synchronises its layers with a grid-wide barrier)
+    const int tiles = ((B + 15) / 16) * 32;
+    const int grid = std::max(1, std::min(std::min(tiles, cus > 0 ? cus : 64), MLPI_MAX_WG));
+    hipLaunchKernelGGL(mlp_head_kernel, dim3(grid), dim3(MLPI_THREADS), 0, (hipStream_t)stream, a, *io);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_mlp_forward_select(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, const ihmr_opt_weights* w,
+                                       const ihmr_mlp_tables* t, const ihmr_mlp_stage* stage, int mode, void* workspace, void* stream) {
+    if (!m || !io || !w || !workspace || B <= 0 || mode < 0 || mode > 2 || (mode && !t)) return -1;
+    MlpSelect sel;
+    memset(&sel, 0, sizeof(sel));
+    if (mode) { if (int rc = mlp_fill_select(sel, t, stage, mode, workspace)) return rc; }
+    OptWork wk = opt_carve(io->workspace, B);
+    // The evaluations of one test() call move the hands by a stage's residual at a time: the collision kernels keep their per-voxel
+    // candidate lists from one evaluation to the next (valid while a hand stays within the slack of the pose its lists were built at,
+    // checked per hand and evaluation; rebuilt otherwise) -- started over by the evaluation that opens the batch.  No static-hand
+    // reuse here: a rejected update falls back to parameters the vertex buffers no longer hold.
+    return opt_forward(m, m_left, io, wk, B, *w, kNoStep, (hipStream_t)stream, 0, LBS_SKIN_FULL, mode == 1 ? 2 : 1, true, true, 0, mode ? &sel : nullptr);
+}
+
+// skeletons + skinning of the parameters in `io` only (no collision term, no losses): the annotation's meshes of the export
+extern "C" int ihmr_opt_forward_verts(const ihmr_mano* m, const ihmr_opt_io* io, int B, void* stream) {
+    if (!m || !io || B <= 0) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    OptWork wk = opt_carve(io->workspace, B);
+    hipLaunchKernelGGL(opt_adam_skel_kernel, dim3(B), dim3(384), 0, st, *m, *io, wk, B, kNoStep, sdf_carve(wk.sdf_ws, 2 * B, true).inside_count);
+    lbs_skin_launch<true>(m, LBS_SKIN_FULL, 2 * B, B, io->verts, wk.joints_raw, wk.lbs, st);
     return (int)hipGetLastError();
 }
 

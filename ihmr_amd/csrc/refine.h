@@ -274,7 +274,7 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
 // evaluates the joint losses and their gradient (-> g_joints); the two halves share nothing but the launch.
 #define OPT_SAMPLE_WORKERS (SDF_SAMPLE_THREADS - WAVE)
 __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void opt_sample_loss_kernel(ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,
-                                                                             VertLayout vl, SdfWorkspace ws, int need_cam) {
+                                                                             VertLayout vl, SdfWorkspace ws, int need_cam, MlpSelect sel) {
     __shared__ LossShared sh;
     __shared__ float red16[SDF_SAMPLE_THREADS / WAVE];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -284,6 +284,8 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void opt_sample_loss_kernel(ihm
     const float gs = w.collision * mask / (ws.loss_div * (float)(io.norm_batch > 0 ? io.norm_batch : B));
     sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, io.coll_per_vert, io.coll_origin_scale, nullptr, wk.g_verts, B, gs,
                      io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
+    // IHMR-MLP: keep / reject the stage's update of this sample and store it to the "prev" tables (mlp_infer.h)
+    if (sel.mode) mlp_select_sample(sel, io.loss_batch, B, b);
 }
 
 // One optimizer step of parameter slot e (< 122) of sample b: adds the direct (non-MANO) gradient terms, takes the

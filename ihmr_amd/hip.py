@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "ihmr_avgpool_relu", "ihmr_preprocess_images", "ihmr_mlp_train_grad", "ihmr_transpose", "ihmr_relu_backward", "ihmr_colsum",
     "ihmr_adam_step", "ihmr_bn_workspace_bytes", "ihmr_bn_train_forward", "ihmr_bn_train_backward", "ihmr_conv_wgrad",
     "ihmr_dilate2", "ihmr_interleave2", "ihmr_pack_dgrad_weight", "ihmr_maxpool3x3s2_backward", "ihmr_avgpool_relu_backward", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer",
+    "ihmr_mlp_workspace_bytes", "ihmr_mlp_stage_head", "ihmr_mlp_forward_select", "ihmr_opt_forward_verts",
     "ihmr_debug_force_lbs_bwd2_streaming", "ihmr_version",
 ]
 
@@ -70,6 +71,22 @@ class OptStage(C.Structure):
 
 class OptWeights(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("joints_2d", "joints_3d", "trans", "shape_reg", "collision", "finger_reg")]
+
+
+class MlpNet(C.Structure):
+    """``ihmr_mlp_net``: one IHMR-MLP sub-network -- packed weights / biases of its four Linear layers, output -> column map."""
+    _fields_ = [("w", C.c_void_p * 4), ("b", C.c_void_p * 4), ("ldw", C.c_int * 4), ("k_out", C.c_int), ("col", C.c_int * 122)]
+
+
+class MlpTables(C.Structure):
+    """``ihmr_mlp_tables``: the "prev" tables of MLPModel (mlp_model.py:297-356) + the batch's working rows."""
+    _fields_ = [(n, C.c_void_p) for n in ("idx", "data_idxs_all", "img_feat_all", "prev_final", "prev_loss", "img_feat", "new_params",
+                                          "final_params", "kept")]
+
+
+class MlpStage(C.Structure):
+    """``ihmr_mlp_stage``: filter / select criteria of one stage (select_better_params, mlp_model.py:592-637)."""
+    _fields_ = [("n_filter", C.c_int), ("filter_loss", C.c_int * 4), ("filter_factor", C.c_float * 4), ("select_loss", C.c_int)]
 
 
 class TrainWeights(C.Structure):
@@ -209,6 +226,11 @@ def lib():
         L.ihmr_opt_forward_graph_create.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(vp)]
         L.ihmr_graph_launch.argtypes = [vp, vp]
         L.ihmr_opt_set_params.argtypes = [C.POINTER(OptIO), vp, i, vp]
+        L.ihmr_mlp_workspace_bytes.argtypes = [i]
+        L.ihmr_mlp_workspace_bytes.restype = C.c_size_t
+        L.ihmr_mlp_stage_head.argtypes = [C.POINTER(MlpNet), C.POINTER(MlpTables), C.POINTER(OptIO), i, vp, vp]
+        L.ihmr_mlp_forward_select.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(MlpTables), C.POINTER(MlpStage), i, vp, vp]
+        L.ihmr_opt_forward_verts.argtypes = [vp, C.POINTER(OptIO), i, vp]
         L.ihmr_eval_metrics.argtypes = [vp, vp, vp, vp, vp, i, vp, vp]
         L.ihmr_eval_mpvpe.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, vp]
         L.ihmr_graph_destroy.argtypes = [vp]

@@ -57,7 +57,7 @@ class MLPModel(MLPTrainMixin):
         # passes, the per-sample selects, the "prev" table scatters) are captured at the first call and replayed afterwards; the
         # inputs live in static device buffers that set_input() refills.  Eager whenever sub-networks are being trained here.
         self.use_test_graph = bool(getattr(opt, "use_test_graph", True))
-        self._in, self._test_graph, self._graph_sig = {}, None, None
+        self._in, self._test_graph, self._graph_sig, self._init_packed, self._gt_packed, self._glue_cache = {}, None, None, None, None, None
 
     def _static(self, name, value, dtype=torch.float32):
         """The persistent device buffer of input `name`, refilled in place (graph replays read the same addresses)."""
@@ -125,6 +125,14 @@ class MLPModel(MLPTrainMixin):
         c["init_hand_trans_j"].zero_()
         self.init_cam, self.init_pose_params = g("init_cam"), g("init_pose_params")
         self.init_shape_params, self.init_hand_trans = g("init_shape_params"), g("init_hand_trans").reshape(B, 3)
+        # packed 122-vectors of the backbone's prediction (mlp_model.py:204-216 order) and of the annotation, for the device-side glue
+        if getattr(self, "_init_packed", None) is None:
+            self._init_packed, self._gt_packed = torch.zeros(B, 122, device=self.device), torch.zeros(B, 122, device=self.device)
+            self._test_graph = None
+        ip, gp = self._init_packed, self._gt_packed
+        ip[:, 0:3].copy_(self.init_cam); ip[:, 3:99].copy_(self.init_pose_params)
+        ip[:, 99:119].copy_(self.init_shape_params); ip[:, 119:122].copy_(self.init_hand_trans)
+        gp[:, 3:99].copy_(self.gt_pose_params); gp[:, 99:119].copy_(self.gt_shape_params); gp[:, 119:122].copy_(self.hand_trans[:, 0, :3])
 
     # reference-named views of the packed state (mlp_model.py:426-439)
     @property
@@ -134,7 +142,8 @@ class MLPModel(MLPTrainMixin):
 
     def _forward_mano_and_losses(self, final):
         """__forward_mano + the selection-relevant part of compute_loss for the packed state `final` (B,122): one
-        scatter kernel + one captured launch of the fused kernels; returns the three per-sample losses (B,3)."""
+        scatter kernel + one captured launch of the fused kernels; returns the three per-sample losses (B,3).  (Training path and
+        diagnostics; test() goes through the device-side glue below.)"""
         hip.check(hip.lib().ihmr_opt_set_params(C.byref(self._core.io), final.data_ptr(), self.batch_size, hip.stream_ptr()),
                   "ihmr_opt_set_params")
         self._core.forward_losses(self._w)
@@ -147,9 +156,57 @@ class MLPModel(MLPTrainMixin):
         self.prev_final[idx] = final
         self.prev_loss[idx] = loss
 
+    # ---- device-side glue of test(): everything between two fused forward passes is ONE launch (csrc/mlp_infer.h)
+    def _glue(self):
+        """Static buffers and the ctypes descriptors of the stage launches (built once per capture of test(): they hold the
+        addresses of the "prev" tables, the sub-networks' packed weights and the strategy's criteria)."""
+        sig = self._test_signature()
+        g = getattr(self, "_glue_cache", None)
+        if g is not None and g["sig"] == sig:
+            return g
+        B, dev, L = self.batch_size, self.device, hip.lib()
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+        g = dict(sig=sig, new=z(B, 122), final=z(B, 122), kept=z(len(self.strategy), B, dt=torch.uint8), kept0=z(B, dt=torch.uint8),
+                 ws=z(L.ihmr_mlp_workspace_bytes(B), dt=torch.uint8), nets=[], stages=[], tables=[])
+        # the annotation's meshes: a second parameter set skinned by the same kernels into its own vertex buffer
+        gtb = dict(cam=z(B, 3), trans=z(B, 3), orient=z(2, B, 3), pose=z(2, B, 45), shape=z(2, B, 10), verts=z(2, B, 778, 3))
+        io = hip.OptIO.from_buffer_copy(self._core.io)
+        for k, v in gtb.items():
+            setattr(io, k, v.data_ptr())
+        g["gt_buf"], g["gt_io"] = gtb, io
+        tab = lambda new, kept: hip.MlpTables(
+            idx=self.data_idxs.data_ptr(), data_idxs_all=self.data_idxs_all.data_ptr(), img_feat_all=self.img_feat_all.data_ptr(),
+            prev_final=self.prev_final.data_ptr(), prev_loss=self.prev_loss.data_ptr(), img_feat=self.img_feat.data_ptr(),
+            new_params=new.data_ptr(), final_params=g["final"].data_ptr(), kept=kept.data_ptr())
+        g["first"] = tab(self._init_packed, g["kept0"])
+        for sid, stage in enumerate(self.strategy):
+            pk = self.sub_network_list[sid].packed(dev)
+            net = hip.MlpNet()
+            for l in range(4):
+                net.w[l], net.b[l], net.ldw[l] = pk[l].w.data_ptr(), pk[l].b.data_ptr(), pk[l].ldw
+            cols = [c for n in stage["update_params"] for c in range(COLS[n].start, COLS[n].stop)]     # mlp_model.py:459-472 order
+            net.k_out = len(cols)
+            for j, c in enumerate(cols):
+                net.col[j] = c
+            st = hip.MlpStage(n_filter=len(stage["filter_loss"]), select_loss=LOSS_SLOT[stage["select_loss"]])
+            for f, (name, pct) in enumerate(stage["filter_loss"]):
+                st.filter_loss[f] = LOSS_SLOT[name]
+                st.filter_factor[f] = float(np.float32(1 + float(pct) / 100))        # torch multiplies the float32 loss by this scalar
+            g["nets"].append(net); g["stages"].append(st); g["tables"].append(tab(g["new"], g["kept"][sid]))
+            g.setdefault("keep", []).append(pk)
+        self._glue_cache = g
+        return g
+
+    @property
+    def kept_history(self):
+        """Per stage, which samples kept the stage's update (select_better_params' decisions)."""
+        return [k.bool() for k in self._glue_cache["kept"]] if getattr(self, "_glue_cache", None) is not None else []
+
     # mlp_model.py:683-699
     @torch.no_grad()
     def test(self):
+        for tr in self.trainers.values():             # weights trained in this process: refresh the modules' copies
+            tr.sync_to_module()
         if not self.use_test_graph or self.trainers:
             return self._test_eager()
         sig = self._test_signature()
@@ -167,54 +224,44 @@ class MLPModel(MLPTrainMixin):
         self._test_graph.replay()
 
     def _test_signature(self):
-        """Everything a captured test() has baked in: the sub-networks, the addresses of the four "prev" tables, the strategy's
-        contents (update columns, filter percentages, select losses) and the loss weights."""
+        """Everything a captured test() has baked in: the sub-networks (and their packed weights), the addresses of the four "prev"
+        tables, the strategy's contents (update columns, filter percentages, select losses) and the loss weights."""
         strat = tuple((tuple(st["update_params"]), tuple((n, str(p)) for n, p in st["filter_loss"]), st["select_loss"]) for st in self.strategy)
         tables = tuple(t.data_ptr() for t in (self.data_idxs_all, self.img_feat_all, self.prev_final, self.prev_loss))
-        return (strat, tables, tuple(sorted(self._w.items())), tuple(id(n) for n in self.sub_network_list))
+        nets = tuple((id(n), tuple(p.w.data_ptr() for p in n.packed(self.device))) for n in self.sub_network_list)
+        inputs = tuple(t.data_ptr() for t in (self.data_idxs, self.img_feat, self._init_packed, self._gt_packed))
+        return (strat, tables, tuple(sorted(self._w.items())), nets, inputs)
 
     def _test_eager(self):
-        # mlp_model.py:204-216: [cam | pose 96 | shape 20 | trans] in the reference's order
-        final = torch.cat([self.init_cam, self.init_pose_params, self.init_shape_params, self.init_hand_trans], dim=1).contiguous()
-        for tr in self.trainers.values():             # weights trained in this process: refresh the modules' copies
-            tr.sync_to_module()
-        loss = self._forward_mano_and_losses(final)
-        self._save_prev(final, loss)
-        self.kept_history = []
-        idx = self.data_idxs
-        for sid, stage in enumerate(self.strategy):
-            feat, prev, prev_loss = self.img_feat_all[idx], self.prev_final[idx], self.prev_loss[idx]
-            res = self.sub_network_list[sid](torch.cat([feat, prev], dim=1))
-            new = prev.clone()
-            o = 0
-            for n in stage["update_params"]:           # mlp_model.py:459-472
-                new[:, COLS[n]] += res[:, o:o + PARAM_DIMS[n]]
-                o += PARAM_DIMS[n]
-            new_loss = self._forward_mano_and_losses(new)
-            # select_better_params (mlp_model.py:592-637): keep the update of a sample only if every filter loss got
-            # strictly better than prev * (1 + pct/100) and the select loss did not get worse
-            ok = torch.ones(self.batch_size, dtype=torch.bool, device=self.device)
-            for name, pct in stage["filter_loss"]:
-                c = LOSS_SLOT[name]
-                ok &= new_loss[:, c] < prev_loss[:, c] * (1 + float(pct) / 100)
-            c = LOSS_SLOT[stage["select_loss"]]
-            ok &= new_loss[:, c] <= prev_loss[:, c]
-            final = torch.where(ok[:, None], new, prev)     # rejected samples fall back to their previous parameters
-            loss = torch.where(ok[:, None], new_loss, prev_loss)
-            self.kept_history.append(ok)
-            self._save_prev(final, loss)
+        """test() as 50 kernel launches and nothing else: [unpack + forward/select] for the backbone's prediction, [sub-network head +
+        forward/select] per stage, [unpack + forward] of the final state, [unpack + skeleton + skinning] of the annotation."""
+        L, B, st = hip.lib(), self.batch_size, hip.stream_ptr()
+        g = self._glue()
+        core = self._core
+        from .optimize_model import _weights
+        io, w = C.byref(core.io), _weights(self._w)
+        mr, ml = core._mano_handles()
+        # mlp_model.py:204-216: [cam | pose 96 | shape 20 | trans] in the reference's order = self._init_packed (filled by set_input)
+        hip.check(L.ihmr_opt_set_params(io, self._init_packed.data_ptr(), B, st), "ihmr_opt_set_params")
+        hip.check(L.ihmr_mlp_forward_select(mr, ml, io, B, C.byref(w), C.byref(g["first"]), None, 1, g["ws"].data_ptr(), st), "ihmr_mlp_forward_select")
+        for sid in range(len(self.strategy)):
+            hip.check(L.ihmr_mlp_stage_head(C.byref(g["nets"][sid]), C.byref(g["tables"][sid]), io, B, g["ws"].data_ptr(), st), "ihmr_mlp_stage_head")
+            hip.check(L.ihmr_mlp_forward_select(mr, ml, io, B, C.byref(w), C.byref(g["tables"][sid]), C.byref(g["stages"][sid]), 2,
+                                                g["ws"].data_ptr(), st), "ihmr_mlp_forward_select")
+        final = g["final"]
+        hip.check(L.ihmr_opt_set_params(io, final.data_ptr(), B, st), "ihmr_opt_set_params")
+        hip.check(L.ihmr_mlp_forward_select(mr, ml, io, B, C.byref(w), None, None, 0, g["ws"].data_ptr(), st), "ihmr_mlp_forward_select")
         self.final_params = final
-        self.collision_loss_batch = self._forward_mano_and_losses(final)[:, 2].clone()
+        self.collision_loss_batch = core.buf["loss_batch"][2]
         for n, sl in COLS.items():
             setattr(self, n, final[:, sl])
-        c = self._core.buf
+        c = core.buf
         self.pred_right_hand_verts, self.pred_left_hand_verts = c["verts"][0], c["verts"][1]
         self.pred_joints_3d, self.collision_loss_origin_scale = c["joints_3d"], c["coll_origin_scale"]
-        # ground-truth meshes for the export (mlp_model.py:497-501) -- seam-A path
-        g = self.gt_pose_params
-        self.gt_right_hand_verts, self.gt_left_hand_verts, _ = two_hand.two_hand_forward(
-            self.mano_models["right"], g[:, :3], g[:, 48:51], g[:, 3:48], g[:, 51:], self.gt_shape_params[:, :10],
-            self.gt_shape_params[:, 10:], self.hand_trans[:, :, :3])
+        # ground-truth meshes for the export (mlp_model.py:497-501): the annotation's parameters through the same skeleton + skinning kernels
+        hip.check(L.ihmr_opt_set_params(C.byref(g["gt_io"]), self._gt_packed.data_ptr(), B, st), "ihmr_opt_set_params")
+        hip.check(L.ihmr_opt_forward_verts(mr, C.byref(g["gt_io"]), B, st), "ihmr_opt_forward_verts")
+        self.gt_right_hand_verts, self.gt_left_hand_verts = g["gt_buf"]["verts"][0], g["gt_buf"]["verts"][1]
 
     def _export_sources(self):
         # the reference root-aligns its GT joint buffer in place (no clone at mlp_model.py:530-531) and exports it

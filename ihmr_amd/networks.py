@@ -211,15 +211,20 @@ class InterHandSubNetwork(nn.Module):
         self._packed = None
         return super().load_state_dict(*a, **k)
 
-    @torch.no_grad()
-    def forward(self, inputs):
-        hip.require_gpu()
-        dev = inputs.device
+    def packed(self, dev):
+        """The four layers as K-major device weights (``_Packed``), built on first use and after every ``load_state_dict``."""
         if self._packed is None or self._packed[0].w.device != dev:
             kx = _ceil(self.input_dim, 16) - self.input_dim
             lins = [self.regressor[i] for i in (0, 2, 4, 6)]
             self._packed = [_Packed(l.weight.detach().to(dev)[:, :, None, None], l.bias.detach().to(dev), k_extra=(kx if i == 0 else 0))
                             for i, l in enumerate(lins)]
+        return self._packed
+
+    @torch.no_grad()
+    def forward(self, inputs):
+        hip.require_gpu()
+        dev = inputs.device
+        self.packed(dev)
         B = inputs.shape[0]
         Kp = self._packed[0].cin
         x = torch.zeros(B, Kp, device=dev)

@@ -362,6 +362,45 @@ typedef struct ihmr_kernel_timer { double ms[IHMR_TIMED_KERNELS]; long n[IHMR_TI
 int ihmr_set_kernel_timer(ihmr_kernel_timer* t);
 int ihmr_flush_kernel_timer(void);
 
+/* ------------------------------------------------------------------ IHMR-MLP inference glue (models/mlp_model.py)
+ * MLPModel.test() (:683-699) per stage: retrive_prev_prediction (:408-423) -> sub-network on [img_feat | final_params]
+ * (networks.py:83-105) -> __update_params_single (:459-472) -> forward + losses -> select_better_params (:592-637) ->
+ * save_pred_to_prev (:337-356).  Two entry points per stage replace the ~25 tensor operations the reference (and rounds 1-3 of
+ * this build) ran around the fused forward:
+ *   ihmr_mlp_stage_head      gathers the batch's rows of the "prev" tables by dataset index, runs the four Linear layers (exact
+ *                            fp32 on the matrix cores, ONE launch with grid-wide barriers between the layers), adds the residual to
+ *                            the stage's columns -> t->new_params (B,122), and scatters that vector into io's parameter buffers;
+ *   ihmr_mlp_forward_select  = ihmr_opt_forward_losses, whose last launch also decides per sample: keep the update iff every filter
+ *                            loss < prev * filter_factor (strictly) and the select loss <= prev; the kept / fallen-back row goes to
+ *                            t->final_params and, with its three losses, to the tables; t->kept (B) gets the decision (mode 2).
+ *                            mode 1: the evaluation of the backbone's prediction that opens test(): nothing to compare, everything
+ *                            saved (+ img_feat -> img_feat_all, data_idxs_all); mode 0: evaluate only (the final state).  The
+ *                            collision kernels carry their candidate lists from one call to the next (exact: checked per hand against
+ *                            the pose the lists were built at); mode 1 starts them over.
+ * Weights: K-major [Kpad][ldw] as ihmr_conv_igemm takes them (layer 0: Kpad = 1152 rows, zeros beyond 1146).  Loss indices: IHMR_LOSS_*
+ * (0 joints_2d_loss_p, 1 joints_3d_loss_p, 2 collision_loss).  workspace: ihmr_mlp_workspace_bytes(B), zero-initialised by the caller
+ * once (its first word is the layer barrier's counter; every forward_select resets it).  All pointers device pointers. */
+typedef struct ihmr_mlp_net { const float* w[4]; const float* b[4]; int ldw[4]; int k_out; int col[122]; } ihmr_mlp_net;
+typedef struct ihmr_mlp_tables {
+    const int64_t* idx;        /* (B) dataset index of every batch row */
+    uint8_t* data_idxs_all;    /* (num_data) */
+    float* img_feat_all;       /* (num_data,1024) */
+    float* prev_final;         /* (num_data,122) */
+    float* prev_loss;          /* (num_data,3) columns IHMR_LOSS_* */
+    const float* img_feat;     /* (B,1024) the batch's image features (first evaluation) */
+    float* new_params;         /* (B,122) the parameters the next forward evaluates */
+    float* final_params;       /* (B,122) the batch's state after the last decided stage */
+    uint8_t* kept;             /* (B) the last stage's decisions */
+} ihmr_mlp_tables;
+typedef struct ihmr_mlp_stage { int n_filter; int filter_loss[4]; float filter_factor[4]; int select_loss; } ihmr_mlp_stage;
+size_t ihmr_mlp_workspace_bytes(int B);
+int ihmr_mlp_stage_head(const ihmr_mlp_net* net, const ihmr_mlp_tables* t, const ihmr_opt_io* io, int B, void* workspace, void* stream);
+int ihmr_mlp_forward_select(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, const ihmr_opt_weights* w,
+                            const ihmr_mlp_tables* t, const ihmr_mlp_stage* stage, int mode, void* workspace, void* stream);
+/* skeletons + skinning of the parameters held in io (no collision term, no losses): io->verts (2,B,778,3).  Used for the
+ * annotation's meshes of the export (mlp_model.py:497-501). */
+int ihmr_opt_forward_verts(const ihmr_mano* m, const ihmr_opt_io* io, int B, void* stream);
+
 /* checker switch (tests only): force = 1 makes the finger-pose backward use the streaming form of its pose-gradient GEMM
  * (lbs_bwd2_kernel) at every launch size; 0 restores the default (the LDS-tiled form lbs_bwd2_lds_kernel from 256 hands on).  The two
  * forms produce the same bits (tests/test_gpu_parity.py::test_lbs_bwd2_forms_are_bit_identical).  Returns the previous value. */
