@@ -546,7 +546,6 @@ static int mlp_fill_select(MlpSelect& s, const ihmr_mlp_tables* t, const ihmr_ml
     s.idx = (const long long*)t->idx; s.new_params = t->new_params; s.img_feat = t->img_feat;
     s.data_idxs_all = t->data_idxs_all; s.img_feat_all = t->img_feat_all; s.prev_final = t->prev_final; s.prev_loss = t->prev_loss;
     s.final_out = t->final_params; s.kept = t->kept;
-    s.barrier = (unsigned*)workspace;
     return 0;
 }
 
@@ -555,7 +554,7 @@ extern "C" int ihmr_mlp_stage_head(const ihmr_mlp_net* net, const ihmr_mlp_table
     if (!net || !t || !io || !workspace || B <= 0 || net->k_out <= 0 || net->k_out > 122) return -1;
     MlpHeadArgs a;
     memset(&a, 0, sizeof(a));
-    a.idx = (const long long*)t->idx; a.feat_all = t->img_feat_all; a.prev_final = t->prev_final;
+    a.feat = t->img_feat; a.prev = t->final_params;
     for (int l = 0; l < 4; ++l) { a.w[l] = net->w[l]; a.b[l] = net->b[l]; a.ldw[l] = net->ldw[l]; if (!a.w[l] || !a.b[l]) return -1; }
     if (a.ldw[0] < 512 || a.ldw[1] < 256 || a.ldw[2] < 128 || a.ldw[3] < ((net->k_out + 15) & ~15)) return -1;
     a.kout = net->k_out;
@@ -563,18 +562,16 @@ extern "C" int ihmr_mlp_stage_head(const ihmr_mlp_net* net, const ihmr_mlp_table
         if (net->col[j] < 0 || net->col[j] >= 122) return -1;
         a.col[j] = (unsigned char)net->col[j];
     }
-    a.barrier = (unsigned*)workspace;
     float* h = (float*)((char*)workspace + 256);
     a.h[0] = h; a.h[1] = h + (size_t)B * 512; a.h[2] = a.h[1] + (size_t)B * 256;
     a.new_params = t->new_params;
     a.B = B;
-    int dev = 0, cus = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    // one workgroup per CU at most (all of them resident: the kernel synchronises its layers with a grid-wide barrier)
-    const int tiles = ((B + 15) / 16) * 32;
-    const int grid = std::max(1, std::min(std::min(tiles, cus > 0 ? cus : 64), MLPI_MAX_WG));
-    hipLaunchKernelGGL(mlp_head_kernel, dim3(grid), dim3(MLPI_THREADS), 0, (hipStream_t)stream, a, *io);
+    const int tr = (B + 15) / 16;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mlp_layer_kernel<0>, dim3(std::min(tr * 32, MLPI_MAX_WG)), dim3(MLPI_THREADS), 0, st, a, *io);
+    hipLaunchKernelGGL(mlp_layer_kernel<1>, dim3(std::min(tr * 16, MLPI_MAX_WG)), dim3(MLPI_THREADS), 0, st, a, *io);
+    hipLaunchKernelGGL(mlp_layer_kernel<2>, dim3(std::min(tr * 8, MLPI_MAX_WG)), dim3(MLPI_THREADS), 0, st, a, *io);
+    hipLaunchKernelGGL(mlp_layer_kernel<3>, dim3(std::min(tr * ((a.kout + 15) / 16), MLPI_MAX_WG)), dim3(MLPI_THREADS), 0, st, a, *io);
     return (int)hipGetLastError();
 }
 
@@ -1014,6 +1011,18 @@ extern "C" int ihmr_debug_stamps(long long* host, int zero) {
     HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sdf_stamps), sizeof(long long) * 4096 * 4 * 8));
     HIP_TRY(hipMemcpyFromSymbol(host + 4096 * 4 * 8, HIP_SYMBOL(g_sdf_span), sizeof(long long) * 4096 * 4 * 4));
     HIP_TRY(hipMemcpyFromSymbol(host + 4096 * 4 * 12, HIP_SYMBOL(g_sdf_prep), sizeof(long long) * 4096 * 8));
+    return 0;
+}
+#endif
+
+#ifdef TAIL_STAMPS
+// experiment builds only (scripts/tail_stamps.py): zero = 1 clears, zero = 0 copies the 3 x 4096 x 8 phase sums of opt_tail_kernel out
+extern "C" int ihmr_debug_tail_stamps(long long* host, int zero) {
+    HIP_TRY(hipDeviceSynchronize());
+    void* p;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_tail_stamps)));
+    if (zero) { HIP_TRY(hipMemset(p, 0, sizeof(long long) * 3 * 4096 * 8)); return 0; }
+    HIP_TRY(hipMemcpy(host, p, sizeof(long long) * 3 * 4096 * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

@@ -1,5 +1,5 @@
 // IHMR-MLP inference glue on the device (BASELINE.json configs[2]; the reference's models/mlp_model.py):
-//   mlp_head_kernel     one launch per stage = retrive_prev_prediction (:408-423: the batch's rows of the "prev" tables, by dataset
+//   mlp_layer_kernel    four launches per stage = retrive_prev_prediction (:408-423: the batch's rows of the "prev" tables, by dataset
 //                       index) -> the stage's sub-network (networks.py:83-105: Linear 1146-512-256-128-k with ReLU, input
 //                       [img_feat | final_params]) -> __update_params_single (:459-472: the residual added to the stage's columns)
 //                       -> the 122-vector scattered into the fused kernels' parameter buffers (= opt_unpack_params_kernel)
@@ -9,13 +9,15 @@
 // GEMM + split-K-reduce pairs.
 //
 // The sub-network at M = batch (128) rows is 192 MFLOP over 3 MB of weights: far too little for one workgroup per row block (the
-// weights would stream through four CUs), so the four layers run as 16 x 16 output tiles spread over up to 256 workgroups with a
-// grid-wide barrier between layers (all workgroups are co-resident: one per CU).  A tile = one workgroup: its four waves split
-// the K loop (v_mfma_f32_16x16x4_f32: exact fp32 = a k-ordered fmaf chain per wave), the four partial tiles are added in fixed
-// order through LDS, bias + ReLU, result to a small global buffer the next layer reads (L2).  Operands go from global memory
-// straight to the MFMA registers: every operand element is used by exactly one MFMA of the workgroup.  The k order inside a
-// 16-wide chunk is permuted (step j takes k = kb + 4 g + j of lane group g) so that a lane's A operands of four steps are ONE
-// 16-byte load; any fixed order is as good as another, and the oracle comparison is by tolerance.
+// weights would stream through four CUs), so every layer runs as 16 x 16 output tiles, one workgroup each (256 / 128 / 64 / 8-48
+// workgroups at batch 128), one launch per layer: 7 + 5 + 5 + 5 us.  (All four layers in ONE launch with grid-wide barriers between
+// them -- 256 co-resident workgroups, atomic counter + polling -- took 59 us: a barrier over 256 workgroups on one address costs
+// ~12 us here, three kernel boundaries ~1.5 us each.  Measured, dropped.)  A tile's four waves split the K loop
+// (v_mfma_f32_16x16x4_f32: exact fp32 = a k-ordered fmaf chain per wave), the four partial tiles are added in fixed order through
+// LDS, bias + ReLU, result to a small global buffer the next layer reads (L2).  Operands go from global memory straight to the
+// MFMA registers: every operand element is used by exactly one MFMA of the workgroup.  The k order inside a 16-wide chunk is
+// permuted (step j takes k = kb + 4 g + j of lane group g) so that a lane's A operands of four steps are ONE 16-byte load; any
+// fixed order is as good as another, and the oracle comparison is by tolerance.
 #pragma once
 #include "ihmr_common.h"
 
@@ -25,9 +27,12 @@
 #define MLPI_MAX_WG 256
 
 struct MlpHeadArgs {
-    const long long* idx;            // (B) dataset index of every batch row
-    const float* feat_all;           // (num_data, 1024)  img_feat_all
-    const float* prev_final;         // (num_data, 122)   final_params of the previous stage
+    // retrive_prev_prediction (mlp_model.py:408-423) gathers the batch's rows of img_feat_all / prev_final by dataset index; the rows it
+    // returns are the ones the previous launch (mlp_select_sample) has just scattered there from `img_feat` / `final_out`, which it also
+    // keeps per batch row: the head reads those (no index load in front of every operand load; duplicate indices in a batch are padding
+    // copies of one sample, opt_dataset.py:49-51, i.e. identical rows either way)
+    const float* feat;               // (B, 1024)  the batch's image features
+    const float* prev;               // (B, 122)   the batch's final_params after the previous stage
     const float* w[4];               // K-major packed weights [Kpad][ldw] (ihmr_amd/networks.py:_Packed)
     const float* b[4];
     int ldw[4];
@@ -35,21 +40,8 @@ struct MlpHeadArgs {
     unsigned char col[128];          // output j -> column of the 122-vector (mlp_model.py:426-439 order)
     float* h[3];                     // hidden activations (B,512), (B,256), (B,128)
     float* new_params;               // (B,122) out: prev + residual on the stage's columns
-    unsigned* barrier;               // grid barrier counter, zero on entry
     int B;
 };
-
-// all workgroups of the launch are resident (grid <= number of CUs, one per CU): a counter barrier is safe
-__device__ __forceinline__ void mlpi_grid_barrier(unsigned* ctr, unsigned target) {
-    __syncthreads();                 // every wave has waited for its own stores (workgroup release)
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // ... and they are written back beyond this XCD's L2
-        atomicAdd(ctr, 1u);
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // drop stale lines of this CU's L1 / this XCD's L2
-    }
-    __syncthreads();
-}
 
 // the 122-vector's column e of sample b -> the fused kernels' parameter buffers (= opt_unpack_params_kernel)
 __device__ __forceinline__ void mlpi_unpack_store(const ihmr_opt_io& io, int B, int b, int e, float v) {
@@ -66,7 +58,7 @@ __device__ __forceinline__ void mlpi_unpack_store(const ihmr_opt_io& io, int B, 
 typedef float mlpi_f4 __attribute__((ext_vector_type(4)));
 
 // One layer: out[r][c] = act(sum_k A[r][k] W[k][c] + bias[c]) over 16 x 16 tiles, tile t -> workgroup t mod grid.
-// LAYER 0 gathers A = [img_feat | final_params | 0] by dataset index; LAYER 3 adds the residual and scatters instead of storing.
+// LAYER 0 reads A = [img_feat | final_params | 0]; LAYER 3 adds the residual and scatters instead of storing.
 // CH = 16-wide k chunks per wave and batch of loads (K = 4 waves x NB x CH x 16).
 template <int LAYER, int CH, int NB>
 __device__ __forceinline__ void mlpi_layer(const MlpHeadArgs& a, const ihmr_opt_io& io, float (*red)[MLPI_THREADS]) {
@@ -82,8 +74,6 @@ __device__ __forceinline__ void mlpi_layer(const MlpHeadArgs& a, const ihmr_opt_
         const int r0 = (tile / ntc) * 16, c0 = (tile % ntc) * 16;
         const int row = r0 + m;
         const bool rok = row < B;
-        long long ridx = 0;
-        if (LAYER == 0 && rok) ridx = a.idx[row];
         mlpi_f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int nb = 0; nb < NB; ++nb) {
@@ -96,9 +86,9 @@ __device__ __forceinline__ void mlpi_layer(const MlpHeadArgs& a, const ihmr_opt_
                 av[c] = mlpi_f4{0.f, 0.f, 0.f, 0.f};
                 if (rok) {
                     if (LAYER == 0) {
-                        if (k4 < 1024) av[c] = *reinterpret_cast<const mlpi_f4*>(a.feat_all + (size_t)ridx * 1024 + k4);
+                        if (k4 < 1024) av[c] = *reinterpret_cast<const mlpi_f4*>(a.feat + (size_t)row * 1024 + k4);
                         else {
-                            const float* p = a.prev_final + (size_t)ridx * 122 + (k4 - 1024);
+                            const float* p = a.prev + (size_t)row * 122 + (k4 - 1024);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) av[c][j] = (k4 - 1024 + j) < 122 ? p[j] : 0.f;
                         }
@@ -128,7 +118,7 @@ __device__ __forceinline__ void mlpi_layer(const MlpHeadArgs& a, const ihmr_opt_
                     a.h[LAYER < 3 ? LAYER : 0][(size_t)orow * N + ocol] = fmaxf(v, 0.f);
                 } else {
                     const int e = (int)a.col[ocol];
-                    v = a.prev_final[(size_t)a.idx[orow] * 122 + e] + v;       // new[:, COLS[n]] += res[:, o:o+k]
+                    v = a.prev[(size_t)orow * 122 + e] + v;       // new[:, COLS[n]] += res[:, o:o+k]
                     a.new_params[(size_t)orow * 122 + e] = v;
                     mlpi_unpack_store(io, B, orow, e, v);
                 }
@@ -138,24 +128,22 @@ __device__ __forceinline__ void mlpi_layer(const MlpHeadArgs& a, const ihmr_opt_
     }
 }
 
-// grid = min(256, tiles of the first layer), block = 256
-__global__ __launch_bounds__(MLPI_THREADS) void mlp_head_kernel(MlpHeadArgs a, ihmr_opt_io io) {
+// grid = the layer's tiles (<= 256), block = 256.  Layer 0 also copies prev -> new (every column; the last layer overwrites the stage's
+// columns: ordered by the kernel boundaries in between) and scatters it to the parameter buffers.
+template <int LAYER>
+__global__ __launch_bounds__(MLPI_THREADS) void mlp_layer_kernel(MlpHeadArgs a, ihmr_opt_io io) {
     __shared__ float red[4][MLPI_THREADS];
-    const unsigned nwg = gridDim.x;
-    // phase 0: new = prev (every column; the last layer overwrites the stage's columns), scattered to the parameter buffers too
-    for (int i = (int)(blockIdx.x * MLPI_THREADS + threadIdx.x); i < a.B * 122; i += (int)(nwg * MLPI_THREADS)) {
-        const int b = i / 122, e = i % 122;
-        const float v = a.prev_final[(size_t)a.idx[b] * 122 + e];
-        a.new_params[i] = v;
-        mlpi_unpack_store(io, a.B, b, e, v);
-    }
-    mlpi_layer<0, 9, 2>(a, io, red);
-    mlpi_grid_barrier(a.barrier, nwg);
-    mlpi_layer<1, 8, 1>(a, io, red);
-    mlpi_grid_barrier(a.barrier, 2 * nwg);
-    mlpi_layer<2, 4, 1>(a, io, red);
-    mlpi_grid_barrier(a.barrier, 3 * nwg);           // (also orders phase 0's stores before the last layer's)
-    mlpi_layer<3, 2, 1>(a, io, red);
+    if (LAYER == 0) {
+        for (int i = (int)(blockIdx.x * MLPI_THREADS + threadIdx.x); i < a.B * 122; i += (int)(gridDim.x * MLPI_THREADS)) {
+            const int b = i / 122, e = i % 122;
+            const float v = a.prev[i];
+            a.new_params[i] = v;
+            mlpi_unpack_store(io, a.B, b, e, v);
+        }
+        mlpi_layer<0, 9, 2>(a, io, red);
+    } else if (LAYER == 1) mlpi_layer<1, 8, 1>(a, io, red);
+    else if (LAYER == 2) mlpi_layer<2, 4, 1>(a, io, red);
+    else mlpi_layer<3, 2, 1>(a, io, red);
 }
 
 // ------------------------------------------------------------------------------------------ select + save
@@ -176,7 +164,6 @@ struct MlpSelect {
     float* prev_loss;                // (num_data,3)
     float* final_out;                // (B,122) the batch's state after this stage
     unsigned char* kept;             // (B) this stage's decision
-    unsigned* barrier;               // the next mlp_head_kernel's grid-barrier counter: zeroed here
 };
 
 // called by all threads of the sample's workgroup after the losses of sample b are in loss_batch
@@ -209,7 +196,6 @@ __device__ __forceinline__ void mlp_select_sample(const MlpSelect& s, const floa
     } else if (tid == 125) {
         s.kept[b] = ok ? 1 : 0;
         s.data_idxs_all[r] = 1;
-        if (b == 0) *s.barrier = 0u;
     }
     if (s.mode == 1)
         for (int k = tid; k < 1024; k += (int)blockDim.x) s.img_feat_all[(size_t)r * 1024 + k] = s.img_feat[(size_t)b * 1024 + k];

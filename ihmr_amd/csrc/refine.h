@@ -392,6 +392,14 @@ __global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_op
 // SKIN (with STEP, stages that keep v_posed -- neither finger pose nor shape moves): a fourth phase skins the stored v_posed of both
 // hands with the skeletons just computed (= lbs_skin_kernel<true, REUSE>, the same operations in the same order: the same bits), so
 // the next iteration starts at the collision kernels: 3 launches per iteration.
+// Phase stamps (experiment builds only, -DTAIL_STAMPS; scripts/tail_stamps.py): shader-clock time of each phase of a sample's workgroup,
+// summed per sample and kernel form
+#ifdef TAIL_STAMPS
+__device__ long long g_tail_stamps[3][4096][8];
+#define TAIL_TK(k) do { if (threadIdx.x == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); if (blockIdx.x < 4096) g_tail_stamps[STEP + SKIN][blockIdx.x][k] += now_ - tk_prev_; tk_prev_ = now_; } } while (0)
+#else
+#define TAIL_TK(k)
+#endif
 template <bool STEP, bool SKIN = false>
 __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_mano m, ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,
                                                                          VertLayout vl, SdfWorkspace ws, int need_cam, int need_mask,
@@ -401,6 +409,10 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
     __shared__ LbsBwdShared bw[2];
     extern __shared__ __attribute__((aligned(16))) float tail_part[];   // [2][nseg][12]
     const int b = blockIdx.x, tid = threadIdx.x;
+#ifdef TAIL_STAMPS
+    long long tk_prev_ = (long long)__builtin_readcyclecounter();
+    if (tid == 0 && blockIdx.x < 4096) g_tail_stamps[STEP + SKIN][blockIdx.x][7] += 1;
+#endif
     // ---- phase 1: collision sampling (waves 0-6) + joint / translation / finger losses (wave 7)
     if (tid >= OPT_SAMPLE_WORKERS) opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS, need_cam);
     const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
@@ -410,16 +422,19 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
     sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, nullptr, nullptr, nullptr, wk.g_verts, B, gs,
                      io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
     __syncthreads();         // g_verts / g_joints of this sample: written above by this workgroup, read below by it
+    TAIL_TK(0);
     // ---- phase 2: LBS backward of both hands
     const int hl = tid / LBS_THREADS;
     lbs_bwd1_hand<true>(m, wk.lbs, B, hl * B + b, tid % LBS_THREADS, bw[hl], tail_part + (size_t)hl * m.nseg * 12, wk.g_verts, wk.g_joints,
                         wk.g_orient, wk.g_shape, wk.g_trans, need_mask);
-    if (!STEP) return;
+    if (!STEP) { TAIL_TK(1); return; }
     __syncthreads();         // the parameter gradients of this sample are in place
+    TAIL_TK(1);
     // ---- phase 3: the optimizer step of this iteration, then both skeletons of the next one (threads [0,192) / [192,384))
     if (b == 0 && tid >= 384 && tid < 384 + SDF_NZERO) sdf_zero_counter(inside_count, tid - 384);   // the next iteration's collision kernels start from zero
     if (st.mask && tid < OPT_NPARAM) { opt_snapshot_losses(io, B, st, b, tid); opt_param_apply(io, wk, B, st, b, tid); }
     __syncthreads();         // the updated parameters are read back below by other threads of this workgroup
+    TAIL_TK(2);
     // (SKIN: the vertex data of phase 4 is requested here, ahead of the skeleton chain: v_posed does not change in such a stage)
     constexpr int VR = (NV + LBS_THREADS - 1) / LBS_THREADS;
     const int lt = tid % LBS_THREADS, hv = hl * B + b;
@@ -440,6 +455,7 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
     const int hs = tid / 192;
     lbs_skel_hand<true>(m, io.orient, io.pose, io.shape, io.trans, B, wk.lbs.skel, wk.joints_raw, bw[hs < 2 ? hs : 0].sk, (hs < 2 ? hs : 0) * B + b, tid % 192,
                         hs < 2);
+    TAIL_TK(3);
     if (!SKIN) return;
     // ---- phase 4: the next iteration's vertices (threads [0,256) right hand, [256,512) left hand; the skinning matrices A and the left
     //      hand's shift are in this hand's LDS record -- visible since the barrier that closes lbs_skel_hand's last LDS phase)
@@ -490,6 +506,7 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
                 jd[0] = out[0]; jd[1] = out[1]; jd[2] = out[2];
             }
     }
+    TAIL_TK(4);
 }
 
 // The reference's packed prediction vector final_params (B,122) = [cam 3 | R orient 3 | R pose 45 | L orient 3 |

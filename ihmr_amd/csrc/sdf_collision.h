@@ -31,7 +31,9 @@
 // chain per thread -- the form for small launches, where the kernel is as long as one workgroup (one batch of 64: 29.0 -> 22.1 us).
 #define SDF_PREP_THREADS_LARGE 512
 #define SDF_PREP_THREADS_SMALL 1024
+#ifndef SDF_PREP_SMALL_MAX_HANDS
 #define SDF_PREP_SMALL_MAX_HANDS 128     // up to this many hands per launch (one batch of 64) the 1024-thread form is used; at 256 hands (IHMR-MLP, batch 128) the 512-thread form is 11 % faster end to end
+#endif
 #define SDF_NCOL (SDF_G * SDF_G)   // 1024 columns (k,j)
 #define SDF_RAYQ 4096               // (triangle, needed column) pairs per window of the prep kernel's ray-parity queue (a hand has ~1000)
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
@@ -186,6 +188,20 @@ struct VertLayout {
 // grid_sample un-normalisation: align_corners = False: ((x + 1) * G - 1) / 2;  True: (x + 1) / 2 * (G - 1)   (torch's expressions)
 __device__ __forceinline__ float sdf_unnorm(float x, int align_corners) {
     return align_corners ? ((x + 1.0f) / 2.0f) * (float)(SDF_G - 1) : ((x + 1.0f) * (float)SDF_G - 1.0f) / 2.0f;
+}
+
+// a / b, correctly rounded (the bits of the IEEE division the oracle's `(v - c) / s` performs), for MANY numerators over ONE divisor:
+// with y = RN(1 / b) (one IEEE division per hand), q0 = RN(a y), r = a - b q0 (exact in one fma), RN(q0 + r y) is the correctly rounded
+// quotient (Markstein's theorem; checked against exact rational arithmetic on 2 x 10^5 random pairs, scripts/experiments/markstein_division.py)
+// -- three instructions instead of the ~10 of the division expansion, six times per vertex pair.  Needs b and the results in the normal
+// range: the caller takes this path only for a box scale in [1e-6, 1e6] (else the plain division: degenerate hands keep the oracle's infs / NaNs).
+struct SdfDivisor { float b, y; bool fast; };
+__device__ __forceinline__ SdfDivisor sdf_divisor(float b) { return SdfDivisor{b, 1.0f / b, b >= 1e-6f && b <= 1e6f}; }
+__device__ __forceinline__ float sdf_div(float a, const SdfDivisor& d) {
+    if (!d.fast) return a / d.b;             // (uniform per hand)
+    const float q0 = a * d.y;
+    const float r = __builtin_fmaf(-d.b, q0, a);
+    return __builtin_fmaf(r, d.y, q0);
 }
 
 // Workgroup barrier for phases that hand over LDS data only: waits for this wave's LDS operations, NOT for its global
@@ -429,17 +445,18 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     SDF_TK(pk_[1] = SDF_STAMP();)
     if (!stat && tid < 4) ws.box[H * 4 + tid] = tid == 0 ? cx : (tid == 1 ? cy : (tid == 2 ? cz : sc));
     // ---- normalise own vertices into [-1,1]^3; which voxels will the other hand's vertices read?
+    const SdfDivisor dsc = sdf_divisor(sc);
 #pragma unroll
     for (int rep = 0; rep < VPT; ++rep) {
         const int v = tid + rep * PT;
         if (v >= NV) break;
         if (!stat) {
-            const float nx = (vn[3 * v] - cx) / sc, ny = (vn[3 * v + 1] - cy) / sc, nz = (vn[3 * v + 2] - cz) / sc;
+            const float nx = sdf_div(vn[3 * v] - cx, dsc), ny = sdf_div(vn[3 * v + 1] - cy, dsc), nz = sdf_div(vn[3 * v + 2] - cz, dsc);
             vn[3 * v] = nx; vn[3 * v + 1] = ny; vn[3 * v + 2] = nz;
             ws.vn4[(size_t)H * SDF_NV4 + v] = make_float4(nx, ny, nz, 0.f);     // the exact distance gathers triangle corners from here
         }
         if (!DENSE) {
-            const float qx0 = (oq[rep][0] - cx) / sc, qy = (oq[rep][1] - cy) / sc, qz0 = (oq[rep][2] - cz) / sc;
+            const float qx0 = sdf_div(oq[rep][0] - cx, dsc), qy = sdf_div(oq[rep][1] - cy, dsc), qz0 = sdf_div(oq[rep][2] - cz, dsc);
             const float qx = ws.swap_xz ? qz0 : qx0, qz = ws.swap_xz ? qx0 : qz0;
             const float ix = sdf_unnorm(qx, ws.align_corners), iy = sdf_unnorm(qy, ws.align_corners), iz = sdf_unnorm(qz, ws.align_corners);
             const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
@@ -1459,8 +1476,9 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
 #pragma unroll
     for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
         const float cx = bx[it].x, cy = bx[it].y, cz = bx[it].z, sc = bx[it].w;
-        const float nx0 = (qv[it][0] - cx) / sc, nz0 = (qv[it][2] - cz) / sc;
-        const float ix = sdf_unnorm(ws.swap_xz ? nz0 : nx0, ws.align_corners), iy = sdf_unnorm((qv[it][1] - cy) / sc, ws.align_corners),
+        const SdfDivisor dsc = sdf_divisor(sc);
+        const float nx0 = sdf_div(qv[it][0] - cx, dsc), nz0 = sdf_div(qv[it][2] - cz, dsc);
+        const float ix = sdf_unnorm(ws.swap_xz ? nz0 : nx0, ws.align_corners), iy = sdf_unnorm(sdf_div(qv[it][1] - cy, dsc), ws.align_corners),
                     iz = sdf_unnorm(ws.swap_xz ? nx0 : nz0, ws.align_corners);
         ixs[it][0] = ix; ixs[it][1] = iy; ixs[it][2] = iz;
         const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);

@@ -367,9 +367,10 @@ int ihmr_flush_kernel_timer(void);
  * (networks.py:83-105) -> __update_params_single (:459-472) -> forward + losses -> select_better_params (:592-637) ->
  * save_pred_to_prev (:337-356).  Two entry points per stage replace the ~25 tensor operations the reference (and rounds 1-3 of
  * this build) ran around the fused forward:
- *   ihmr_mlp_stage_head      gathers the batch's rows of the "prev" tables by dataset index, runs the four Linear layers (exact
- *                            fp32 on the matrix cores, ONE launch with grid-wide barriers between the layers), adds the residual to
- *                            the stage's columns -> t->new_params (B,122), and scatters that vector into io's parameter buffers;
+ *   ihmr_mlp_stage_head      the four Linear layers (exact fp32 on the matrix cores, one launch per layer, 16 x 16 output tiles) on
+ *                            [t->img_feat | t->final_params] -- the batch's rows of the "prev" tables, which the preceding
+ *                            ihmr_mlp_forward_select keeps per batch row as well as by dataset index --, the residual added to the
+ *                            stage's columns -> t->new_params (B,122), and that vector scattered into io's parameter buffers;
  *   ihmr_mlp_forward_select  = ihmr_opt_forward_losses, whose last launch also decides per sample: keep the update iff every filter
  *                            loss < prev * filter_factor (strictly) and the select loss <= prev; the kept / fallen-back row goes to
  *                            t->final_params and, with its three losses, to the tables; t->kept (B) gets the decision (mode 2).
@@ -378,8 +379,8 @@ int ihmr_flush_kernel_timer(void);
  *                            collision kernels carry their candidate lists from one call to the next (exact: checked per hand against
  *                            the pose the lists were built at); mode 1 starts them over.
  * Weights: K-major [Kpad][ldw] as ihmr_conv_igemm takes them (layer 0: Kpad = 1152 rows, zeros beyond 1146).  Loss indices: IHMR_LOSS_*
- * (0 joints_2d_loss_p, 1 joints_3d_loss_p, 2 collision_loss).  workspace: ihmr_mlp_workspace_bytes(B), zero-initialised by the caller
- * once (its first word is the layer barrier's counter; every forward_select resets it).  All pointers device pointers. */
+ * (0 joints_2d_loss_p, 1 joints_3d_loss_p, 2 collision_loss).  workspace: ihmr_mlp_workspace_bytes(B) (the hidden activations).
+ * All pointers device pointers. */
 typedef struct ihmr_mlp_net { const float* w[4]; const float* b[4]; int ldw[4]; int k_out; int col[122]; } ihmr_mlp_net;
 typedef struct ihmr_mlp_tables {
     const int64_t* idx;        /* (B) dataset index of every batch row */
