@@ -138,3 +138,13 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* buf) {
     __syncthreads();
     return r;
 }
+
+// n dwords global -> LDS by DMA (global_load_lds: no registers, asynchronous; the issuing wave's `s_waitcnt vmcnt(0)` + a workgroup barrier
+// make them visible), by a group of `threads` consecutive threads of which this is thread `t`.  The LDS layout stays linear (the LDS
+// address of a DMA load is a wave-uniform base + lane * 4).
+__device__ __forceinline__ void lds_dma_dwords(const float* __restrict__ src, float* dst_lds, int n, int t, int threads) {
+    const int lane = t % WAVE;
+    for (int base = (t / WAVE) * WAVE; base < n; base += threads)
+        if (base + lane < n)
+            __builtin_amdgcn_global_load_lds(src + base + lane, (__attribute__((address_space(3))) void*)(dst_lds + base), 4, 0, 0);
+}

@@ -460,7 +460,11 @@ __device__ __forceinline__ void lbs_bwd1_hand(const ihmr_mano& m, const LbsWork&
                                               float* bwd1_part /* [nseg][12], LDS */,
                                               const float* __restrict__ d_verts, const float* __restrict__ d_joints,
                                               float* __restrict__ d_orient, float* __restrict__ d_betas,
-                                              float* __restrict__ d_trans, int need_mask) {
+                                              float* __restrict__ d_trans, int need_mask, const LbsBwdShared* lds_left = nullptr) {
+    // lds_left != nullptr (opt_tail_kernel): the caller has already put this hand's inputs into `bw` -- g and gj (raw hand frame) written
+    // by the sampling / loss phase of the same workgroup, vp and sk by DMA -- and passes the LEFT hand's record for d L / d shift;
+    // nothing is read back from global memory and the staging phase is skipped.  The same values in the same order: the same bits.
+    const bool in_lds = TWO_HAND && lds_left != nullptr;
     const bool left = TWO_HAND && h >= B;
     const int b = TWO_HAND ? (left ? h - B : h) : 0;
     const bool need_orient = need_mask & 1, need_pose = need_mask & 2, need_betas = need_mask & 4, need_trans = need_mask & 8;
@@ -472,6 +476,17 @@ __device__ __forceinline__ void lbs_bwd1_hand(const ihmr_mano& m, const LbsWork&
     // this hand's output gradients, v_posed and skeleton record, the joint gradients
     constexpr int NR = (NV3 + LBS_THREADS - 1) / LBS_THREADS, SR = (SK_STRIDE + LBS_THREADS - 1) / LBS_THREADS;
     float rg[NR], rv[NR], rs[SR], gl0[VR][3], gjl[3] = {0.f, 0.f, 0.f}, gjo = 0.f;
+    if (in_lds) {
+        // the left hand's raw output gradients from its LDS record (x stored negated: negated back, exactly)
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            const int v = tid + r * LBS_THREADS;
+            gl0[r][0] = v < NV ? -lds_left->g[3 * v] : 0.f;
+            gl0[r][1] = v < NV ? lds_left->g[3 * v + 1] : 0.f;
+            gl0[r][2] = v < NV ? lds_left->g[3 * v + 2] : 0.f;
+        }
+        if (tid < 21) { gjl[0] = -lds_left->gj[tid][0]; gjl[1] = lds_left->gj[tid][1]; gjl[2] = lds_left->gj[tid][2]; }
+    } else {
     if (TWO_HAND) {
         const float* gl = d_verts + ((size_t)(B + b) * NV) * 3;
 #pragma unroll
@@ -498,6 +513,7 @@ __device__ __forceinline__ void lbs_bwd1_hand(const ihmr_mano& m, const LbsWork&
         if (TWO_HAND) gjo = d_joints[((size_t)b * 42 + (left ? 21 : 0) + j) * 3 + k];
         else gjo = j < NJ ? d_joints[((size_t)h * NJ + j) * 3 + k] : 0.f;
     }
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- TWO_HAND: d L / d shift = sum over the LEFT hand's vertex and joint gradients of this sample
     if (TWO_HAND) {
@@ -520,6 +536,7 @@ __device__ __forceinline__ void lbs_bwd1_hand(const ihmr_mano& m, const LbsWork&
     }
 
     // ---- skeleton record of this iteration's forward, output gradients into the raw hand frame
+    if (!in_lds) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int i = tid + r * LBS_THREADS;
@@ -536,6 +553,7 @@ __device__ __forceinline__ void lbs_bwd1_hand(const ihmr_mano& m, const LbsWork&
     if (tid < 21 * 3) {
         const int j = tid / 3, k = tid % 3;
         bw.gj[j][k] = (TWO_HAND && left && k == 0) ? -gjo : gjo;
+    }
     }
     __syncthreads();
     if (TWO_HAND && tid < IHMR_NUM_TIPS * 3) {  // fingertip joints are vertices

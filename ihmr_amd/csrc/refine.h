@@ -79,8 +79,10 @@ struct LossShared {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       \
     } while (0)
 
+// gj_lds (fused tail): the joint gradients go straight to the LBS backward's LDS records -- bw[hand].gj, raw hand frame: x of the left
+// hand negated, what lbs_bwd1_hand's staging does with the values it reads back from global memory -- instead of wk.g_joints
 __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWork& wk, int B, const ihmr_opt_weights& w,
-                                              LossShared& sh, int b, int j, int need_cam) {
+                                              LossShared& sh, int b, int j, int need_cam, LbsBwdShared* gj_lds = nullptr) {
     const bool act = j < 42;
     const int Bn = io.norm_batch > 0 ? io.norm_batch : B;   // the batch the reference's means run over
     // ---- every global input of this sample first, in one batch (the stores below may alias them as far as the
@@ -231,7 +233,9 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float g0 = g1[k] - ((root1 >= 0 && j == root1) ? sh.gsum[1][k] : 0.f);
-            wk.g_joints[(b * 42 + j) * 3 + k] = g0 + g_raw[k];
+            const float gv = g0 + g_raw[k];
+            if (gj_lds) gj_lds[j / 21].gj[j % 21][k] = (j >= 21 && k == 0) ? -gv : gv;
+            else wk.g_joints[(b * 42 + j) * 3 + k] = gv;
         }
     }
 
@@ -413,20 +417,28 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
     long long tk_prev_ = (long long)__builtin_readcyclecounter();
     if (tid == 0 && blockIdx.x < 4096) g_tail_stamps[STEP + SKIN][blockIdx.x][7] += 1;
 #endif
-    // ---- phase 1: collision sampling (waves 0-6) + joint / translation / finger losses (wave 7)
-    if (tid >= OPT_SAMPLE_WORKERS) opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS, need_cam);
+    // ---- phase 0: what the LBS backward (phase 2) needs from the forward of this iteration -- v_posed and the skeleton record of both
+    //      hands -- goes global -> LDS by DMA now (no registers held, nobody waits): it lands while phase 1 runs
+    const int hl = tid / LBS_THREADS;
+    if ((need_mask & 7) != 0) {
+        lds_dma_dwords(wk.lbs.v_posed + (size_t)(hl * B + b) * NV3, bw[hl].vp, NV3, tid % LBS_THREADS, LBS_THREADS);
+        lds_dma_dwords(wk.lbs.skel + (size_t)(hl * B + b) * SK_STRIDE, bw[hl].sk, SK_STRIDE, tid % LBS_THREADS, LBS_THREADS);
+    }
+    // ---- phase 1: collision sampling (waves 0-6) + joint / translation / finger losses (wave 7).  Their gradients -- d L / d vertices,
+    //      d L / d joints -- are handed to phase 2 through its LDS records, not through global memory (the same values)
+    if (tid >= OPT_SAMPLE_WORKERS) opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS, need_cam, bw);
     const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
     const float gs = w.collision * mask / (ws.loss_div * (float)(io.norm_batch > 0 ? io.norm_batch : B));
     // (inside the loop nobody reads the per-vertex depths: the 12 KB per sample and iteration are not written -- the forward that
     // closes optimize(), opt_sample_loss_kernel, writes the ones that are exported)
-    sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, nullptr, nullptr, nullptr, wk.g_verts, B, gs,
-                     io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
-    __syncthreads();         // g_verts / g_joints of this sample: written above by this workgroup, read below by it
+    sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, nullptr, nullptr, nullptr, nullptr, B, gs,
+                     io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS, bw[0].g, bw[1].g);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (this wave's DMA writes to LDS have landed; the barrier publishes them)
+    __syncthreads();         // the gradients of this sample and the DMA'd records: written above by this workgroup, read below by it
     TAIL_TK(0);
     // ---- phase 2: LBS backward of both hands
-    const int hl = tid / LBS_THREADS;
-    lbs_bwd1_hand<true>(m, wk.lbs, B, hl * B + b, tid % LBS_THREADS, bw[hl], tail_part + (size_t)hl * m.nseg * 12, wk.g_verts, wk.g_joints,
-                        wk.g_orient, wk.g_shape, wk.g_trans, need_mask);
+    lbs_bwd1_hand<true>(m, wk.lbs, B, hl * B + b, tid % LBS_THREADS, bw[hl], tail_part + (size_t)hl * m.nseg * 12, nullptr, nullptr,
+                        wk.g_orient, wk.g_shape, wk.g_trans, need_mask, &bw[1]);
     if (!STEP) { TAIL_TK(1); return; }
     __syncthreads();         // the parameter gradients of this sample are in place
     TAIL_TK(1);

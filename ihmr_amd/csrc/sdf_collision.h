@@ -1448,7 +1448,8 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
                                                  float* __restrict__ loss, float* __restrict__ per_vert,
                                                  float* __restrict__ origin, float* __restrict__ dval,
                                                  float* __restrict__ gverts, int B, float gs,
-                                                 const float* __restrict__ hand_type, float* red16, int b, int nworkers) {
+                                                 const float* __restrict__ hand_type, float* red16, int b, int nworkers,
+                                                 float* g_lds_r = nullptr, float* g_lds_l = nullptr) {
     const int tid = threadIdx.x;
     float acc = 0.f;
     // A thread owns the entries tid, tid + nworkers, ... (at most SDF_SAMPLE_NIT).  Three phases over ALL of them, so that the two
@@ -1575,6 +1576,11 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
         if (gverts) {
             float* g = gverts + (((size_t)(1 - hnd) * B + b) * NV + v) * 3;
             g[0] = gs * gx; g[1] = gs * gy; g[2] = gs * gz;
+        }
+        if (g_lds_r) {     // fused tail: straight into the LBS backward's LDS record of the hand the vertex belongs to (raw hand frame:
+            float* g = (hnd ? g_lds_r : g_lds_l) + 3 * v;       // the left hand's x negated, as lbs_bwd1_hand's staging does)
+            const float g0 = gs * gx;
+            g[0] = hnd ? g0 : -g0; g[1] = gs * gy; g[2] = gs * gz;
         }
         acc += val;
     }

@@ -278,9 +278,11 @@ class MLPTrainMixin:
                 cols = [c for n in self.strategy[sid]["update_params"] for c in range(COLS[n].start, COLS[n].stop)]
                 self._out_cols[sid] = torch.tensor(cols, dtype=torch.int32, device=self.device)
             oc, tr = self._out_cols[sid], self.trainers[sid]
+            # (set_input keeps these as slices of the packed 122-vectors: dense copies for the training kernel)
+            gt_pose, gt_shape, init_shape = self.gt_pose_params.contiguous(), self.gt_shape_params.contiguous(), self.init_shape_params.contiguous()
             hip.check(hip.lib().ihmr_mlp_train_grad(mr, ml, C.byref(io), B, C.byref(ow), C.byref(tw),
-                                                    hip.ptr(self.gt_pose_params), hip.ptr(self.gt_shape_params), hip.ptr(self.mano_params_weight),
-                                                    hip.ptr(self.init_shape_params), None, hip.ptr(self._grad122),
+                                                    hip.ptr(gt_pose), hip.ptr(gt_shape), hip.ptr(self.mano_params_weight),
+                                                    hip.ptr(init_shape), None, hip.ptr(self._grad122),
                                                     hip.ptr(self._terms5), hip.ptr(oc), oc.numel(), hip.ptr(tr.dy[3]), tr.dy[3].shape[1],
                                                     hip.stream_ptr()), "ihmr_mlp_train_grad")
         finally:
