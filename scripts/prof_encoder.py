@@ -25,6 +25,6 @@ tot = sum(r[0] for r in recs)
 agg = {}
 for dt, fl, name in recs:
     a = agg.setdefault(name, [0, 0, 0]); a[0] += dt; a[1] += fl; a[2] += 1
-for name, (dt, fl, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
+for name, (dt, fl, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"{dt*1e3:7.3f} ms  x{n}  {fl/dt/1e12:6.1f} TF  {name}")
 print("sum conv ms", tot * 1e3)
