@@ -170,13 +170,13 @@ def kernel_models(kernel, hands, st):
         # + 20 per hit-mask evaluation (counted together in ray_tests: (u, v) tests + needed voxels of the hit columns)
         return (hands * (2 * HAND_VERT_BYTES + 9336 + 4096 + HAND_TABLE_BYTES + 16) + st["needed_voxels"] * 4,
                 hands * (778 * 20.0 + 1538 * 130.0) + st["ray_tests"] * 17.0)
-    # opt_tail_kernel, per sample: sampling reads both hands' vertices + one phi value per needed voxel, writes the 1556 depths
-    # twice (per-vertex value, origin scale) and d L / d vertices (2 x 9.3 KB, read back by the LBS backward in the same launch:
-    # counted once); LBS backward reads v_posed of both hands; the translation / orientation form also skins the next vertices
-    # (v_posed in, vertices out).  flops: 60 per sampled vertex (trilinear value + gradient), LBS backward over the four non-zero
-    # weights (778 x 4 x 24 x 2 per hand), skinning 778 x 4 x 24 per hand
+    # opt_tail_kernel, per sample: sampling reads both hands' vertices + one phi value per needed voxel; the LBS backward reads v_posed of
+    # both hands (+ the 3 KB skeleton records); the translation / orientation form also skins the next vertices (vertices out).  The
+    # gradients between the phases stay in LDS and the per-vertex depths are not written inside the loop: no bytes.  flops: 60 per
+    # sampled vertex (trilinear value + gradient), LBS backward over the four non-zero weights (778 x 4 x 24 x 2 per hand), skinning
+    # 778 x 4 x 24 per hand
     skin = 0.5            # the translation / orientation stages (half the iterations of opt_default) also skin: vertices out
-    return (samples * (2 * HAND_VERT_BYTES + 2 * 1556 * 4 + 2 * HAND_VERT_BYTES + 2 * HAND_VERT_BYTES + skin * 2 * HAND_VERT_BYTES) + st["needed_voxels"] * 4,
+    return (samples * (2 * HAND_VERT_BYTES + 2 * (HAND_VERT_BYTES + 3136) + skin * 2 * HAND_VERT_BYTES) + st["needed_voxels"] * 4,
             samples * (1556 * 60.0 + 2 * 778 * 4 * 24 * 2.0 + skin * 2 * 778 * 4 * 24))
 
 
