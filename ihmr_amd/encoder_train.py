@@ -48,14 +48,16 @@ def unpack_wgrad(dw_packed: torch.Tensor, shape) -> torch.Tensor:
     return dw_packed[:kh * kw * cin, :cout].reshape(kh, kw, cin, cout).permute(3, 2, 0, 1).contiguous()
 
 
-def conv_forward(x, w_packed, N, H, W, Cin, Cout, k, stride, pad, out=None):
-    """Plain convolution (no bias, no activation): x [N*H*W, Cin] -> [N*Ho*Wo, Cout]."""
+def conv_forward(x, w_packed, N, H, W, Cin, Cout, k, stride, pad, out=None, residual=None):
+    """Plain convolution (no bias, no activation): x [N*H*W, Cin] -> [N*Ho*Wo, Cout] (+ ``residual`` [N*Ho*Wo, Cout], added in the
+    kernel's epilogue: the sum of two gradient branches without an extra pass over the tensor)."""
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     if out is None:
         out = torch.empty(N * Ho * Wo, Cout, device=x.device)
     ws = _splitk_workspace(x.device)
-    hip.check(hip.lib().ihmr_conv_igemm(hip.ptr(x), hip.ptr(w_packed), None, None, hip.ptr(out), N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad,
-                                        x.shape[1], w_packed.shape[1], out.shape[1], 0, 0, ws.data_ptr(), ws.numel() * 4, hip.stream_ptr()),
+    hip.check(hip.lib().ihmr_conv_igemm(hip.ptr(x), hip.ptr(w_packed), None, hip.ptr(residual), hip.ptr(out), N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad,
+                                        x.shape[1], w_packed.shape[1], out.shape[1], 0 if residual is None else residual.shape[1], 0,
+                                        ws.data_ptr(), ws.numel() * 4, hip.stream_ptr()),
               "ihmr_conv_igemm")
     return out, Ho, Wo
 
@@ -94,8 +96,9 @@ def conv_dgrad_s2_3x3(dy, phase_weights, N, H, W, Cin, Cout):
     return dx
 
 
-def conv_dgrad(dy, w_dgrad, N, H, W, Cin, Cout, k, stride, pad):
-    """dy [N*Ho*Wo, Cout] -> dx [N*H*W, Cin] (H, W even for the stride-2 layers, as everywhere in ResNet-50 at 224 x 224)."""
+def conv_dgrad(dy, w_dgrad, N, H, W, Cin, Cout, k, stride, pad, residual=None):
+    """dy [N*Ho*Wo, Cout] -> dx [N*H*W, Cin] (H, W even for the stride-2 layers, as everywhere in ResNet-50 at 224 x 224).
+    ``residual`` (stride-1 layers): another gradient w.r.t. the same input, added in the epilogue."""
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     src, Hs, Ws = dy, Ho, Wo
     if stride == 2 and k == 1 and pad == 0:
@@ -113,9 +116,9 @@ def conv_dgrad(dy, w_dgrad, N, H, W, Cin, Cout, k, stride, pad):
         Hs, Ws = H, W
     else:
         assert stride == 1
-    dx, H2, W2 = conv_forward(src, w_dgrad, N, Hs, Ws, Cout, Cin, k, 1, k - 1 - pad)
+    dx, H2, W2 = conv_forward(src, w_dgrad, N, Hs, Ws, Cout, Cin, k, 1, k - 1 - pad, residual=residual if stride == 1 else None)
     assert (H2, W2) == (H, W)
-    return dx
+    return dx if (residual is None or stride == 1) else dx + residual
 
 
 _WG_WS = {}
@@ -393,8 +396,10 @@ class EncoderTrainer:
         relu_backward_(g, b["c3"]["save"]["y"])                                  # the ReLU after the residual add
         g3 = self._unit_backward(b["c3"], g)
         g2 = self._unit_backward(b["c2"], g3, masked=False)
-        g1 = self._unit_backward(b["c1"], g2, masked=False)
-        return g1 + (self._unit_backward(b["ds"], g) if b["ds"] is not None else g)
+        # the gradient of the skip branch (identity or downsample) is added in the epilogue of c1's input-gradient convolution
+        # (every c1 is 1 x 1 / stride 1): g1 + skip without a pass of its own over the tensor, the same bits
+        skip = self._unit_backward(b["ds"], g) if b["ds"] is not None else g
+        return self._unit_backward(b["c1"], g2, masked=False, residual=skip)
 
     def forward(self, img):
         B, dev = self.B, self.dev
@@ -431,7 +436,7 @@ class EncoderTrainer:
         return self.pred_params, self.hand_type
 
     # ---- backward
-    def _unit_backward(self, u, g, need_dx=True, masked=True):
+    def _unit_backward(self, u, g, need_dx=True, masked=True, residual=None):
         """g = gradient w.r.t. the unit's output -> gradient w.r.t. its input.  masked=False: the unit's ReLU mask has not been
         applied to g yet; the BatchNorm backward kernels apply it on the fly."""
         s = u["save"]
@@ -442,7 +447,7 @@ class EncoderTrainer:
             return None
         if "w_phase" in u:
             return conv_dgrad_s2_3x3(dz, u["w_phase"], s["N"], s["H"], s["W"], u["cin"], u["cout"])
-        return conv_dgrad(dz, u["w_dgrad"], s["N"], s["H"], s["W"], u["cin"], u["cout"], u["k"], u["stride"], u["pad"])
+        return conv_dgrad(dz, u["w_dgrad"], s["N"], s["H"], s["W"], u["cin"], u["cout"], u["k"], u["stride"], u["pad"], residual=residual)
 
     def backward(self, d_params, d_hand):
         B, dev, Kp, P = self.B, self.dev, self.reg.kpad, self.nparam
