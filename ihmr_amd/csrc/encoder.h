@@ -15,6 +15,7 @@
 // buffer after them, ONE barrier per K step.  The host picks the largest tile that still gives >= 1.5 workgroups
 // per CU (the 14x14 / 7x7 layers of a 64-image batch have only 12544 / 3136 rows).
 #pragma once
+#include <type_traits>
 #include "ihmr_common.h"
 
 #define CONV_BK 16
@@ -227,6 +228,174 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs a) {
         if (a.act == 1) v[e] = fmaxf(v[e], 0.f);
         else if (a.act == 2) v[e] = 1.0f / (1.0f + expf(-v[e]));
         a.y[(size_t)m * a.ldy + n + e] = v[e];
+    }
+}
+
+// ---- Stream-K form of the 128 x 128 tile (fast path only) for the layers whose tile count does not fill the GPU evenly.
+// ResNet-50 at batch 64 has M = 64 * 49 * 4^j output rows: 100, 196 or 392 tiles of 128 x 128 on 256 CUs, i.e. 0.8 or 1.5
+// workgroups per CU with one tile per workgroup -- a quarter of the CUs' time is lost to the uneven last generation (and a 2-way
+// K split only moves the problem: 392 or 784 workgroups).  Here a fixed number of workers (gridDim.x, two per CU) share the
+// layer's tiles x K-steps evenly: worker w owns the steps [w * total / W, (w + 1) * total / W) of the sequence (tile 0: steps
+// 0..nk-1, tile 1: ...; tiles ordered M-fastest), at most two of its tile segments are partial.  A tile a worker covers
+// completely gets the ordinary epilogue; partial sums go to the worker's two 64 KB slots of the workspace (slot 1: the segment
+// that begins a tile, slot 0: any other) and conv_streamk_fixup_kernel adds a tile's segments in ascending K order -- a fixed
+// order, so the result does not depend on timing -- and applies bias / residual / activation.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
+void conv_streamk_kernel(ConvArgs a, int tiles_m, int nk, int total) {
+    constexpr int BM = 128, BN = 128, LDA = BM + 5, LDB = BN + 4;
+    __shared__ float As[2][CONV_BK][LDA];
+    __shared__ float Bs[2][CONV_BK][LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, kl = lane >> 5, l31 = lane & 31;
+    const int M = a.N * a.Ho * a.Wo;
+    const int arow = tid >> 2, ak4 = (tid & 3) * 4;        // A loader: one float4 per thread (row, 4 consecutive k)
+    const int bk = tid >> 5, bn4 = (tid & 31) * 4;         // B loader: one float4 per thread (k row, 4 consecutive n)
+    // consecutive workgroup ids go to the 8 XCDs round-robin; worker numbers are handed out so that an XCD's workers own ONE contiguous
+    // eighth of the step sequence -- neighbouring tiles, whose activation rows and filter columns then meet in that XCD's L2
+#ifndef CONV_SK_NO_XCD
+    const int worker = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // gridDim.x is a multiple of 8
+#else
+    const int worker = blockIdx.x;
+#endif
+    int s = (int)((long)worker * total / gridDim.x);
+    const int s_end = (int)((long)(worker + 1) * total / gridDim.x);
+    while (s < s_end) {
+        const int tile = s / nk, kc0 = s - tile * nk, kc1 = min(nk, kc0 + (s_end - s));
+        const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+        const int am = m0 + arow;
+        const bool am_ok = am < M;
+        int an = 0, aho = 0, awo = 0;
+        if (am_ok) { an = am / (a.Ho * a.Wo); const int r = am % (a.Ho * a.Wo); aho = r / a.Wo; awo = r % a.Wo; }
+        const int hbase = aho * a.stride - a.pad, wbase = awo * a.stride - a.pad;
+        int tap_c, tap_h, tap_w;
+        { const int k0 = kc0 * CONV_BK, tap = k0 / a.Cin; tap_c = k0 % a.Cin; tap_h = tap / a.kw; tap_w = tap % a.kw; }
+        // operand tiles travel global -> registers -> LDS; TWO tiles are in flight in registers (sets 0 / 1), so that a tile's loads have
+        // two K steps (2 x 16 MFMAs per wave) to arrive before they are stored: measured alone on a CU a workgroup's K step is ~2 us
+        // with one tile in flight, of which the MFMAs are 0.85 us (scripts/experiments/conv_tail_generation.py)
+        // The K loop is kept free of branches: every load and store below is unconditional (a padding pixel is read from a valid dummy
+        // address and zeroed when it is stored; past the segment's end the filter row is clamped and the tile loaded is never used).
+        // Behind a branch the compiler has to wait for ALL outstanding loads at the next use (`s_waitcnt vmcnt(0)`), which would put
+        // the newest tile's round trip back on the critical path.
+        float4 areg0, areg1, breg0, breg1;
+        bool aok0 = false, aok1 = false;
+        auto load_tile = [&](int kc, auto set) {
+            constexpr int S = decltype(set)::value;
+            const int hi = hbase + tap_h, wi = wbase + tap_w;
+            const bool ok = am_ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+            const float* src = a.x + (ok ? ((size_t)(an * a.H + hi) * a.W + wi) * a.ldx : (size_t)0) + tap_c + ak4;
+            const float4 av = *reinterpret_cast<const float4*>(src);
+            const float4 bv = *reinterpret_cast<const float4*>(a.w + (size_t)(kc * CONV_BK + bk) * a.ldw + n0 + bn4);
+            if constexpr (S == 0) { areg0 = av; breg0 = bv; aok0 = ok; } else { areg1 = av; breg1 = bv; aok1 = ok; }
+            tap_c += CONV_BK;
+            if (tap_c >= a.Cin) { tap_c = 0; if (++tap_w == a.kw) { tap_w = 0; ++tap_h; } }
+        };
+        auto store_tile = [&](int buf, auto set) {
+            constexpr int S = decltype(set)::value;
+            const float4 av = S == 0 ? areg0 : areg1, bv = S == 0 ? breg0 : breg1;
+            const bool ok = S == 0 ? aok0 : aok1;
+            As[buf][ak4 + 0][arow] = ok ? av.x : 0.f; As[buf][ak4 + 1][arow] = ok ? av.y : 0.f;
+            As[buf][ak4 + 2][arow] = ok ? av.z : 0.f; As[buf][ak4 + 3][arow] = ok ? av.w : 0.f;
+            *reinterpret_cast<float4*>(&Bs[buf][bk][bn4]) = bv;
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        f32x16 acc[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        // K step with LDS buffer CUR holding tile kc: register set CUR is free (its tile went to LDS one step ago), set CUR ^ 1 holds
+        // tile kc + 1 (in flight since the previous step)
+        auto k_step = [&](int kc, auto cur_c) {
+            constexpr int CUR = decltype(cur_c)::value;
+            load_tile(min(kc + 2, nk - 1), std::integral_constant<int, CUR>{});
+#pragma unroll
+            for (int kk = 0; kk < CONV_BK; kk += 2) {
+                const float a0 = As[CUR][kk + kl][wm * 64 + l31], a1 = As[CUR][kk + kl][wm * 64 + 32 + l31], bf = Bs[CUR][kk + kl][wn * 32 + l31];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf, acc[1], 0, 0, 0);
+            }
+            store_tile(CUR ^ 1, std::integral_constant<int, CUR ^ 1>{});
+            __syncthreads();                                   // also fences the LDS buffers against the next segment's first store
+        };
+        load_tile(kc0, S0{});
+        load_tile(min(kc0 + 1, nk - 1), S1{});
+        store_tile(0, S0{});
+        __syncthreads();
+        int kc = kc0;
+        for (; kc + 1 < kc1; kc += 2) {
+            k_step(kc, S0{});
+            k_step(kc + 1, S1{});
+        }
+        if (kc < kc1) k_step(kc, S0{});
+        const int nl = wn * 32 + l31, n = n0 + nl, rbase = 4 * kl;
+        if (kc0 == 0 && kc1 == nk) {                           // the whole tile: ordinary epilogue
+            const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                float res[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    res[r] = (a.residual && m < M && n < a.Cout) ? a.residual[(size_t)m * a.ldr + n] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    if (m >= M || n >= a.Cout) continue;
+                    float v = acc[mi][r] + bv + res[r];
+                    if (a.act == 1) v = fmaxf(v, 0.f);
+                    else if (a.act == 2) v = 1.0f / (1.0f + expf(-v));
+                    a.y[(size_t)m * a.ldy + n] = v;
+                }
+            }
+        } else {
+            float* part = a.partial + ((size_t)worker * 2 + (kc0 == 0 ? 1 : 0)) * (BM * BN);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    part[ml * BN + nl] = acc[mi][r];
+                }
+        }
+        s += kc1 - kc0;
+    }
+}
+
+// One workgroup per (tile, band of 16 rows): adds the tile's partial segments in ascending K order and finishes the layer.
+__global__ __launch_bounds__(256)
+void conv_streamk_fixup_kernel(ConvArgs a, int tiles_m, int nk, int total, int W) {
+    constexpr int BM = 128, BN = 128;
+    const int tile = blockIdx.x, s_lo = tile * nk, s_hi = s_lo + nk;
+    auto start = [&](int w) { return (int)((long)w * total / W); };
+    int w = (int)((long)s_lo * W / total);
+    while (start(w + 1) <= s_lo) ++w;
+    while (start(w) > s_lo) --w;                               // worker w owns step s_lo
+    if (start(w + 1) >= s_hi) return;                          // it owns the whole tile and has written y itself
+    const int M = a.N * a.Ho * a.Wo;
+    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = threadIdx.x + i * 256;                   // 16 rows x 32 float4
+        const int ml = blockIdx.y * 16 + (f >> 5), nl = (f & 31) * 4;
+        const int m = m0 + ml, n = n0 + nl;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ww = w; ww < W && start(ww) < s_hi; ++ww) {
+            const int slot = start(ww) <= s_lo ? 1 : 0;       // the segment that begins the tile sits in slot 1
+            const float4 p = *reinterpret_cast<const float4*>(a.partial + ((size_t)ww * 2 + slot) * (BM * BN) + ml * BN + nl);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (m >= M || n >= a.Cout) continue;
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] += a.bias ? a.bias[n + e] : 0.f;
+            if (a.residual) o[e] += a.residual[(size_t)m * a.ldr + n + e];
+            if (a.act == 1) o[e] = fmaxf(o[e], 0.f);
+            else if (a.act == 2) o[e] = 1.0f / (1.0f + expf(-o[e]));
+        }
+        *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 

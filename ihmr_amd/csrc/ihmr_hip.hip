@@ -739,10 +739,26 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
     }
 #endif
     a.ksplit = ksplit;
+    const bool fast = (Cin % CONV_BK) == 0 && (ldx % 4) == 0;
+    // Stream-K (csrc/encoder.h): layers with a long K loop and at most three 128 x 128 tiles per CU -- at batch 64 every 3 x 3 layer and the
+    // first 1 x 1 of every bottleneck from 28 x 28 down (100, 196 or 392 tiles: 0.4-1.5 per CU) -- are shared evenly by two workers per CU.
+    // Measured per layer (scripts/prof_encoder_layers.sh, round 4): 3 x 3 layers 175-187 -> 144-158 us, 1 x 1 layers with K >= 1024
+    // 90-155 -> 77-141 us; with 32 K steps the fix-up's traffic eats the gain (85 -> 88 us), so those keep one workgroup per tile.
+    int sk_workers = 512, sk_max_tiles = 768, sk_min_nk = 64;
+#ifdef IHMR_TUNING_BUILD
+    if (const char* f = getenv("IHMR_CONV_SK")) sscanf(f, "%d %d %d", &sk_max_tiles, &sk_min_nk, &sk_workers);   // "<max tiles> <min K steps> <workers>"
+#endif
+    const long sk_tiles = blocks(0);
+    if (fast && pick == 0 && M > 64 && Cout % 128 == 0 && ldy % 4 == 0 && sk_tiles >= 64 && sk_tiles <= sk_max_tiles && nk >= sk_min_nk &&
+        sk_tiles * nk >= 4L * sk_workers && workspace && workspace_bytes >= (size_t)sk_workers * 2 * 128 * 128 * sizeof(float)) {
+        const int tiles_m = (M + 127) / 128, total = (int)(sk_tiles * nk);
+        hipLaunchKernelGGL(conv_streamk_kernel, dim3(sk_workers), dim3(512), 0, st, a, tiles_m, nk, total);
+        hipLaunchKernelGGL(conv_streamk_fixup_kernel, dim3((unsigned)sk_tiles, 8), dim3(256), 0, st, a, tiles_m, nk, total, sk_workers);
+        return (int)hipGetLastError();
+    }
     // (a persistent 1-D grid walking the tiles with a stride -- the cure for sdf_dist_kernel's slow slot refill -- was measured here too:
     // 6.95 -> 7.17 ms per 64-image pass at 6, 5 and 4 waves per SIMD alike; one workgroup per tile stays)
     const dim3 grid((M + tiles[pick][0] - 1) / tiles[pick][0], (Cout + tiles[pick][1] - 1) / tiles[pick][1], ksplit);
-    const bool fast = (Cin % CONV_BK) == 0 && (ldx % 4) == 0;
     if (fast) {
         switch (pick) {
             case 0: hipLaunchKernelGGL((conv_igemm_kernel<128, 128, true>), grid, dim3(512), 0, st, a); break;

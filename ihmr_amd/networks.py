@@ -52,10 +52,11 @@ _WS = {}
 
 
 def _splitk_workspace(device):
-    """32 MB of scratch per (device, stream) for the split-K partial sums of the small layers (ihmr_conv_igemm)."""
+    """128 MB of scratch per (device, stream) for the partial sums of ihmr_conv_igemm (split-K layers: ksplit x M x Cout floats;
+    Stream-K layers: two 64 KB tile slots per worker, 512 workers)."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _WS:
-        _WS[key] = torch.empty(8 * 1024 * 1024, device=device, dtype=torch.float32)
+        _WS[key] = torch.empty(32 * 1024 * 1024, device=device, dtype=torch.float32)
     return _WS[key]
 
 

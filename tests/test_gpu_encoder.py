@@ -36,6 +36,37 @@ def test_conv_igemm_matches_torch(cfg):
     _report(f"conv {cfg}", got, ref, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(N=33, H=14, W=14, Cin=256, Cout=256, k=3, s=1, p=1, res=True),    # 102 tiles (last M tile partial) x 144 K steps: every tile in pieces
+    dict(N=96, H=10, W=10, Cin=1024, Cout=1024, k=1, s=1, p=0, res=True),  # 600 tiles x 64 K steps: workers own whole tiles AND pieces
+    dict(N=64, H=7, W=7, Cin=512, Cout=512, k=3, s=1, p=1, res=False),     # the 7 x 7 layer of a 64-image batch: 100 tiles x 288 K steps
+    dict(N=40, H=28, W=28, Cin=128, Cout=128, k=3, s=2, p=1, res=False),   # stride 2, one column of tiles (62 -> below the limit: split-K path)
+])
+def test_conv_streamk_matches_torch(cfg):
+    """The Stream-K form of the 128 x 128 tile (csrc/encoder.h: conv_streamk_kernel + conv_streamk_fixup_kernel) on shapes that
+    select it (ihmr_conv_igemm: >= 64 K steps, 64..768 tiles), with residual + ReLU in both epilogues, and bit-identical on a re-run
+    (the partial sums are added in a fixed order)."""
+    from ihmr_amd.networks import _Packed, conv_igemm
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(cfg["N"], cfg["Cin"], cfg["H"], cfg["W"], generator=g)
+    w = torch.randn(cfg["Cout"], cfg["Cin"], cfg["k"], cfg["k"], generator=g) / np.sqrt(cfg["Cin"] * cfg["k"] ** 2)
+    b = torch.randn(cfg["Cout"], generator=g)
+    ref = torch.nn.functional.conv2d(x.cuda(), w.cuda(), b.cuda(), stride=cfg["s"], padding=cfg["p"])   # rocm fp32 conv as the reference
+    pk = _Packed(w.cuda(), b.cuda(), stride=cfg["s"], pad=cfg["p"])
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    res = None
+    if cfg["res"]:
+        res = torch.randn(cfg["N"] * Ho * Wo, cfg["Cout"], generator=g).cuda()
+        ref = ref + res.view(cfg["N"], Ho, Wo, cfg["Cout"]).permute(0, 3, 1, 2)
+    ref = torch.relu(ref).cpu()
+    y, _, _ = conv_igemm(xn, pk, cfg["N"], cfg["H"], cfg["W"], ldx=cfg["Cin"], residual=res, ldr=cfg["Cout"], act=1)
+    y2, _, _ = conv_igemm(xn, pk, cfg["N"], cfg["H"], cfg["W"], ldx=cfg["Cin"], residual=res, ldr=cfg["Cout"], act=1)
+    assert torch.equal(y, y2)
+    got = y.view(cfg["N"], Ho, Wo, cfg["Cout"]).permute(0, 3, 1, 2).cpu()
+    _report(f"stream-K conv {cfg}", got, ref, atol=3e-5, rtol=1e-5)
+
+
 def test_encoder_matches_oracle():
     from helpers import seeded_state_dict
     from ihmr_amd.networks import InterHandEncoder
