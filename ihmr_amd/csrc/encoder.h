@@ -152,23 +152,81 @@ void conv_igemm_kernel(ConvArgs a) {
         }
     }
     const int kl = lane >> 5, l31 = lane & 31;
-    if (kc0 < kc1) {
-        load_tile(kc0);
-        store_tile(0);
-    }
-    __syncthreads();
-    for (int kc = kc0; kc < kc1; ++kc) {
-        const int cur = (kc - kc0) & 1;
-        const int nk = kc1;
-        if (kc + 1 < nk) load_tile(kc + 1);   // in flight during the MFMAs below
+    auto mfma_tile = [&](int cur) {
 #pragma unroll
         for (int kk = 0; kk < CONV_BK; kk += 2) {
             const float a0 = As[cur][kk + kl][wm * 64 + l31], a1 = As[cur][kk + kl][wm * 64 + 32 + l31], bf = Bs[cur][kk + kl][wn * 32 + l31];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf, acc[1], 0, 0, 0);
         }
-        if (kc + 1 < nk) store_tile(cur ^ 1);  // the other buffer: its readers finished before the previous barrier
+    };
+    // Two operand tiles in flight in registers and a branch-free K loop (see conv_streamk_kernel) for the tiles that run at 4-5 waves per
+    // SIMD: 128 x 64 (the Cout = 64 layers at 56 x 56) 183 -> 168 us (3 x 3) and 100 -> 88 us (1 x 1, 256 -> 64) per call; the 128 x 128 tile,
+    // held to 80 registers for three workgroups per CU, loses 1-2 % with it and keeps one tile in flight.
+    if constexpr (FAST && !(BM == 128 && BN == 128)) {
+        const int nk_last = Kpad / CONV_BK - 1;
+        float4 ar0[A_F4], ar1[A_F4], br0[B_F4], br1[B_F4];
+        bool ok0[A_F4], ok1[A_F4];
+        auto load2 = [&](int kc, auto set) {
+            constexpr int S = decltype(set)::value;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int hi = aho[i] * a.stride + tap_h - a.pad, wi = awo[i] * a.stride + tap_w - a.pad;
+                const bool ok = am_ok[i] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                const float4 v = *reinterpret_cast<const float4*>(a.x + (ok ? ((size_t)(an[i] * a.H + hi) * a.W + wi) * a.ldx : (size_t)0) + tap_c + ak4[i]);
+                if constexpr (S == 0) { ar0[i] = v; ok0[i] = ok; } else { ar1[i] = v; ok1[i] = ok; }
+            }
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int g = tid + i * THREADS;
+                const float4 v = *reinterpret_cast<const float4*>(a.w + (size_t)(kc * CONV_BK + g / B_F4_PER_ROW) * a.ldw + n0 + (g % B_F4_PER_ROW) * 4);
+                if constexpr (S == 0) br0[i] = v; else br1[i] = v;
+            }
+            tap_c += CONV_BK;
+            if (tap_c >= a.Cin) { tap_c = 0; if (++tap_w == a.kw) { tap_w = 0; ++tap_h; } }
+        };
+        auto store2 = [&](int buf, auto set) {
+            constexpr int S = decltype(set)::value;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const float4 v = S == 0 ? ar0[i] : ar1[i];
+                const bool ok = S == 0 ? ok0[i] : ok1[i];
+                As[buf][ak4[i] + 0][arow[i]] = ok ? v.x : 0.f; As[buf][ak4[i] + 1][arow[i]] = ok ? v.y : 0.f;
+                As[buf][ak4[i] + 2][arow[i]] = ok ? v.z : 0.f; As[buf][ak4[i] + 3][arow[i]] = ok ? v.w : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int g = tid + i * THREADS;
+                *reinterpret_cast<float4*>(&Bs[buf][g / B_F4_PER_ROW][(g % B_F4_PER_ROW) * 4]) = S == 0 ? br0[i] : br1[i];
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        if (kc0 < kc1) {
+            load2(kc0, S0{});
+            load2(min(kc0 + 1, nk_last), S1{});
+            store2(0, S0{});
+        }
         __syncthreads();
+        int kc = kc0;
+        for (; kc + 1 < kc1; kc += 2) {
+            load2(min(kc + 2, nk_last), S0{}); mfma_tile(0); store2(1, S1{}); __syncthreads();
+            load2(min(kc + 3, nk_last), S1{}); mfma_tile(1); store2(0, S0{}); __syncthreads();
+        }
+        if (kc < kc1) { mfma_tile(0); __syncthreads(); }
+    } else {
+        if (kc0 < kc1) {
+            load_tile(kc0);
+            store_tile(0);
+        }
+        __syncthreads();
+        for (int kc = kc0; kc < kc1; ++kc) {
+            const int cur = (kc - kc0) & 1;
+            if (kc + 1 < kc1) load_tile(kc + 1);   // in flight during the MFMAs below
+            mfma_tile(cur);
+            if (kc + 1 < kc1) store_tile(cur ^ 1); // the other buffer: its readers finished before the previous barrier
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias (+ residual) (+ activation); C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
