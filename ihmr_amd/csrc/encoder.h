@@ -298,25 +298,34 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs a) {
 // completely gets the ordinary epilogue; partial sums go to the worker's two 64 KB slots of the workspace (slot 1: the segment
 // that begins a tile, slot 0: any other) and conv_streamk_fixup_kernel adds a tile's segments in ascending K order -- a fixed
 // order, so the result does not depend on timing -- and applies bias / residual / activation.
+// Zero page: a padding pixel's loader reads from here instead of the image (one unconditional load per step, no select afterwards)
+__device__ float g_conv_zero[2048 + 64];
+
+// The K loop is written for the fewest VECTOR-ALU instructions per MFMA.  Measured (scripts/experiments/dummy_valu.sh): 32 extra v_add per wave
+// and K step cost the 3 x 3 layers 137 -> 149 us, 64 cost 158 us -- plain VALU work does NOT run in the shadow of the MFMAs of the other
+// waves of the SIMD, it is added to them (4 cycles per instruction against 64 per MFMA; the one-tile-per-workgroup kernel of rounds 1-3
+// issued 4.0 VALU instructions per MFMA = a quarter of its MFMA time).  So: operand pointers are carried and incremented (the gather's
+// index arithmetic runs only when the filter tap changes, every Cin / 16 steps, under a wave-uniform branch that contains no load), padding
+// pixels are read from a zero page (no select), A is stored in LDS with rows r and r + 32 interleaved so that a lane's two A operands are
+// ONE 8-byte read (the compiler pairs two of them into a ds_read2_b64), B rows are 160 floats apart (the two k rows of a read hit
+// disjoint banks): ~10 VALU instructions per K step and wave instead of ~50.
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
 void conv_streamk_kernel(ConvArgs a, int tiles_m, int nk, int total) {
-    constexpr int BM = 128, BN = 128, LDA = BM + 5, LDB = BN + 4;
-    __shared__ float As[2][CONV_BK][LDA];
-    __shared__ float Bs[2][CONV_BK][LDB];
+    constexpr int BM = 128, BN = 128, LDA = BM + 4, LDB = BN + 32;
+    __shared__ __attribute__((aligned(16))) float As[2][CONV_BK][LDA];   // column c = 64 h + 2 j + b holds tile row 64 h + 32 b + j
+    __shared__ __attribute__((aligned(16))) float Bs[2][CONV_BK][LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3, kl = lane >> 5, l31 = lane & 31;
     const int M = a.N * a.Ho * a.Wo;
-    const int arow = tid >> 2, ak4 = (tid & 3) * 4;        // A loader: one float4 per thread (row, 4 consecutive k)
+    const int acol = tid >> 2, ak4 = (tid & 3) * 4;        // A loader: one float4 per thread: LDS column acol, 4 consecutive k
+    const int arow = (acol & 64) | ((acol & 1) << 5) | ((acol >> 1) & 31);
     const int bk = tid >> 5, bn4 = (tid & 31) * 4;         // B loader: one float4 per thread (k row, 4 consecutive n)
     // consecutive workgroup ids go to the 8 XCDs round-robin; worker numbers are handed out so that an XCD's workers own ONE contiguous
     // eighth of the step sequence -- neighbouring tiles, whose activation rows and filter columns then meet in that XCD's L2
-#ifndef CONV_SK_NO_XCD
     const int worker = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // gridDim.x is a multiple of 8
-#else
-    const int worker = blockIdx.x;
-#endif
     int s = (int)((long)worker * total / gridDim.x);
     const int s_end = (int)((long)(worker + 1) * total / gridDim.x);
+    const size_t bstep = (size_t)CONV_BK * a.ldw;
     while (s < s_end) {
         const int tile = s / nk, kc0 = s - tile * nk, kc1 = min(nk, kc0 + (s_end - s));
         const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
@@ -325,34 +334,36 @@ void conv_streamk_kernel(ConvArgs a, int tiles_m, int nk, int total) {
         int an = 0, aho = 0, awo = 0;
         if (am_ok) { an = am / (a.Ho * a.Wo); const int r = am % (a.Ho * a.Wo); aho = r / a.Wo; awo = r % a.Wo; }
         const int hbase = aho * a.stride - a.pad, wbase = awo * a.stride - a.pad;
-        int tap_c, tap_h, tap_w;
+        int tap_c, tap_h, tap_w;                           // wave-uniform: filter tap / channel offset of the NEXT tile to load
         { const int k0 = kc0 * CONV_BK, tap = k0 / a.Cin; tap_c = k0 % a.Cin; tap_h = tap / a.kw; tap_w = tap % a.kw; }
-        // operand tiles travel global -> registers -> LDS; TWO tiles are in flight in registers (sets 0 / 1), so that a tile's loads have
-        // two K steps (2 x 16 MFMAs per wave) to arrive before they are stored: measured alone on a CU a workgroup's K step is ~2 us
-        // with one tile in flight, of which the MFMAs are 0.85 us (scripts/experiments/conv_tail_generation.py)
-        // The K loop is kept free of branches: every load and store below is unconditional (a padding pixel is read from a valid dummy
-        // address and zeroed when it is stored; past the segment's end the filter row is clamped and the tile loaded is never used).
-        // Behind a branch the compiler has to wait for ALL outstanding loads at the next use (`s_waitcnt vmcnt(0)`), which would put
-        // the newest tile's round trip back on the critical path.
-        float4 areg0, areg1, breg0, breg1;
-        bool aok0 = false, aok1 = false;
-        auto load_tile = [&](int kc, auto set) {
-            constexpr int S = decltype(set)::value;
+        const float* pa;                                   // this thread's 4 channels of the next tile's pixel (or the zero page)
+        auto retap = [&]() {
             const int hi = hbase + tap_h, wi = wbase + tap_w;
             const bool ok = am_ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-            const float* src = a.x + (ok ? ((size_t)(an * a.H + hi) * a.W + wi) * a.ldx : (size_t)0) + tap_c + ak4;
-            const float4 av = *reinterpret_cast<const float4*>(src);
-            const float4 bv = *reinterpret_cast<const float4*>(a.w + (size_t)(kc * CONV_BK + bk) * a.ldw + n0 + bn4);
-            if constexpr (S == 0) { areg0 = av; breg0 = bv; aok0 = ok; } else { areg1 = av; breg1 = bv; aok1 = ok; }
-            tap_c += CONV_BK;
-            if (tap_c >= a.Cin) { tap_c = 0; if (++tap_w == a.kw) { tap_w = 0; ++tap_h; } }
+            pa = (ok ? a.x + ((size_t)(an * a.H + hi) * a.W + wi) * a.ldx : g_conv_zero) + tap_c + ak4;
+        };
+        retap();
+        const float* pb = a.w + (size_t)(kc0 * CONV_BK + bk) * a.ldw + n0 + bn4;
+        int kb = kc0;                                      // K tile pb points at (clamped to the last one: loads past the segment are unused)
+        // Two operand tiles are in flight in registers (sets 0 / 1): a tile's loads have two K steps to arrive.  Every load and LDS store
+        // of the loop is unconditional -- behind a branch hipcc waits for ALL outstanding loads at the next use (`s_waitcnt vmcnt(0)`),
+        // which would put the newest tile's round trip back on the critical path.
+        float4 areg0, areg1, breg0, breg1;
+        auto load_tile = [&](auto set) {
+            constexpr int S = decltype(set)::value;
+            const float4 av = *reinterpret_cast<const float4*>(pa);
+            const float4 bv = *reinterpret_cast<const float4*>(pb);
+            if constexpr (S == 0) { areg0 = av; breg0 = bv; } else { areg1 = av; breg1 = bv; }
+            pb += kb + 1 < nk ? bstep : 0;
+            kb += kb + 1 < nk ? 1 : 0;
+            tap_c += CONV_BK; pa += CONV_BK;
+            if (tap_c >= a.Cin) { tap_c = 0; if (++tap_w == a.kw) { tap_w = 0; ++tap_h; } retap(); }
         };
         auto store_tile = [&](int buf, auto set) {
             constexpr int S = decltype(set)::value;
             const float4 av = S == 0 ? areg0 : areg1, bv = S == 0 ? breg0 : breg1;
-            const bool ok = S == 0 ? aok0 : aok1;
-            As[buf][ak4 + 0][arow] = ok ? av.x : 0.f; As[buf][ak4 + 1][arow] = ok ? av.y : 0.f;
-            As[buf][ak4 + 2][arow] = ok ? av.z : 0.f; As[buf][ak4 + 3][arow] = ok ? av.w : 0.f;
+            As[buf][ak4 + 0][acol] = av.x; As[buf][ak4 + 1][acol] = av.y;
+            As[buf][ak4 + 2][acol] = av.z; As[buf][ak4 + 3][acol] = av.w;
             *reinterpret_cast<float4*>(&Bs[buf][bk][bn4]) = bv;
         };
         using S0 = std::integral_constant<int, 0>;
@@ -364,28 +375,29 @@ void conv_streamk_kernel(ConvArgs a, int tiles_m, int nk, int total) {
             for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
         // K step with LDS buffer CUR holding tile kc: register set CUR is free (its tile went to LDS one step ago), set CUR ^ 1 holds
         // tile kc + 1 (in flight since the previous step)
-        auto k_step = [&](int kc, auto cur_c) {
+        auto k_step = [&](auto cur_c) {
             constexpr int CUR = decltype(cur_c)::value;
-            load_tile(min(kc + 2, nk - 1), std::integral_constant<int, CUR>{});
+            load_tile(std::integral_constant<int, CUR>{});
 #pragma unroll
             for (int kk = 0; kk < CONV_BK; kk += 2) {
-                const float a0 = As[CUR][kk + kl][wm * 64 + l31], a1 = As[CUR][kk + kl][wm * 64 + 32 + l31], bf = Bs[CUR][kk + kl][wn * 32 + l31];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf, acc[1], 0, 0, 0);
+                const float2 av = *reinterpret_cast<const float2*>(&As[CUR][kk + kl][wm * 64 + 2 * l31]);
+                const float bf = Bs[CUR][kk + kl][wn * 32 + l31];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf, acc[1], 0, 0, 0);
             }
             store_tile(CUR ^ 1, std::integral_constant<int, CUR ^ 1>{});
             __syncthreads();                                   // also fences the LDS buffers against the next segment's first store
         };
-        load_tile(kc0, S0{});
-        load_tile(min(kc0 + 1, nk - 1), S1{});
+        load_tile(S0{});
+        load_tile(S1{});
         store_tile(0, S0{});
         __syncthreads();
         int kc = kc0;
         for (; kc + 1 < kc1; kc += 2) {
-            k_step(kc, S0{});
-            k_step(kc + 1, S1{});
+            k_step(S0{});
+            k_step(S1{});
         }
-        if (kc < kc1) k_step(kc, S0{});
+        if (kc < kc1) k_step(S0{});
         const int nl = wn * 32 + l31, n = n0 + nl, rbase = 4 * kl;
         if (kc0 == 0 && kc1 == nk) {                           // the whole tile: ordinary epilogue
             const float bv = a.bias ? a.bias[n] : 0.f;
