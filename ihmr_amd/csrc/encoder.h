@@ -298,6 +298,19 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs a) {
 // completely gets the ordinary epilogue; partial sums go to the worker's two 64 KB slots of the workspace (slot 1: the segment
 // that begins a tile, slot 0: any other) and conv_streamk_fixup_kernel adds a tile's segments in ascending K order -- a fixed
 // order, so the result does not depend on timing -- and applies bias / residual / activation.
+// Phase stamps (experiment builds only, -DCONV_STAMPS; scripts/experiments/conv_stamps.py): shader-clock time thread 0 of every worker spends
+// in each phase of conv_streamk_kernel: 0 segment prologue, 1 load issue, 2 LDS reads + MFMA issue, 3 wait for the older tile + LDS stores,
+// 4 barrier, 5 epilogue / partial store; 6 = K steps, 7 = segments
+#ifdef CONV_STAMPS
+__device__ long long g_conv_stamps[1024][10];   // 8 = the worker's life in shader clocks, 9 = in 100 MHz wall-clock ticks
+// (sums are kept in registers and written once at the end: a read-modify-write of global memory per stamp would drain the operand loads)
+#define CONV_TK(k) do { const long long now_ = (long long)__builtin_readcyclecounter(); tk_acc_[k] += now_ - tk_prev_; tk_prev_ = now_; } while (0)
+#define CONV_CNT(k) do { tk_acc_[k] += 1; } while (0)
+#else
+#define CONV_TK(k)
+#define CONV_CNT(k)
+#endif
+
 // Zero page: a padding pixel's loader reads from here instead of the image (one unconditional load per step, no select afterwards)
 __device__ float g_conv_zero[2048 + 64];
 
@@ -326,6 +339,11 @@ void conv_streamk_kernel(ConvArgs a, int tiles_m, int nk, int total) {
     int s = (int)((long)worker * total / gridDim.x);
     const int s_end = (int)((long)(worker + 1) * total / gridDim.x);
     const size_t bstep = (size_t)CONV_BK * a.ldw;
+#ifdef CONV_STAMPS
+    long long tk_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tk_prev_ = (long long)__builtin_readcyclecounter();
+    const long long tk_c0_ = tk_prev_, tk_w0_ = (long long)wall_clock64();
+#endif
     while (s < s_end) {
         const int tile = s / nk, kc0 = s - tile * nk, kc1 = min(nk, kc0 + (s_end - s));
         const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
@@ -378,6 +396,15 @@ void conv_streamk_kernel(ConvArgs a, int tiles_m, int nk, int total) {
         auto k_step = [&](auto cur_c) {
             constexpr int CUR = decltype(cur_c)::value;
             load_tile(std::integral_constant<int, CUR>{});
+#ifdef CONV_DUMMY_VALU
+            {   // experiment (scripts/experiments/dummy_valu.sh): does plain VALU work run in the shadow of the MFMAs?
+                int dummy_ = kb;
+#pragma unroll
+                for (int q = 0; q < CONV_DUMMY_VALU; ++q) asm volatile("v_add_u32 %0, %0, 1" : "+v"(dummy_));
+                if (dummy_ == -12345) acc[0][0] = 1.f;
+            }
+#endif
+            CONV_TK(1);
 #pragma unroll
             for (int kk = 0; kk < CONV_BK; kk += 2) {
                 const float2 av = *reinterpret_cast<const float2*>(&As[CUR][kk + kl][wm * 64 + 2 * l31]);
@@ -385,13 +412,17 @@ void conv_streamk_kernel(ConvArgs a, int tiles_m, int nk, int total) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf, acc[1], 0, 0, 0);
             }
+            CONV_TK(2);
             store_tile(CUR ^ 1, std::integral_constant<int, CUR ^ 1>{});
+            CONV_TK(3);
             __syncthreads();                                   // also fences the LDS buffers against the next segment's first store
+            CONV_TK(4); CONV_CNT(6);
         };
         load_tile(S0{});
         load_tile(S1{});
         store_tile(0, S0{});
         __syncthreads();
+        CONV_TK(0); CONV_CNT(7);
         int kc = kc0;
         for (; kc + 1 < kc1; kc += 2) {
             k_step(S0{});
@@ -429,8 +460,16 @@ void conv_streamk_kernel(ConvArgs a, int tiles_m, int nk, int total) {
                     part[ml * BN + nl] = acc[mi][r];
                 }
         }
+        CONV_TK(5);
         s += kc1 - kc0;
     }
+#ifdef CONV_STAMPS
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 8; ++k) g_conv_stamps[blockIdx.x][k] += tk_acc_[k];
+        g_conv_stamps[blockIdx.x][8] += (long long)__builtin_readcyclecounter() - tk_c0_;
+        g_conv_stamps[blockIdx.x][9] += (long long)wall_clock64() - tk_w0_;
+    }
+#endif
 }
 
 // One workgroup per (tile, band of 16 rows): adds the tile's partial segments in ascending K order and finishes the layer.

@@ -1031,6 +1031,18 @@ extern "C" int ihmr_debug_stamps(long long* host, int zero) {
 }
 #endif
 
+#ifdef CONV_STAMPS
+// experiment builds only (scripts/experiments/conv_stamps.py): zero = 1 clears, zero = 0 copies the 1024 x 10 phase sums of conv_streamk_kernel out
+extern "C" int ihmr_debug_conv_stamps(long long* host, int zero) {
+    HIP_TRY(hipDeviceSynchronize());
+    void* p;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_conv_stamps)));
+    if (zero) { HIP_TRY(hipMemset(p, 0, sizeof(long long) * 1024 * 10)); return 0; }
+    HIP_TRY(hipMemcpy(host, p, sizeof(long long) * 1024 * 10, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
 #ifdef TAIL_STAMPS
 // experiment builds only (scripts/tail_stamps.py): zero = 1 clears, zero = 0 copies the 3 x 4096 x 8 phase sums of opt_tail_kernel out
 extern "C" int ihmr_debug_tail_stamps(long long* host, int zero) {

@@ -25,13 +25,14 @@ for name, N, H, cin, cout, k in (("3x3 256 @14", 64, 14, 256, 256, 3), ("3x3 128
     for _ in range(R):
         conv_igemm(x, pk, N, H, H, cin, act=1)
     e1.record(); torch.cuda.synchronize()
-    raw = np.zeros(1024 * 8, np.int64)
+    raw = np.zeros(1024 * 10, np.int64)
     L.ihmr_debug_conv_stamps(raw.ctypes.data, 0)
-    raw = raw.reshape(1024, 8)[:512].astype(np.float64)
+    raw = raw.reshape(1024, 10)[:512].astype(np.float64)
+    ghz = raw[:, 8].sum() / (raw[:, 9].sum() * 10.0)          # shader clocks per ns of the 100 MHz wall clock
     steps, segs = raw[:, 6].mean() / R, raw[:, 7].mean() / R
     per_step = raw[:, 1:5].sum(0) / raw[:, 6].sum() / 2403.0
     per_seg = raw[:, [0, 5]].sum(0) / raw[:, 7].sum() / 2403.0
     tot = raw[:, :6].sum(1) / R / 2403.0
     print(f"{name}: {e0.elapsed_time(e1) * 1e3 / R:.1f} us per call (main + fix-up); worker: {steps:.1f} K steps in {segs:.2f} segments, {tot.mean():.1f} us (max {tot.max():.1f}); "
           f"per K step: load issue {per_step[0]:.3f}, LDS reads + MFMA issue {per_step[1]:.3f}, wait + LDS stores {per_step[2]:.3f}, barrier {per_step[3]:.3f} = {per_step.sum():.3f} us; "
-          f"per segment: prologue {per_seg[0]:.2f}, epilogue {per_seg[1]:.2f} us")
+          f"per segment: prologue {per_seg[0]:.2f}, epilogue {per_seg[1]:.2f} us (all at 2.403 shader clocks per ns); shader clock while the workers ran: {ghz:.3f} GHz")
