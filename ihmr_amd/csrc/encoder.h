@@ -35,6 +35,9 @@ struct ConvArgs {
     int ksplit;             // gridDim.z; 1 = no split
 };
 
+// Zero page: a padding pixel's loader reads from here instead of the image (one unconditional load per step, no select afterwards)
+__device__ float g_conv_zero[2048 + 64];
+
 // FAST: Cin % 16 == 0 (every layer but the stem), compiled without the generic gather so that its per-loader state does not
 // cost registers or a branch per K step;
 // and the 128 x 128 tile is held to 80 registers (three resident workgroups per CU instead of two; measured: 4 waves per SIMD
@@ -49,49 +52,151 @@ __attribute__((amdgpu_waves_per_eu((FAST && BM == 128 && BN == 128) ? CONV_WAVES
 void conv_igemm_kernel(ConvArgs a) {
     constexpr int WN_WAVES = BN / 32;                      // waves along n; each wave owns a 64 x 32 sub-tile
     constexpr int THREADS = (BM / 64) * WN_WAVES * 64;
-    constexpr int LDA = BM + 5, LDB = BN + 4;              // 8*LDA % 32 != 0: the two k-halves of a row hit different banks
+    // LDS layouts.  FAST: A column c = 64 h + 2 j + b holds tile row 64 h + 32 b + j, so that a lane's two A operands (rows j and j + 32 of its
+    // wave's 64-row block) are ONE 8-byte read; LDA = BM + 4 keeps the loaders' stores (16 consecutive columns x 4 k rows per wave) and
+    // LDB = BN + 32 the B reads (32 consecutive columns x 2 k rows) free of bank conflicts.  Generic (stem): rows in order, scalar reads.
+    constexpr int LDA = FAST ? BM + 4 : BM + 5, LDB = FAST ? BN + 32 : BN + 4;
     constexpr int A_F4 = BM * CONV_BK / 4 / THREADS;       // float4 loads of A per thread (1 or 2)
     constexpr int B_F4 = CONV_BK * BN / 4 / THREADS;       // float4 loads of B per thread (1 or 2)
-    __shared__ float As[2][CONV_BK][LDA];
-    __shared__ float Bs[2][CONV_BK][LDB];
+    constexpr int B_F4_PER_ROW = BN / 4;
+    __shared__ __attribute__((aligned(16))) float As[2][CONV_BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][CONV_BK][LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
+    const int kl = lane >> 5, l31 = lane & 31;
     const int M = a.N * a.Ho * a.Wo, K = a.kh * a.kw * a.Cin, Kpad = (K + CONV_BK - 1) / CONV_BK * CONV_BK;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    constexpr bool fast = FAST;                            // a 16-wide K chunk never straddles a filter tap
+    // split-K: this workgroup owns K tiles [kc0, kc1)
+    const int nk_all = Kpad / CONV_BK, nk_per = (nk_all + a.ksplit - 1) / a.ksplit;
+    const int kc0 = blockIdx.z * nk_per, kc1 = min(nk_all, kc0 + nk_per);
 
-    // ---- A loader: float4 f = tid + i*THREADS -> (row f / 4, 4 consecutive k at (f % 4) * 4)
-    int arow[A_F4], ak4[A_F4], an[A_F4], aho[A_F4], awo[A_F4];
-    bool am_ok[A_F4];
+    f32x16 acc[2];
 #pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-        const int f = tid + i * THREADS;
-        arow[i] = f >> 2; ak4[i] = (f & 3) * 4;
-        const int am = m0 + arow[i];
-        am_ok[i] = am < M;
-        an[i] = 0; aho[i] = 0; awo[i] = 0;
-        if (am_ok[i]) { an[i] = am / (a.Ho * a.Wo); const int r = am % (a.Ho * a.Wo); aho[i] = r / a.Wo; awo[i] = r % a.Wo; }
-    }
-    // ---- B loader: float4 g = tid + i*THREADS -> (k row g / (BN/4), 4 consecutive n)
-    constexpr int B_F4_PER_ROW = BN / 4;
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
-    float4 areg[A_F4], breg[B_F4];
-    int tap_h = 0, tap_w = 0, tap_c = 0;                   // filter tap / channel offset of the NEXT tile to load (fast path)
-    int gc[A_F4], gfw[A_F4], gfh[A_F4];                    // generic path: (channel, tap column, tap row) of each loader's element 0
-    const int gstep_c = CONV_BK % a.Cin, gstep_t = CONV_BK / a.Cin;
-    auto load_tile = [&](int kc) {
-        const int k0 = kc * CONV_BK;
+    if constexpr (FAST) {
+        // Cin % 16 == 0 (every layer but the stem): a 16-wide K chunk never straddles a filter tap.  The K loop follows conv_streamk_kernel
+        // (below): as few vector-ALU instructions per MFMA as possible -- they are NOT hidden behind the MFMAs of the SIMD's other waves --
+        // i.e. carried operand pointers (the gather's index arithmetic runs only when the tap changes, under a wave-uniform branch without
+        // loads), padding pixels read from a zero page, two operand tiles in flight in registers, every load and LDS store unconditional.
+        const int ak4 = (tid & 3) * 4;                     // THREADS % 4 == 0: the same k offset for every float4 of a thread
+        int acol[A_F4], an[A_F4], hbase[A_F4], wbase[A_F4];
+        bool am_ok[A_F4];
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            if (fast) {
-                const int hi = aho[i] * a.stride + tap_h - a.pad, wi = awo[i] * a.stride + tap_w - a.pad;
+            acol[i] = (tid + i * THREADS) >> 2;
+            const int am = m0 + ((acol[i] & 64) | ((acol[i] & 1) << 5) | ((acol[i] >> 1) & 31));
+            am_ok[i] = am < M;
+            int aho = 0, awo = 0;
+            an[i] = 0;
+            if (am_ok[i]) { an[i] = am / (a.Ho * a.Wo); const int r = am % (a.Ho * a.Wo); aho = r / a.Wo; awo = r % a.Wo; }
+            hbase[i] = aho * a.stride - a.pad; wbase[i] = awo * a.stride - a.pad;
+        }
+        int tap_c, tap_h, tap_w;                           // wave-uniform: filter tap / channel offset of the NEXT tile to load
+        { const int k0 = kc0 * CONV_BK, tap = k0 / a.Cin; tap_c = k0 % a.Cin; tap_h = tap / a.kw; tap_w = tap % a.kw; }
+        const float* pa[A_F4];
+        auto retap = [&]() {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int hi = hbase[i] + tap_h, wi = wbase[i] + tap_w;
                 const bool ok = am_ok[i] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-                areg[i] = ok ? *reinterpret_cast<const float4*>(a.x + ((size_t)(an[i] * a.H + hi) * a.W + wi) * a.ldx + tap_c + ak4[i])
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                // generic gather (Cin not a multiple of 16, i.e. the 7x7 stem with Cin = 3): element e of the float4 is
-                // k = k0 + ak4 + e; its (channel, tap column, tap row) is carried incrementally, no div / mod in the loop
+                pa[i] = (ok ? a.x + ((size_t)(an[i] * a.H + hi) * a.W + wi) * a.ldx : g_conv_zero) + tap_c + ak4;
+            }
+        };
+        retap();
+        const float* pb[B_F4];
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int g = tid + i * THREADS;
+            pb[i] = a.w + (size_t)(kc0 * CONV_BK + g / B_F4_PER_ROW) * a.ldw + n0 + (g % B_F4_PER_ROW) * 4;   // ldw >= n0 + BN, zero padded
+        }
+        const size_t bstep = (size_t)CONV_BK * a.ldw;
+        int kb = kc0;                                      // K tile pb points at, clamped to the last one (loads past the end are unused)
+        float4 ar0[A_F4], ar1[A_F4], br0[B_F4], br1[B_F4];
+        auto load2 = [&](auto set) {
+            constexpr int S = decltype(set)::value;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(pa[i]);
+                if constexpr (S == 0) ar0[i] = v; else ar1[i] = v;
+                pa[i] += CONV_BK;
+            }
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(pb[i]);
+                if constexpr (S == 0) br0[i] = v; else br1[i] = v;
+                pb[i] += kb + 1 < nk_all ? bstep : 0;
+            }
+            kb += kb + 1 < nk_all ? 1 : 0;
+            tap_c += CONV_BK;
+            if (tap_c >= a.Cin) { tap_c = 0; if (++tap_w == a.kw) { tap_w = 0; ++tap_h; } retap(); }
+        };
+        auto store2 = [&](int buf, auto set) {
+            constexpr int S = decltype(set)::value;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const float4 v = S == 0 ? ar0[i] : ar1[i];
+                As[buf][ak4 + 0][acol[i]] = v.x; As[buf][ak4 + 1][acol[i]] = v.y;
+                As[buf][ak4 + 2][acol[i]] = v.z; As[buf][ak4 + 3][acol[i]] = v.w;
+            }
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int g = tid + i * THREADS;
+                *reinterpret_cast<float4*>(&Bs[buf][g / B_F4_PER_ROW][(g % B_F4_PER_ROW) * 4]) = S == 0 ? br0[i] : br1[i];
+            }
+        };
+        auto mfma2 = [&](int cur) {
+#pragma unroll
+            for (int kk = 0; kk < CONV_BK; kk += 2) {
+                const float2 av = *reinterpret_cast<const float2*>(&As[cur][kk + kl][wm * 64 + 2 * l31]);
+                const float bf = Bs[cur][kk + kl][wn * 32 + l31];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf, acc[1], 0, 0, 0);
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        if (kc0 < kc1) {
+            load2(S0{});
+            load2(S1{});
+            store2(0, S0{});
+        }
+        __syncthreads();
+        int kc = kc0;
+        for (; kc + 1 < kc1; kc += 2) {
+            load2(S0{}); mfma2(0); store2(1, S1{}); __syncthreads();
+            load2(S1{}); mfma2(1); store2(0, S0{}); __syncthreads();
+        }
+        if (kc < kc1) { mfma2(0); __syncthreads(); }
+    } else {
+        // ---- generic gather (Cin not a multiple of 16, i.e. the 7x7 stem with Cin = 3): one tile in flight
+        int arow[A_F4], ak4[A_F4], an[A_F4], aho[A_F4], awo[A_F4];
+        bool am_ok[A_F4];
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int f = tid + i * THREADS;               // float4 f -> (row f / 4, 4 consecutive k at (f % 4) * 4)
+            arow[i] = f >> 2; ak4[i] = (f & 3) * 4;
+            const int am = m0 + arow[i];
+            am_ok[i] = am < M;
+            an[i] = 0; aho[i] = 0; awo[i] = 0;
+            if (am_ok[i]) { an[i] = am / (a.Ho * a.Wo); const int r = am % (a.Ho * a.Wo); aho[i] = r / a.Wo; awo[i] = r % a.Wo; }
+        }
+        float4 areg[A_F4], breg[B_F4];
+        int gc[A_F4], gfw[A_F4], gfh[A_F4];                // (channel, tap column, tap row) of each loader's element 0
+        const int gstep_c = CONV_BK % a.Cin, gstep_t = CONV_BK / a.Cin;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int k = kc0 * CONV_BK + ak4[i], tap = k / a.Cin;
+            gc[i] = k % a.Cin; gfw[i] = tap % a.kw; gfh[i] = tap / a.kw;
+        }
+        auto load_tile = [&](int kc) {
+            const int k0 = kc * CONV_BK;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                // element e of the float4 is k = k0 + ak4 + e; its (channel, tap column, tap row) is carried incrementally, no div / mod in the loop
                 float v[4];
                 int c = gc[i], fw = gfw[i], fh = gfh[i];
 #pragma unroll
@@ -111,110 +216,25 @@ void conv_igemm_kernel(ConvArgs a) {
                 while (gfw[i] >= a.kw) { gfw[i] -= a.kw; ++gfh[i]; }
                 areg[i] = make_float4(v[0], v[1], v[2], v[3]);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            const int g = tid + i * THREADS;
-            const int k = k0 + g / B_F4_PER_ROW, n4 = (g % B_F4_PER_ROW) * 4;
-            breg[i] = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.ldw + n0 + n4);   // ldw >= n0 + BN, zero padded
-        }
-        tap_c += CONV_BK;                                   // advance to the next tile's tap (fast path only)
-        if (tap_c >= a.Cin) { tap_c = 0; if (++tap_w == a.kw) { tap_w = 0; ++tap_h; } }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            As[buf][ak4[i] + 0][arow[i]] = areg[i].x; As[buf][ak4[i] + 1][arow[i]] = areg[i].y;
-            As[buf][ak4[i] + 2][arow[i]] = areg[i].z; As[buf][ak4[i] + 3][arow[i]] = areg[i].w;
-        }
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            const int g = tid + i * THREADS;
-            *reinterpret_cast<float4*>(&Bs[buf][g / B_F4_PER_ROW][(g % B_F4_PER_ROW) * 4]) = breg[i];
-        }
-    };
-
-    f32x16 acc[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-
-    // split-K: this workgroup owns K tiles [kc0, kc1)
-    const int nk_all = Kpad / CONV_BK, nk_per = (nk_all + a.ksplit - 1) / a.ksplit;
-    const int kc0 = blockIdx.z * nk_per, kc1 = min(nk_all, kc0 + nk_per);
-    if (fast) { const int k0 = kc0 * CONV_BK, tap = k0 / a.Cin; tap_c = k0 % a.Cin; tap_h = tap / a.kw; tap_w = tap % a.kw; }
-    else {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int k = kc0 * CONV_BK + ak4[i], tap = k / a.Cin;
-            gc[i] = k % a.Cin; gfw[i] = tap % a.kw; gfh[i] = tap / a.kw;
-        }
-    }
-    const int kl = lane >> 5, l31 = lane & 31;
-    auto mfma_tile = [&](int cur) {
-#pragma unroll
-        for (int kk = 0; kk < CONV_BK; kk += 2) {
-            const float a0 = As[cur][kk + kl][wm * 64 + l31], a1 = As[cur][kk + kl][wm * 64 + 32 + l31], bf = Bs[cur][kk + kl][wn * 32 + l31];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf, acc[1], 0, 0, 0);
-        }
-    };
-    // Two operand tiles in flight in registers and a branch-free K loop (see conv_streamk_kernel) for the tiles that run at 4-5 waves per
-    // SIMD: 128 x 64 (the Cout = 64 layers at 56 x 56) 183 -> 168 us (3 x 3) and 100 -> 88 us (1 x 1, 256 -> 64) per call; the 128 x 128 tile,
-    // held to 80 registers for three workgroups per CU, loses 1-2 % with it and keeps one tile in flight.
-    if constexpr (FAST && !(BM == 128 && BN == 128)) {
-        const int nk_last = Kpad / CONV_BK - 1;
-        float4 ar0[A_F4], ar1[A_F4], br0[B_F4], br1[B_F4];
-        bool ok0[A_F4], ok1[A_F4];
-        auto load2 = [&](int kc, auto set) {
-            constexpr int S = decltype(set)::value;
+            for (int i = 0; i < B_F4; ++i) {
+                const int g = tid + i * THREADS;
+                const int k = k0 + g / B_F4_PER_ROW, n4 = (g % B_F4_PER_ROW) * 4;
+                breg[i] = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.ldw + n0 + n4);   // ldw >= n0 + BN, zero padded
+            }
+        };
+        auto store_tile = [&](int buf) {
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
-                const int hi = aho[i] * a.stride + tap_h - a.pad, wi = awo[i] * a.stride + tap_w - a.pad;
-                const bool ok = am_ok[i] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-                const float4 v = *reinterpret_cast<const float4*>(a.x + (ok ? ((size_t)(an[i] * a.H + hi) * a.W + wi) * a.ldx : (size_t)0) + tap_c + ak4[i]);
-                if constexpr (S == 0) { ar0[i] = v; ok0[i] = ok; } else { ar1[i] = v; ok1[i] = ok; }
+                As[buf][ak4[i] + 0][arow[i]] = areg[i].x; As[buf][ak4[i] + 1][arow[i]] = areg[i].y;
+                As[buf][ak4[i] + 2][arow[i]] = areg[i].z; As[buf][ak4[i] + 3][arow[i]] = areg[i].w;
             }
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
                 const int g = tid + i * THREADS;
-                const float4 v = *reinterpret_cast<const float4*>(a.w + (size_t)(kc * CONV_BK + g / B_F4_PER_ROW) * a.ldw + n0 + (g % B_F4_PER_ROW) * 4);
-                if constexpr (S == 0) br0[i] = v; else br1[i] = v;
-            }
-            tap_c += CONV_BK;
-            if (tap_c >= a.Cin) { tap_c = 0; if (++tap_w == a.kw) { tap_w = 0; ++tap_h; } }
-        };
-        auto store2 = [&](int buf, auto set) {
-            constexpr int S = decltype(set)::value;
-#pragma unroll
-            for (int i = 0; i < A_F4; ++i) {
-                const float4 v = S == 0 ? ar0[i] : ar1[i];
-                const bool ok = S == 0 ? ok0[i] : ok1[i];
-                As[buf][ak4[i] + 0][arow[i]] = ok ? v.x : 0.f; As[buf][ak4[i] + 1][arow[i]] = ok ? v.y : 0.f;
-                As[buf][ak4[i] + 2][arow[i]] = ok ? v.z : 0.f; As[buf][ak4[i] + 3][arow[i]] = ok ? v.w : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < B_F4; ++i) {
-                const int g = tid + i * THREADS;
-                *reinterpret_cast<float4*>(&Bs[buf][g / B_F4_PER_ROW][(g % B_F4_PER_ROW) * 4]) = S == 0 ? br0[i] : br1[i];
+                *reinterpret_cast<float4*>(&Bs[buf][g / B_F4_PER_ROW][(g % B_F4_PER_ROW) * 4]) = breg[i];
             }
         };
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
-        if (kc0 < kc1) {
-            load2(kc0, S0{});
-            load2(min(kc0 + 1, nk_last), S1{});
-            store2(0, S0{});
-        }
-        __syncthreads();
-        int kc = kc0;
-        for (; kc + 1 < kc1; kc += 2) {
-            load2(min(kc + 2, nk_last), S0{}); mfma_tile(0); store2(1, S1{}); __syncthreads();
-            load2(min(kc + 3, nk_last), S1{}); mfma_tile(1); store2(0, S0{}); __syncthreads();
-        }
-        if (kc < kc1) { mfma_tile(0); __syncthreads(); }
-    } else {
         if (kc0 < kc1) {
             load_tile(kc0);
             store_tile(0);
@@ -223,7 +243,12 @@ void conv_igemm_kernel(ConvArgs a) {
         for (int kc = kc0; kc < kc1; ++kc) {
             const int cur = (kc - kc0) & 1;
             if (kc + 1 < kc1) load_tile(kc + 1);   // in flight during the MFMAs below
-            mfma_tile(cur);
+#pragma unroll
+            for (int kk = 0; kk < CONV_BK; kk += 2) {
+                const float a0 = As[cur][kk + kl][wm * 64 + l31], a1 = As[cur][kk + kl][wm * 64 + 32 + l31], bf = Bs[cur][kk + kl][wn * 32 + l31];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf, acc[1], 0, 0, 0);
+            }
             if (kc + 1 < kc1) store_tile(cur ^ 1); // the other buffer: its readers finished before the previous barrier
             __syncthreads();
         }
@@ -310,9 +335,6 @@ __device__ long long g_conv_stamps[1024][10];   // 8 = the worker's life in shad
 #define CONV_TK(k)
 #define CONV_CNT(k)
 #endif
-
-// Zero page: a padding pixel's loader reads from here instead of the image (one unconditional load per step, no select afterwards)
-__device__ float g_conv_zero[2048 + 64];
 
 // The K loop is written for the fewest VECTOR-ALU instructions per MFMA.  Measured (scripts/experiments/dummy_valu.sh): 32 extra v_add per wave
 // and K step cost the 3 x 3 layers 137 -> 149 us, 64 cost 158 us -- plain VALU work does NOT run in the shadow of the MFMAs of the other
