@@ -35,6 +35,64 @@ struct ConvArgs {
     int ksplit;             // gridDim.z; 1 = no split
 };
 
+// Epilogue of one wave's 64 x 32 sub-tile (C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)):
+// y = act(acc + bias (+ residual)).  Written for few vector-ALU instructions (they are not hidden behind other waves' MFMAs, and a layer with
+// 4-16 K steps has only 64-256 MFMAs per wave to set them against): the activation and the presence of a residual are template parameters
+// (rounds 1-3 branched on them per element), a row's address is the lane's base pointer + a wave-uniform (scalar) multiple of the row
+// stride, and the per-row bounds test exists only in the EDGE instance (the layer's last M tile).
+template <int ACT, bool RES, bool EDGE>
+__device__ __forceinline__ void conv_store_subtile(const ConvArgs& a, const f32x16 (&acc)[2], int mw, int n, int M, float bv) {
+    float* yp = a.y + (size_t)mw * a.ldy + n;              // mw = first row of this lane in the sub-tile (wave's row block + 4 (lane >> 5))
+    const float* rp = RES ? a.residual + (size_t)mw * a.ldr + n : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        // residual rows first, the loads of one 32-row half in flight together; one half at a time keeps 16 instead of 32 registers live
+        float res[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = mi * 32 + (r & 3) + 8 * (r >> 2);
+            res[r] = (RES && (!EDGE || mw + dr < M)) ? rp[dr * a.ldr] : 0.f;    // (32-bit scalar product: one VALU instruction per address)
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = mi * 32 + (r & 3) + 8 * (r >> 2);
+            float v = acc[mi][r] + bv;
+            if (RES) v += res[r];
+            if (ACT == 1) v = fmaxf(v, 0.f);
+            if (!EDGE || mw + dr < M) yp[dr * a.ldy] = v;
+        }
+    }
+}
+
+// bias / residual / activation dispatch of a sub-tile; tile_end = first row after the workgroup's tile (wave-uniform)
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&acc)[2], int mw, int n, int M, int tile_end) {
+    const float bv = a.bias ? a.bias[n] : 0.f;
+    const bool edge = tile_end > M;
+    if (a.act == 2) {                                      // sigmoid: the hand classifier's single tile; generic form
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mw + mi * 32 + (r & 3) + 8 * (r >> 2);
+                if (m >= M) continue;
+                const float v = acc[mi][r] + bv + (a.residual ? a.residual[(size_t)m * a.ldr + n] : 0.f);
+                a.y[(size_t)m * a.ldy + n] = 1.0f / (1.0f + expf(-v));
+            }
+        return;
+    }
+    const int sel = (a.act == 1 ? 4 : 0) | (a.residual ? 2 : 0) | (edge ? 1 : 0);
+    switch (sel) {
+        case 0: conv_store_subtile<0, false, false>(a, acc, mw, n, M, bv); break;
+        case 1: conv_store_subtile<0, false, true>(a, acc, mw, n, M, bv); break;
+        case 2: conv_store_subtile<0, true, false>(a, acc, mw, n, M, bv); break;
+        case 3: conv_store_subtile<0, true, true>(a, acc, mw, n, M, bv); break;
+        case 4: conv_store_subtile<1, false, false>(a, acc, mw, n, M, bv); break;
+        case 5: conv_store_subtile<1, false, true>(a, acc, mw, n, M, bv); break;
+        case 6: conv_store_subtile<1, true, false>(a, acc, mw, n, M, bv); break;
+        default: conv_store_subtile<1, true, true>(a, acc, mw, n, M, bv); break;
+    }
+}
+
 // Zero page: a padding pixel's loader reads from here instead of the image (one unconditional load per step, no select afterwards)
 __device__ float g_conv_zero[2048 + 64];
 
@@ -258,37 +316,18 @@ void conv_igemm_kernel(ConvArgs a) {
     const int n = n0 + wn * 32 + l31, rbase = 4 * kl;
     if (n >= a.Cout) return;
     if (a.ksplit > 1) {   // raw partial sums; the reduce kernel finishes the layer
-        float* part = a.partial + (size_t)blockIdx.z * M * a.Cout;
+        const int mw = m0 + wm * 64 + rbase;
+        float* part = a.partial + ((size_t)blockIdx.z * M + mw) * a.Cout + n;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                if (m < M) part[(size_t)m * a.Cout + n] = acc[mi][r];
+                const int dr = mi * 32 + (r & 3) + 8 * (r >> 2);
+                if (mw + dr < M) part[dr * a.Cout] = acc[mi][r];
             }
         return;
     }
-    const float bv = a.bias ? a.bias[n] : 0.f;
-    // residual rows first, the loads of one 32-row half in flight together (y may alias nothing here, but the compiler cannot
-    // know: interleaved with the stores it would issue them one by one); one half at a time keeps 16 instead of 32 registers live
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        float res[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-            res[r] = (a.residual && m < M) ? a.residual[(size_t)m * a.ldr + n] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-            if (m >= M) continue;
-            float v = acc[mi][r] + bv + res[r];
-            if (a.act == 1) v = fmaxf(v, 0.f);
-            else if (a.act == 2) v = 1.0f / (1.0f + expf(-v));
-            a.y[(size_t)m * a.ldy + n] = v;
-        }
-    }
+    conv_epilogue(a, acc, m0 + wm * 64 + rbase, n, M, m0 + BM);
 }
 
 // split-K epilogue: y = act(sum_z partial[z] (fixed order) + bias + residual); one thread per VEC output channels
@@ -453,25 +492,7 @@ void conv_streamk_kernel(ConvArgs a, int tiles_m, int nk, int total) {
         if (kc < kc1) k_step(S0{});
         const int nl = wn * 32 + l31, n = n0 + nl, rbase = 4 * kl;
         if (kc0 == 0 && kc1 == nk) {                           // the whole tile: ordinary epilogue
-            const float bv = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                float res[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                    res[r] = (a.residual && m < M && n < a.Cout) ? a.residual[(size_t)m * a.ldr + n] : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                    if (m >= M || n >= a.Cout) continue;
-                    float v = acc[mi][r] + bv + res[r];
-                    if (a.act == 1) v = fmaxf(v, 0.f);
-                    else if (a.act == 2) v = 1.0f / (1.0f + expf(-v));
-                    a.y[(size_t)m * a.ldy + n] = v;
-                }
-            }
+            if (n < a.Cout) conv_epilogue(a, acc, m0 + wm * 64 + rbase, n, M, m0 + BM);
         } else {
             float* part = a.partial + ((size_t)worker * 2 + (kc0 == 0 ? 1 : 0)) * (BM * BN);
 #pragma unroll
