@@ -104,10 +104,15 @@ __device__ float g_conv_zero[2048 + 64];
 #ifndef CONV_WAVES_PER_EU
 #define CONV_WAVES_PER_EU 6
 #endif
-template <int BM, int BN, bool FAST>
+#define CONV_GENERIC 0
+#define CONV_FAST 1
+#define CONV_C4 2
+template <int BM, int BN, int MODE>                        // MODE: CONV_GENERIC, CONV_FAST (Cin % 16 == 0), CONV_C4 (Cin == 4: the padded stem)
 __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64)
-__attribute__((amdgpu_waves_per_eu((FAST && BM == 128 && BN == 128) ? CONV_WAVES_PER_EU : 4)))
+__attribute__((amdgpu_waves_per_eu((MODE == CONV_FAST && BM == 128 && BN == 128) ? CONV_WAVES_PER_EU : 4)))
 void conv_igemm_kernel(ConvArgs a) {
+    constexpr bool FAST = MODE != CONV_GENERIC;             // float4 gathers, lean K loop
+    constexpr bool C4 = MODE == CONV_C4;
     constexpr int WN_WAVES = BN / 32;                      // waves along n; each wave owns a 64 x 32 sub-tile
     constexpr int THREADS = (BM / 64) * WN_WAVES * 64;
     // LDS layouts.  FAST: A column c = 64 h + 2 j + b holds tile row 64 h + 32 b + j, so that a lane's two A operands (rows j and j + 32 of its
@@ -136,7 +141,10 @@ void conv_igemm_kernel(ConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
     if constexpr (FAST) {
-        // Cin % 16 == 0 (every layer but the stem): a 16-wide K chunk never straddles a filter tap.  The K loop follows conv_streamk_kernel
+        // CONV_FAST: Cin % 16 == 0 (every layer but the stem): a 16-wide K chunk never straddles a filter tap and the whole wave reads one tap.
+        // CONV_C4: Cin == 4 (the image padded to 4 channels): a K chunk is 4 consecutive taps x 4 channels, a thread's float4 is ONE pixel of
+        // tap 4 kc + (tid & 3) -- 16-byte loads instead of the generic path's scalar gather with a bounds test per element (stem 256 -> us).
+        // The K loop follows conv_streamk_kernel
         // (below): as few vector-ALU instructions per MFMA as possible -- they are NOT hidden behind the MFMAs of the SIMD's other waves --
         // i.e. carried operand pointers (the gather's index arithmetic runs only when the tap changes, under a wave-uniform branch without
         // loads), padding pixels read from a zero page, two operand tiles in flight in registers, every load and LDS store unconditional.
@@ -153,15 +161,21 @@ void conv_igemm_kernel(ConvArgs a) {
             if (am_ok[i]) { an[i] = am / (a.Ho * a.Wo); const int r = am % (a.Ho * a.Wo); aho = r / a.Wo; awo = r % a.Wo; }
             hbase[i] = aho * a.stride - a.pad; wbase[i] = awo * a.stride - a.pad;
         }
-        int tap_c, tap_h, tap_w;                           // wave-uniform: filter tap / channel offset of the NEXT tile to load
-        { const int k0 = kc0 * CONV_BK, tap = k0 / a.Cin; tap_c = k0 % a.Cin; tap_h = tap / a.kw; tap_w = tap % a.kw; }
+        // CONV_FAST: wave-uniform filter tap / channel offset of the NEXT tile to load.  CONV_C4: this THREAD's tap of the next tile
+        // (tap_c unused), advanced by 4 taps per K step; taps past the last one (zero-padded K) read whatever pixel they land on or the
+        // zero page -- their filter rows are zero.
+        int tap_c, tap_h, tap_w;
+        {
+            const int k0 = kc0 * CONV_BK, tap = C4 ? k0 / 4 + (tid & 3) : k0 / a.Cin;
+            tap_c = C4 ? 0 : k0 % a.Cin; tap_h = tap / a.kw; tap_w = tap % a.kw;
+        }
         const float* pa[A_F4];
         auto retap = [&]() {
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
                 const int hi = hbase[i] + tap_h, wi = wbase[i] + tap_w;
                 const bool ok = am_ok[i] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-                pa[i] = (ok ? a.x + ((size_t)(an[i] * a.H + hi) * a.W + wi) * a.ldx : g_conv_zero) + tap_c + ak4;
+                pa[i] = (ok ? a.x + ((size_t)(an[i] * a.H + hi) * a.W + wi) * a.ldx : g_conv_zero) + (C4 ? 0 : tap_c + ak4);
             }
         };
         retap();
@@ -180,7 +194,7 @@ void conv_igemm_kernel(ConvArgs a) {
             for (int i = 0; i < A_F4; ++i) {
                 const float4 v = *reinterpret_cast<const float4*>(pa[i]);
                 if constexpr (S == 0) ar0[i] = v; else ar1[i] = v;
-                pa[i] += CONV_BK;
+                if constexpr (!C4) pa[i] += CONV_BK;
             }
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
@@ -189,8 +203,14 @@ void conv_igemm_kernel(ConvArgs a) {
                 pb[i] += kb + 1 < nk_all ? bstep : 0;
             }
             kb += kb + 1 < nk_all ? 1 : 0;
-            tap_c += CONV_BK;
-            if (tap_c >= a.Cin) { tap_c = 0; if (++tap_w == a.kw) { tap_w = 0; ++tap_h; } retap(); }
+            if constexpr (C4) {
+                tap_w += 4;                                // kw >= 4 (7 x 7 stem): at most one wrap
+                if (tap_w >= a.kw) { tap_w -= a.kw; ++tap_h; }
+                retap();
+            } else {
+                tap_c += CONV_BK;
+                if (tap_c >= a.Cin) { tap_c = 0; if (++tap_w == a.kw) { tap_w = 0; ++tap_h; } retap(); }
+            }
         };
         auto store2 = [&](int buf, auto set) {
             constexpr int S = decltype(set)::value;

@@ -761,17 +761,20 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
     const dim3 grid((M + tiles[pick][0] - 1) / tiles[pick][0], (Cout + tiles[pick][1] - 1) / tiles[pick][1], ksplit);
     if (fast) {
         switch (pick) {
-            case 0: hipLaunchKernelGGL((conv_igemm_kernel<128, 128, true>), grid, dim3(512), 0, st, a); break;
-            case 1: hipLaunchKernelGGL((conv_igemm_kernel<64, 128, true>), grid, dim3(256), 0, st, a); break;
-            case 2: hipLaunchKernelGGL((conv_igemm_kernel<128, 64, true>), grid, dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL((conv_igemm_kernel<64, 64, true>), grid, dim3(128), 0, st, a); break;
+            case 0: hipLaunchKernelGGL((conv_igemm_kernel<128, 128, CONV_FAST>), grid, dim3(512), 0, st, a); break;
+            case 1: hipLaunchKernelGGL((conv_igemm_kernel<64, 128, CONV_FAST>), grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((conv_igemm_kernel<128, 64, CONV_FAST>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((conv_igemm_kernel<64, 64, CONV_FAST>), grid, dim3(128), 0, st, a); break;
         }
+    } else if (Cin == 4 && (ldx % 4) == 0 && kw >= 4 && !wide_ok) {      // the stem on the image padded to 4 channels
+        if (pick == 2) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, CONV_C4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_kernel<64, 64, CONV_C4>), grid, dim3(128), 0, st, a);
     } else {
         switch (pick) {
-            case 0: hipLaunchKernelGGL((conv_igemm_kernel<128, 128, false>), grid, dim3(512), 0, st, a); break;
-            case 1: hipLaunchKernelGGL((conv_igemm_kernel<64, 128, false>), grid, dim3(256), 0, st, a); break;
-            case 2: hipLaunchKernelGGL((conv_igemm_kernel<128, 64, false>), grid, dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL((conv_igemm_kernel<64, 64, false>), grid, dim3(128), 0, st, a); break;
+            case 0: hipLaunchKernelGGL((conv_igemm_kernel<128, 128, CONV_GENERIC>), grid, dim3(512), 0, st, a); break;
+            case 1: hipLaunchKernelGGL((conv_igemm_kernel<64, 128, CONV_GENERIC>), grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((conv_igemm_kernel<128, 64, CONV_GENERIC>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((conv_igemm_kernel<64, 64, CONV_GENERIC>), grid, dim3(128), 0, st, a); break;
         }
     }
     if (ksplit > 1) {

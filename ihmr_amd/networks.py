@@ -128,7 +128,7 @@ class InterHandEncoder(nn.Module):
         me = self.main_encoder
         t = lambda x: x.to(dev)
         w, b = _fold_bn(me.conv1, me.bn1)
-        P["stem"] = _Packed(t(w), t(b), stride=2, pad=3)
+        P["stem"] = _Packed(t(w), t(b), stride=2, pad=3, k_extra=1)   # the image is padded to 4 channels: 16-byte gathers (csrc/encoder.h: CONV_C4)
         for li in range(1, 5):
             for bi, blk in enumerate(getattr(me, f"layer{li}")):
                 for ci, (conv, bn, st, pd) in enumerate([(blk.conv1, blk.bn1, 1, 0), (blk.conv2, blk.bn2, blk.stride, 1),
@@ -153,9 +153,12 @@ class InterHandEncoder(nn.Module):
             self._pack(dev)
         P = self._packed
         B, C, H, W = main_input.shape
-        x = main_input.float().permute(0, 2, 3, 1).contiguous()           # NHWC (layout plumbing only)
+        x = getattr(self, "_nhwc4", None)                                  # NHWC, 3 -> 4 channels (layout plumbing only); channel 3 stays zero
+        if x is None or x.shape[:3] != (B, H, W) or x.device != dev:
+            x = self._nhwc4 = torch.zeros(B, H, W, 4, device=dev)
+        x[..., :3].copy_(main_input.permute(0, 2, 3, 1))
         # stem: conv 7x7/2 + BN + ReLU, max-pool 3x3/2
-        y, H, W = conv_igemm(x, P["stem"], B, H, W, ldx=3, act=1)
+        y, H, W = conv_igemm(x, P["stem"], B, H, W, ldx=4, act=1)
         Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         xp = torch.empty(B * Hp * Wp, 64, device=dev)
         hip.check(hip.lib().ihmr_maxpool3x3s2(hip.ptr(y), hip.ptr(xp), B, H, W, 64, Hp, Wp, hip.stream_ptr()), "ihmr_maxpool3x3s2")
