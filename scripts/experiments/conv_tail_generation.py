@@ -8,7 +8,7 @@ from ihmr_amd.networks import _Packed, conv_igemm
 
 dev = torch.device("cuda")
 for cin, cout, ms in ((256, 1024, tuple(4096 * k for k in range(1, 9)) + (96 * 128 + 128, 98 * 128, 100 * 128)), (128, 512, (384 * 128, 392 * 128, 400 * 128)),
-                      (512, 2048, (16 * 128, 24 * 128, 3136, 32 * 128))):
+                      (512, 2048, (16 * 128, 24 * 128, 3136, 32 * 128)), (512, 1024, (96 * 128, 98 * 128)), (256, 128, (1536 * 128, 1568 * 128))):
     pk = _Packed(torch.randn(cout, cin, 1, 1, device=dev) * 0.05, torch.zeros(cout, device=dev))
     for M in ms:
         x = torch.randn(M, cin, device=dev); res = torch.randn(M, cout, device=dev); out = torch.empty(M, cout, device=dev)
