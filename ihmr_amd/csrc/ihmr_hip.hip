@@ -728,6 +728,11 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
         ksplit = (int)std::max<long>(1, std::min<long>(std::min<long>(32, cap), nk / 4));
     } else if (blocks(pick) < 384 && nk >= 64 && cap >= 2) {
         ksplit = 2;
+    } else if (wide_ok && blocks(0) > 768 && blocks(0) < 896) {
+        // 784 tiles (the 14 x 14 layers with >= 1024 output channels): three resident workgroups per CU take 768, the last 16 run alone at ~2 us
+        // per K step (8-33 us: scripts/experiments/conv_tail_generation.py); as 1568 half-height tiles (six resident per CU) the stragglers
+        // are half as long.  Measured per layer (scripts/experiments/tile_sweep.sh): 145 -> 132 us (32 K steps), 82 -> 77.5 us (16 K steps)
+        pick = 1;
     }
 #ifdef IHMR_TUNING_BUILD   // per-layer tile / split measurements (scripts/prof_encoder.py builds its own library with this macro)
     if (const char* force = getenv("IHMR_CONV_FORCE")) {   // "<tile 0-3> <ksplit>"
