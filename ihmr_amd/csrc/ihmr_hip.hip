@@ -874,13 +874,15 @@ extern "C" int ihmr_adam_step(float* params, const float* grads, float* exp_avg,
 }
 
 // ------------------------------------------------------------------------------------------ encoder training kernels
+#define BN_MAX_CHUNKS 1024
 static int bn_chunks(long M, int* rows_per) {
-    long rp = std::max<long>(64, (M + 255) / 256);
+    long rp = std::max<long>(16, (M + BN_MAX_CHUNKS - 1) / BN_MAX_CHUNKS);
     *rows_per = (int)rp;
     return (int)((M + rp - 1) / rp);
 }
+static dim3 bn_grid(int C, int S) { return dim3((unsigned)((C / 4 + 255) / 256), (unsigned)S); }
 
-extern "C" size_t ihmr_bn_workspace_bytes(int C) { return (size_t)256 * 2 * C * sizeof(float) + (size_t)2 * C * sizeof(float); }
+extern "C" size_t ihmr_bn_workspace_bytes(int C) { return (size_t)BN_MAX_CHUNKS * 2 * C * sizeof(float) + (size_t)2 * C * sizeof(float); }
 
 extern "C" int ihmr_bn_train_forward(const float* z, long M, int C, const float* gamma, const float* beta, const float* residual,
                                      int relu, float eps, float* y, float* mean, float* var, float* invstd, float* running_mean,
@@ -890,7 +892,7 @@ extern "C" int ihmr_bn_train_forward(const float* z, long M, int C, const float*
     int rows_per;
     const int S = bn_chunks(M, &rows_per);
     float* part = (float*)workspace;
-    const dim3 grid((C + 63) / 64, S);
+    const dim3 grid = bn_grid(C, S);
     // one pass over z: sum z and sum (z - z0)^2 with row 0 as the pivot, then mean / variance / invstd
     hipLaunchKernelGGL(bn_partial_kernel<3>, grid, dim3(256), 0, st, z, (const float*)nullptr, (int)M, C, C, C, rows_per,
                        (const float*)nullptr, (const float*)nullptr, part, (const float*)nullptr);
@@ -910,7 +912,7 @@ extern "C" int ihmr_bn_train_backward(const float* z, const float* g, long M, in
     const int S = bn_chunks(M, &rows_per);
     float* part = (float*)workspace;
     // sum g -> dbeta, sum g * xhat -> dgamma (written by the finish kernel itself, read back by the apply kernel)
-    hipLaunchKernelGGL(bn_partial_kernel<2>, dim3((C + 63) / 64, S), dim3(256), 0, st, z, g, (int)M, C, C, C, rows_per, mean, invstd, part, relu_y);
+    hipLaunchKernelGGL(bn_partial_kernel<2>, bn_grid(C, S), dim3(256), 0, st, z, g, (int)M, C, C, C, rows_per, mean, invstd, part, relu_y);
     hipLaunchKernelGGL(bn_finish_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)part, S, 2, C, 1.0, dbeta,
                        (float*)nullptr, 0.f, dgamma);
     hipLaunchKernelGGL(bn_backward_apply_kernel, dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, st, z, g, mean, invstd, gamma,
