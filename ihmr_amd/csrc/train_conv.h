@@ -343,24 +343,48 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_wgrad_kernel(
     const int nchunks = (M + CONV_BK - 1) / CONV_BK;
     const int mc0 = blockIdx.z * a.chunks_per, mc1 = min(nchunks, mc0 + a.chunks_per);
     float4 areg[A_F4], breg[B_F4];
-    auto load_tile = [&](int mc) {
+    // Vector-ALU instructions are not hidden behind the MFMAs (csrc/encoder.h), and this loop walks PIXELS: rounds 1-3 decomposed every
+    // loader's pixel index with four integer divisions per K step (~200 VALU instructions per 16 MFMAs).  Now: two exact small-integer
+    // divisions by multiplication with a float reciprocal (+- 1 correction; m < 2^23) and the filter-tap offsets folded into per-loader
+    // constants; the dY loader carries its pointer.
+    const float r_howo = 1.0f / (float)HoWo, r_wo = 1.0f / (float)a.Wo;
+    auto sdiv = [](int v, int d, float rd) {               // v / d for 0 <= v < 2^23, d > 0
+        int q = (int)((float)v * rd);
+        const int r = v - q * d;
+        q += r >= d ? 1 : (r < 0 ? -1 : 0);
+        return q;
+    };
+    int am[A_F4], hoff[A_F4], woff[A_F4];                  // next pixel of each loader; its tap's offset in the input image
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) { am[i] = mc0 * CONV_BK + arow[i]; hoff[i] = afh[i] - a.pad; woff[i] = afw[i] - a.pad; }
+    const float* pb[B_F4];
+    int bm[B_F4];
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+        const int g = tid + i * THREADS;
+        bm[i] = mc0 * CONV_BK + g / B_PER_ROW;
+        pb[i] = a.dy + (size_t)bm[i] * a.lddy + n0 + (g % B_PER_ROW) * 4;
+    }
+    const bool bn_ok0 = n0 + (tid % B_PER_ROW) * 4 < a.lddy;   // THREADS % B_PER_ROW == 0: the same column for every float4 of a thread
+    const size_t bstep = (size_t)CONV_BK * a.lddy;
+    auto load_tile = [&](int) {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int m = mc * CONV_BK + arow[i];
+            const int m = am[i];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (aok[i] && m < M) {
-                const int n = m / HoWo, r = m % HoWo, ho = r / a.Wo, wo = r % a.Wo;
-                const int hi = ho * a.stride + afh[i] - a.pad, wi = wo * a.stride + afw[i] - a.pad;
+                const int n = sdiv(m, HoWo, r_howo), r = m - n * HoWo, ho = sdiv(r, a.Wo, r_wo), wo = r - ho * a.Wo;
+                const int hi = ho * a.stride + hoff[i], wi = wo * a.stride + woff[i];
                 if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
                     v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + hi) * a.W + wi) * a.ldx + ac[i]);
             }
             areg[i] = v;
+            am[i] += CONV_BK;
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            const int g = tid + i * THREADS, m = mc * CONV_BK + g / B_PER_ROW, n4 = (g % B_PER_ROW) * 4;
-            breg[i] = (m < M && n0 + n4 < a.lddy) ? *reinterpret_cast<const float4*>(a.dy + (size_t)m * a.lddy + n0 + n4)
-                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            breg[i] = (bm[i] < M && bn_ok0) ? *reinterpret_cast<const float4*>(pb[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bm[i] += CONV_BK; pb[i] += bstep;
         }
     };
     auto store_tile = [&](int buf) {
@@ -395,13 +419,14 @@ __global__ __launch_bounds__((BM / 64) * (BN / 32) * 64) void conv_wgrad_kernel(
     }
     const int n = n0 + wn * 32 + l31;
     if (n >= a.Cout) return;
-    float* part = a.partial + (size_t)blockIdx.z * K * a.Cout;
+    const int kw0 = k0 + wm * 64 + 4 * kl;
+    float* part = a.partial + ((size_t)blockIdx.z * K + kw0) * a.Cout + n;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int k = k0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-            if (k < K) part[(size_t)k * a.Cout + n] = acc[mi][r];
+            const int dr = mi * 32 + (r & 3) + 8 * (r >> 2);
+            if (kw0 + dr < K) part[dr * a.Cout] = acc[mi][r];
         }
 }
 
