@@ -853,8 +853,13 @@ extern "C" int ihmr_transpose(const float* x, float* y, int rows, int cols, int 
 
 extern "C" int ihmr_relu_backward(float* dx, const float* y, int rows, int cols, int ld_dx, int ld_y, void* stream) {
     if (!dx || !y || rows <= 0 || cols <= 0) return -1;
-    hipLaunchKernelGGL(relu_backward_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, y, rows, cols, ld_dx,
-                       ld_y);
+    const long total = (long)rows * cols;
+    if (ld_dx == cols && ld_y == cols && total % 4 == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)y % 16) == 0)
+        hipLaunchKernelGGL(relu_backward4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float4*)dx,
+                           (const float4*)y, total / 4);
+    else
+        hipLaunchKernelGGL(relu_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dx, y, rows, cols, ld_dx,
+                           ld_y);
     return (int)hipGetLastError();
 }
 

@@ -165,6 +165,20 @@ __global__ __launch_bounds__(256) void relu_backward_kernel(float* __restrict__ 
     if (!(y[(size_t)r * ld_y + c] > 0.f)) dx[(size_t)r * ld_dx + c] = 0.f;
 }
 
+// the same for dense matrices (ld == cols) whose element count is a multiple of 4: one 16-byte load of y and of dx and one store per thread
+// (the encoder's block outputs: up to 51 M elements per call)
+__global__ __launch_bounds__(256) void relu_backward4_kernel(float4* __restrict__ dx, const float4* __restrict__ y, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 yv = y[i];
+    float4 d = dx[i];
+    if (!(yv.x > 0.f)) d.x = 0.f;
+    if (!(yv.y > 0.f)) d.y = 0.f;
+    if (!(yv.z > 0.f)) d.z = 0.f;
+    if (!(yv.w > 0.f)) d.w = 0.f;
+    dx[i] = d;
+}
+
 // out[c] = sum_r x[r][c] (bias gradient): a workgroup owns 64 columns, its 4 waves take rows w, w + 4, ... (coalesced over the
 // columns), the four partial sums are added in wave order
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int cols, int ldx) {
