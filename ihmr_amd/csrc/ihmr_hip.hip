@@ -744,7 +744,7 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
     }
 #endif
     a.ksplit = ksplit;
-    const bool fast = (Cin % CONV_BK) == 0 && (ldx % 4) == 0;
+    const bool fast = (Cin % CONV_BK) == 0 && (ldx % 4) == 0 && Cin <= 2048;   // (2048: the zero page the padding pixels are read from, csrc/encoder.h)
     // Stream-K (csrc/encoder.h): layers with a long K loop and at most three 128 x 128 tiles per CU -- at batch 64 every 3 x 3 layer and the
     // first 1 x 1 of every bottleneck from 28 x 28 down (100, 196 or 392 tiles: 0.4-1.5 per CU) -- are shared evenly by two workers per CU.
     // Measured per layer (scripts/prof_encoder_layers.sh, round 4): 3 x 3 layers 175-187 -> 144-158 us, 1 x 1 layers with K >= 1024

@@ -103,8 +103,17 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict_
     const bool ok = i < NQ * C;
     const int q = ok ? i / C : 0, c = ok ? i % C : 0;
     double s = 0.0;
-    if (ok)
-        for (int k = g; k < S; k += 16) s += (double)part[((size_t)k * NQ + q) * C + c];
+    if (ok) {
+        int k = g;
+        for (; k + 7 * 16 < S; k += 8 * 16) {            // eight chunks' loads in flight, added in chunk order (the same sum as one by one)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[((size_t)(k + 16 * u) * NQ + q) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; k < S; k += 16) s += (double)part[((size_t)k * NQ + q) * C + c];
+    }
     red[g][e] = s;
     __syncthreads();
     if (g == 0 && ok) {
@@ -127,8 +136,17 @@ __global__ __launch_bounds__(256) void bn_finish_stats_kernel(const float* __res
     const int e = threadIdx.x % 16, g = threadIdx.x / 16, c = blockIdx.x * 16 + e;
     const bool ok = c < C;
     double s0 = 0.0, s1 = 0.0;
-    if (ok)
-        for (int k = g; k < S; k += 16) { s0 += (double)part[((size_t)k * 2) * C + c]; s1 += (double)part[((size_t)k * 2 + 1) * C + c]; }
+    if (ok) {
+        int k = g;
+        for (; k + 7 * 16 < S; k += 8 * 16) {            // eight chunks' loads in flight, added in chunk order
+            float v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v0[u] = part[((size_t)(k + 16 * u) * 2) * C + c]; v1[u] = part[((size_t)(k + 16 * u) * 2 + 1) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s0 += (double)v0[u]; s1 += (double)v1[u]; }
+        }
+        for (; k < S; k += 16) { s0 += (double)part[((size_t)k * 2) * C + c]; s1 += (double)part[((size_t)k * 2 + 1) * C + c]; }
+    }
     red[0][g][e] = s0; red[1][g][e] = s1;
     __syncthreads();
     if (g == 0 && ok) {
