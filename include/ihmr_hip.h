@@ -229,8 +229,14 @@ int ihmr_opt_sdf_counters(const ihmr_opt_io* io, int B, unsigned long long* out1
  * x: NHWC, pixel stride ldx floats;  w: [ceil16(kh*kw*Cin)][ldw] K-major with BatchNorm folded in, zero padded,
  * ldw a multiple of 64 (128 to use the wide tile) and >= Cout;  bias [Cout];  residual optional [M][ldr];
  * y [M][ldy];  act: 0 none, 1 ReLU, 2 sigmoid.  A Linear layer is the case H = W = kh = kw = 1.
- * workspace (optional, device, workspace_bytes): scratch for split-K partial sums -- layers too small to fill the
- * GPU (7x7 maps: 2; Linear layers: up to 32) split their K loop over up to min(32, workspace_bytes / (M*Cout*4)) workgroups. */
+ * Gather forms (chosen by shape): Cin % 16 == 0, ldx % 4 == 0, Cin <= 2048: 16-byte loads, one filter tap per K chunk; Cin == 4 (an
+ * image padded from 3 channels), kw >= 4: 16-byte loads, one pixel of one tap per load; anything else: a scalar gather.
+ * workspace (optional, device, workspace_bytes): scratch for partial sums.  Layers too small to fill the GPU (Linear layers: up to 32)
+ * split their K loop over up to min(32, workspace_bytes / (M*Cout*4)) workgroups.  Layers with >= 64 K steps of 16 and 64..768 tiles
+ * of 128 x 128 (at batch 64: every 3 x 3 layer and the long 1 x 1 layers from 28 x 28 down) run in Stream-K form when
+ * workspace_bytes >= 64 MiB + 4 KiB (512 workers x two 64 KB tile slots): the workers share tiles x K steps evenly and a fix-up launch adds
+ * a tile's pieces in ascending K order.  Every form sums in a fixed order: results are bit-identical from run to run; they differ between
+ * forms (i.e. with and without a workspace) in the last bits. */
 int ihmr_conv_igemm(const float* x, const float* w, const float* bias, const float* residual, float* y, int N, int H, int W,
                     int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int ldx, int ldw, int ldy, int ldr,
                     int act, void* workspace, size_t workspace_bytes, void* stream);

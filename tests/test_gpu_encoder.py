@@ -22,6 +22,7 @@ def _report(name, got, ref, atol, rtol):
     dict(N=2, H=32, W=32, Cin=3, Cout=64, k=7, s=2, p=3),       # stem-like, Cin = 3 (generic gather path)
     dict(N=3, H=30, W=34, Cin=4, Cout=64, k=7, s=2, p=3),       # the stem on a 4-channel image (CONV_C4: one pixel of one tap per 16-byte load)
     dict(N=1, H=9, W=9, Cin=4, Cout=40, k=5, s=1, p=2),         # CONV_C4, 64-row tile, taps wrapping every step (kw = 5), Cout not a tile multiple
+    dict(N=1, H=6, W=5, Cin=2064, Cout=32, k=3, s=1, p=1),      # Cin beyond the zero page of the fast gather: generic path, padding still zero
 ])
 def test_conv_igemm_matches_torch(cfg):
     from ihmr_amd.networks import _Packed, conv_igemm
