@@ -570,6 +570,83 @@ __device__ __forceinline__ void lbs_bwd1_hand(const ihmr_mano& m, const LbsWork&
         bw.nchild[p] = n;
     }
 
+    // ---- orientation stage (only the root rotation moves): every vertex and posed joint is R0 q + J0 with q independent of R0, so
+    //      d L / d R0 = [sum_v g_v (x) (v - J0) + sum_j gj_j (x) (G_j.t - J0)] R0 -- one 3 x 3 reduction over the re-skinned vertices instead
+    //      of the per-joint segmented reduction and the chain backward by tree level (round 4; ~14 -> ~4 us of opt_tail_kernel in that stage).
+    //      Fixed summation order (lane partial sums, DPP wave sums, waves in index order, joints in index order).
+    if ((need_mask & 7) == 1 && m.sparse4) {
+        float4 wr[VR];
+        uint32_t jr[VR];
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            const int v = min(tid + r * LBS_THREADS, NV - 1);
+            wr[r] = m.w4_w[v];
+            jr[r] = m.w4_j[v];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float J0[3] = {sJ[0], sJ[1], sJ[2]};
+        float acc[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            const int v = tid + r * LBS_THREADS;
+            if (v >= NV) break;
+            const float wv[4] = {wr[r].x, wr[r].y, wr[r].z, wr[r].w};
+            float T[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                const float4* A4 = reinterpret_cast<const float4*>(sA + 12 * (int)((jr[r] >> (8 * sI)) & 0xffu));
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float4 a = A4[q];
+                    T[4 * q] = __builtin_fmaf(wv[sI], a.x, T[4 * q]);
+                    T[4 * q + 1] = __builtin_fmaf(wv[sI], a.y, T[4 * q + 1]);
+                    T[4 * q + 2] = __builtin_fmaf(wv[sI], a.z, T[4 * q + 2]);
+                    T[4 * q + 3] = __builtin_fmaf(wv[sI], a.w, T[4 * q + 3]);
+                }
+            }
+            const float p0 = bw.vp[3 * v], p1 = bw.vp[3 * v + 1], p2 = bw.vp[3 * v + 2];
+            const float g[3] = {bw.g[3 * v], bw.g[3 * v + 1], bw.g[3 * v + 2]};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float d = (T[4 * c] * p0 + T[4 * c + 1] * p1 + T[4 * c + 2] * p2 + T[4 * c + 3]) - J0[c];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[3 * q + c] = __builtin_fmaf(g[q], d, acc[3 * q + c]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc[e] = wave_reduce_sum_dpp(acc[e]);
+        if (tid % WAVE == 0) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) bw.dA[tid / WAVE][e] = acc[e];       // (dA is free in this stage: scratch for the wave sums)
+        }
+        __syncthreads();
+        if (tid < 9) {
+            const int q = tid / 3, c = tid % 3;
+            float t = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < LBS_THREADS / WAVE; ++wv) t += bw.dA[wv][tid];
+            for (int j = 0; j < NJ; ++j) t = __builtin_fmaf(bw.gj[j][q], sG[12 * j + 4 * c + 3] - J0[c], t);
+            bw.dG[0][tid] = t;                                               // M[q][c]
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float dR0[9], dr[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    dR0[3 * q + c] = bw.dG[0][3 * q] * sR[c] + bw.dG[0][3 * q + 1] * sR[3 + c] + bw.dG[0][3 * q + 2] * sR[6 + c];
+            rodrigues_bwd(bw.sk + SK_POSE, dR0, dr);
+            if (left) { dr[1] = -dr[1]; dr[2] = -dr[2]; }
+            d_orient[h * 3 + 0] = dr[0]; d_orient[h * 3 + 1] = dr[1]; d_orient[h * 3 + 2] = dr[2];
+        }
+        return;
+    }
+
     // ---- per vertex: d v_posed = T.R^T g, T.R = sum_j w_j A_j.R over all 16 joints (no branches: a zero weight adds
     //      an exact zero), the matrices read from LDS as broadcast rows.  Only the finger-pose and shape gradients need it.
     if (need_pose || need_betas) {
