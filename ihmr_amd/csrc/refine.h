@@ -423,6 +423,8 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
     if ((need_mask & 7) != 0) {
         lds_dma_dwords(wk.lbs.v_posed + (size_t)(hl * B + b) * NV3, bw[hl].vp, NV3, tid % LBS_THREADS, LBS_THREADS);
         lds_dma_dwords(wk.lbs.skel + (size_t)(hl * B + b) * SK_STRIDE, bw[hl].sk, SK_STRIDE, tid % LBS_THREADS, LBS_THREADS);
+    } else if (SKIN) {       // translation stage: the skeleton records stay valid for the next iteration's vertices (phase 3 / 4)
+        lds_dma_dwords(wk.lbs.skel + (size_t)(hl * B + b) * SK_STRIDE, bw[hl].sk, SK_STRIDE, tid % LBS_THREADS, LBS_THREADS);
     }
     // ---- phase 1: collision sampling (waves 0-6) + joint / translation / finger losses (wave 7).  Their gradients -- d L / d vertices,
     //      d L / d joints -- are handed to phase 2 through its LDS records, not through global memory (the same values)
@@ -464,9 +466,33 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    const int hs = tid / 192;
-    lbs_skel_hand<true>(m, io.orient, io.pose, io.shape, io.trans, B, wk.lbs.skel, wk.joints_raw, bw[hs < 2 ? hs : 0].sk, (hs < 2 ? hs : 0) * B + b, tid % 192,
-                        hs < 2);
+    if (SKIN && (need_mask & 7) == 0) {
+        // Translation stage: neither skeleton changes -- the records DMA'd into LDS in phase 0 ARE the next iteration's -- except the left hand's
+        // shift (= hand_trans + right wrist - mirrored left wrist) and with it the left hand's posed joints.  The three shift components are
+        // recomputed with lbs_skel_hand's own expression (the same bits) instead of both skeletons (Rodrigues, joint regression, chain by level:
+        // 3.8 us of the 512-sample launch).
+        if (tid < 3) {
+            const float* br = io.shape + (size_t)b * 10;                 // right wrist: J_template[0] + J_shapedirs[0] . beta_right
+            float jr = m.J_template[tid];
+#pragma unroll
+            for (int l = 0; l < 10; ++l) jr = __builtin_fmaf(m.J_shapedirs[tid * 10 + l], br[l], jr);
+            const float* sJl = bw[1].sk + SK_J;
+            const float jl = tid == 0 ? -sJl[0] : sJl[tid];              // mirrored left wrist
+            const float sh = io.trans[b * 3 + tid] + (jr - jl);
+            bw[1].sk[SK_SHIFT + tid] = sh;
+            wk.lbs.skel[((size_t)B + b) * SK_STRIDE + SK_SHIFT + tid] = sh;
+        }
+        __syncthreads();
+        if (tid < NJ * 3) {
+            const int j = tid / 3, k = tid % 3;
+            const float val = bw[1].sk[SK_G + 12 * j + 4 * k + 3];
+            wk.joints_raw[((size_t)b * 42 + 21 + j) * 3 + k] = (k == 0 ? -val : val) + bw[1].sk[SK_SHIFT + k];
+        }
+    } else {
+        const int hs = tid / 192;
+        lbs_skel_hand<true>(m, io.orient, io.pose, io.shape, io.trans, B, wk.lbs.skel, wk.joints_raw, bw[hs < 2 ? hs : 0].sk, (hs < 2 ? hs : 0) * B + b, tid % 192,
+                            hs < 2);
+    }
     TAIL_TK(3);
     if (!SKIN) return;
     // ---- phase 4: the next iteration's vertices (threads [0,256) right hand, [256,512) left hand; the skinning matrices A and the left
