@@ -754,7 +754,7 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
     if (const char* f = getenv("IHMR_CONV_SK")) sscanf(f, "%d %d %d", &sk_max_tiles, &sk_min_nk, &sk_workers);   // "<max tiles> <min K steps> <workers>"
 #endif
     const long sk_tiles = blocks(0);
-    if (fast && pick == 0 && M > 64 && Cout % 128 == 0 && ldy % 4 == 0 && sk_tiles >= 64 && sk_tiles <= sk_max_tiles && nk >= sk_min_nk &&
+    if (fast && pick == 0 && M > 64 && Cout % 128 == 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 && sk_tiles >= 64 && sk_tiles <= sk_max_tiles && nk >= sk_min_nk &&
         sk_tiles * nk >= 4L * sk_workers && workspace && workspace_bytes >= (size_t)sk_workers * 2 * 128 * 128 * sizeof(float)) {
         const int tiles_m = (M + 127) / 128, total = (int)(sk_tiles * nk);
         hipLaunchKernelGGL(conv_streamk_kernel, dim3(sk_workers), dim3(512), 0, st, a, tiles_m, nk, total);

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     const int tid = threadIdx.x, col = blockIdx.x * CW + tid % CW, phase = tid / CW, c = col * 4, s = blockIdx.y;
     const int r0 = s * rows_per, r1 = min(M, r0 + rows_per);
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    if (col < c4) {
+    if (col < c4 && phase < RP) {                          // (C / 4 not a power of two: the last 256 - RP * CW threads have no row phase)
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 mu = MODE == 3 ? *reinterpret_cast<const float4*>(z + c) : (MODE >= 1 ? *reinterpret_cast<const float4*>(mean + c) : zero);
         const float4 is = MODE == 2 ? *reinterpret_cast<const float4*>(invstd + c) : zero;

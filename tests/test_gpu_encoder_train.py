@@ -27,7 +27,8 @@ def _nchw(m, N, H, W):   # [N*H*W, C] -> (N,C,H,W) on the CPU
 
 
 @pytest.mark.parametrize("N,C,H,W,res,relu", [(4, 64, 14, 14, False, True), (2, 256, 9, 7, True, True), (3, 8, 5, 5, False, False),
-                                              (8, 64, 56, 56, True, True)])
+                                              (8, 64, 56, 56, True, True), (5, 192, 11, 13, False, True),      # C / 4 = 48: not a power of two
+                                              (2, 2048, 7, 7, True, False)])                                      # two column blocks of 256 float4s
 def test_batchnorm_train_forward_backward(N, C, H, W, res, relu):
     from ihmr_amd import encoder_train as T
     g = torch.Generator().manual_seed(N * 1000 + C)
