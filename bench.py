@@ -430,9 +430,9 @@ def secondary(config, with_cpu=True):
                    config=dict(workload="BASELINE.json configs[1]: InterHandModel.test() + get_pred_result(), batch 64, 224x224"),
                    two_batches_in_flight=dict(images_per_s=B / dt2, ms_per_batch=dt2 * 1e3, note="two model instances on two HIP streams"),
                    roofline=dict(bound="mfma", kernel="conv_streamk_kernel + conv_igemm_kernel (whole encoder)", achieved=8.2e9 * B / enc_dt / 1e12,
-                                 clock_note="peak = 157.3 TFLOP/s at 2.4 GHz; the shader clock measured inside these kernels (shader-clock counter against "
-                                            "the 100 MHz wall clock, scripts/experiments/conv_stamps.py with a -DCONV_STAMPS build) is 2.00-2.09 GHz: "
-                                            "131-137 TFLOP/s is what the MFMA pipes can deliver at that clock",
+                                 clock_note="peak = 157.3 TFLOP/s at 2.4 GHz; the shader clock read inside these kernels (shader-clock counter against the "
+                                            "100 MHz wall clock, scripts/experiments/encoder_clock_in_pass.py with a -DCONV_STAMPS build) ramps from 2.0-2.1 GHz "
+                                            "in the first milliseconds of a burst to 2.33-2.34 GHz in a sustained run; this figure is a short run (13 passes)",
                                  peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=8.2e9 * B / enc_dt / 1e12 / FP32_PEAK_TFLOPS,
                                  traffic=enc_traffic, traffic_unit="bytes per encoder forward (64 images)", traffic_source=enc_traffic_src,
                                  hbm=dict(achieved=(enc_traffic / enc_dt / 1e9) if enc_traffic else None, peak=HBM_PEAK_GBS, unit="GB/s",

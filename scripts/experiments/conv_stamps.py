@@ -19,7 +19,7 @@ for name, N, H, cin, cout, k in (("3x3 256 @14", 64, 14, 256, 256, 3), ("3x3 128
     for _ in range(3):
         conv_igemm(x, pk, N, H, H, cin, act=1)
     L.ihmr_debug_conv_stamps(None, 1)
-    R = 10
+    R = int(sys.argv[1]) if len(sys.argv) > 1 else 10      # launches per measurement (the clock is reported for all of them together)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(R):
