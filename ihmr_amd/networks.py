@@ -187,7 +187,9 @@ class InterHandEncoder(nn.Module):
         conv_igemm(main_feat, P["feat"], B, 1, 1, ldx=1024, out=bufs[0], ldy=Kp, act=1)
         bufs[1][:, :1024].copy_(bufs[0][:, :1024])
         self.feat = bufs[1][:, :1024]            # networks.py:68 -- the 1024-d image feature the MLP stages consume as `img_feat`
-        mp = self.mean_params.to(dev)
+        mp = getattr(self, "_mean_dev", None)     # device copy made once (a host-to-device copy cannot be captured in a graph)
+        if mp is None or mp.device != dev or mp.shape != self.mean_params.shape:
+            mp = self._mean_dev = self.mean_params.to(dev)
         bufs[0][:, 1024:1024 + nparam].copy_(mp if mp.shape[0] == B else mp[:1].expand(B, -1))
         cur = 0
         for _ in range(3):  # networks.py:71-75: params += Linear([feat | params])
