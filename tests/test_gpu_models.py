@@ -179,6 +179,33 @@ def test_mlp_model_batch128_matches_oracle(mano_arrays):
     _report("mlp128 penetration depth, oracle on the product's own vertices [m]", res["collision_loss_origin_scale"], own.numpy(), atol=1e-6)
 
 
+def test_baseline_test_graph_replays_equal_eager_launches(mano_arrays):
+    """InterHandModel.test() is replayed from one captured graph (opt.use_test_graph): the replay over NEW inputs in the static buffers and
+    after a change of the encoder's weights (re-capture) must give the bits of eager launches."""
+    from helpers import seeded_state_dict
+    from ihmr_amd.baseline_model import InterHandModel
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    from ihmr_amd import two_hand
+    B = 4
+    graph, eager = InterHandModel(_opt(B)), InterHandModel(_opt(B, use_test_graph=False))
+    assert graph.use_test_graph and not eager.use_test_graph
+    fwd = lambda p, s, t: two_hand.forward_from_packed(graph.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
+    for round_, seed in enumerate((5, 6, 7)):
+        if round_ != 1:                                   # rounds 0 and 2: new weights (the captured graph holds the old packed copies)
+            sd = seeded_state_dict(graph.encoder, 40 + round_)
+            sd["regressor_ih.0.weight"] *= 0.05; sd["regressor_ih.0.bias"] *= 0.05
+            graph.encoder.load_state_dict(sd); eager.encoder.load_state_dict(sd)
+            graph.eval(); eager.eval()
+        batch = synthetic_opt_batch(B, fwd, seed=seed, with_image=True)
+        outs = []
+        for m in (graph, eager):
+            m.set_input(batch); m.test(); torch.cuda.synchronize()
+            outs.append(m.get_pred_result())
+        assert graph._test_graph is not None and getattr(eager, "_test_graph", None) is None
+        for k in outs[0]:
+            assert np.array_equal(np.asarray(outs[0][k]), np.asarray(outs[1][k])), (round_, k)
+
+
 @pytest.mark.parametrize("B", [2, 64])
 def test_baseline_model_matches_oracle(mano_arrays, B):
     """InterHandModel.test(): encoder -> separate right/left MANO -> shift -> projection -> collision metric.
