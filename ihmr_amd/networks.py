@@ -188,8 +188,9 @@ class InterHandEncoder(nn.Module):
         bufs[1][:, :1024].copy_(bufs[0][:, :1024])
         self.feat = bufs[1][:, :1024]            # networks.py:68 -- the 1024-d image feature the MLP stages consume as `img_feat`
         mp = getattr(self, "_mean_dev", None)     # device copy made once (a host-to-device copy cannot be captured in a graph)
-        if mp is None or mp.device != dev or mp.shape != self.mean_params.shape:
+        if mp is None or mp.device != dev or getattr(self, "_mean_src", None) is not self.mean_params:
             mp = self._mean_dev = self.mean_params.to(dev)
+            self._mean_src = self.mean_params
         bufs[0][:, 1024:1024 + nparam].copy_(mp if mp.shape[0] == B else mp[:1].expand(B, -1))
         cur = 0
         for _ in range(3):  # networks.py:71-75: params += Linear([feat | params])
