@@ -1,3 +1,7 @@
+"""Shader clock INSIDE the Stream-K launches of whole encoder passes run back to back (5, 50, 400 passes): the clock ramps with sustained load
+(2.18 -> 2.33 -> 2.34 GHz), the pass time settles at 5.72-5.8 ms.  Needs an experiment build:
+   hipcc <HIPCC_FLAGS of ihmr_amd/hip.py> -DCONV_STAMPS ihmr_amd/csrc/ihmr_hip.hip -o build/ab/conv_stamps.so
+   IHMR_HIP_LIBRARY=build/ab/conv_stamps.so python3 scripts/experiments/encoder_clock_in_pass.py"""
 import ctypes as C, os, sys, types, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
