@@ -352,7 +352,8 @@ def encoder_traffic():
     if prefix is None:
         return None, None
     rows = profile_rows(prefix, "pmc_traffic", "conv_")
-    stem = [r for r in rows if r["kernel"].startswith("conv_igemm_kernel") and "false>" in r["kernel"]]
+    # the stem is the only layer on the 4-channel gather: conv_igemm_kernel<BM, BN, MODE = CONV_C4 (2)>
+    stem = [r for r in rows if r["kernel"].startswith("conv_igemm_kernel") and r["kernel"].rstrip().endswith(", 2>")]
     if not rows or not stem:
         return None, None
     fwd = sum(int(r["launches"]) for r in stem)
@@ -735,7 +736,17 @@ def main():
         return dt, r
 
     run_steps(max(args.warmup, 0))
+    # (experiment builds only, -DIHMR_TIMELINE + IHMR_TIMELINE_OUT=<file.npy>: workgroup records of the timed region, scripts/timeline_wg.py)
+    tl_out = os.environ.get("IHMR_TIMELINE_OUT") if hasattr(hip.lib(), "ihmr_debug_timeline") else None
+    if tl_out:
+        hip.lib().ihmr_debug_timeline.restype = C.c_long
+        hip.lib().ihmr_debug_timeline.argtypes = [C.c_void_p, C.c_long]
+        assert hip.lib().ihmr_debug_timeline(None, 4 << 20) == 0
     elapsed, res = timed(args.steps, inputs)
+    if tl_out:
+        rec = np.zeros((4 << 20, 3), np.uint64)
+        n_rec = hip.lib().ihmr_debug_timeline(rec.ctypes.data, 0)
+        np.save(tl_out, rec[:max(n_rec, 0)])
     ms_per_step = 1000.0 * elapsed / args.steps
     value = world * B * args.steps / elapsed
     # the same K steps with the per-step host-to-device copy of the inputs inside the timed region (never `value`)

@@ -22,6 +22,36 @@
         if (_e != hipSuccess) return (int)_e; \
     } while (0)
 
+// Workgroup timeline (experiment builds only, -DIHMR_TIMELINE; scripts/timeline_wg.py): every workgroup of the instrumented kernels
+// appends (kind, waves, start, end, hardware id) to a ring -- constant 100 MHz wall clock, the same on every CU -- from which the
+// host reconstructs how many waves of which kernel were resident when: what the kernels of several streams really overlap
+// (a rocprofv3 kernel trace serialises the dispatches it times and cannot show it).
+#ifdef IHMR_TIMELINE
+__device__ unsigned long long* g_tl_ring = nullptr;      // [TL_SEGS][seg_cap][3]
+__device__ unsigned g_tl_cap = 0, g_tl_cursor[256 * 32];   // records per segment; one cursor per segment, 128 bytes apart (1.8 M atomics
+                                                           // on ONE address took as long as the run: 12 M/s across the XCDs)
+struct TlScope {
+    unsigned long long t0; unsigned kind;
+    __device__ __forceinline__ TlScope(unsigned k) : t0(wall_clock64()), kind(k) {}
+    __device__ __forceinline__ ~TlScope() {
+        if (threadIdx.x == 0 && g_tl_ring) {
+            const unsigned seg = (blockIdx.x * 7u + kind * 41u) & 255u;
+            const unsigned i = atomicAdd(&g_tl_cursor[seg * 32], 1u);
+            if (i < g_tl_cap) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                unsigned long long* r = g_tl_ring + 3 * ((size_t)seg * g_tl_cap + i);
+                r[0] = t0 | ((unsigned long long)kind << 58) | ((unsigned long long)(blockDim.x / 64) << 52);
+                r[1] = wall_clock64();
+                r[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+            }
+        }
+    }
+};
+#define TL_SCOPE(k) TlScope tl_scope_(k)
+#else
+#define TL_SCOPE(k)
+#endif
+
 // dot product in the fixed order of the SDF arithmetic spec: fma(z, fma(y, x*x'))
 #define DOT3(ax, ay, az, bx, by, bz) __builtin_fmaf((az), (bz), __builtin_fmaf((ay), (by), (ax) * (bx)))
 

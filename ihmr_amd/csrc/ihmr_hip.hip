@@ -1070,4 +1070,36 @@ extern "C" int ihmr_debug_tail_stamps(long long* host, int zero) {
 }
 #endif
 
+#ifdef IHMR_TIMELINE
+// experiment builds only (scripts/timeline_wg.py): cap > 0 -- allocate a ring of `cap` workgroup records (256 segments) and start
+// recording; cap == 0 -- copy the records out (host: [n][3] uint64, n = return value) and stop
+extern "C" long ihmr_debug_timeline(unsigned long long* host, long cap) {
+    static unsigned long long* ring = nullptr;
+    static unsigned seg_cap = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    void* cur = nullptr;
+    if (hipGetSymbolAddress(&cur, HIP_SYMBOL(g_tl_cursor)) != hipSuccess) return -1;
+    if (cap > 0) {
+        if (ring) (void)hipFree(ring);
+        seg_cap = (unsigned)(cap / 256);
+        if (hipMalloc(&ring, (size_t)seg_cap * 256 * 24) != hipSuccess) return -1;
+        if (hipMemset(cur, 0, 256 * 32 * 4) != hipSuccess) return -1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl_cap), &seg_cap, 4) != hipSuccess) return -1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl_ring), &ring, 8) != hipSuccess) return -1;
+        return 0;
+    }
+    static unsigned counts[256 * 32];
+    if (hipMemcpy(counts, cur, sizeof(counts), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    long n = 0;
+    for (int s = 0; s < 256; ++s) {
+        const unsigned c = counts[s * 32] < seg_cap ? counts[s * 32] : seg_cap;
+        if (c && hipMemcpy(host + 3 * n, ring + 3 * (size_t)s * seg_cap, (size_t)c * 24, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        n += c;
+    }
+    unsigned long long* null = nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_ring), &null, 8);
+    return n;
+}
+#endif
+
 extern "C" const char* ihmr_version(void) { return "ihmr_hip 0.1 (gfx950)"; }

@@ -243,6 +243,7 @@ template <bool TWO_HAND, bool REUSE = false, int HG = LBS_HG>
 __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, const float* __restrict__ skel, int N, int B,
                                                                float* __restrict__ verts, float* __restrict__ joints,
                                                                float* __restrict__ v_posed_ws) {
+    TL_SCOPE(6);
     __shared__ float4 pfT[136][HG / 4];   // [e][hands 0-3 | 4-7]
     __shared__ float A_s[HG / 2][192][2];   // skinning matrices, the two hands of a pair interleaved
     __shared__ float beta_s[10][HG];  // [l][hand]
@@ -915,6 +916,7 @@ __global__ __launch_bounds__(LBS_THREADS, 4) void lbs_bwd1_kernel(ihmr_mano m, L
 // lane then streams 64 contiguous bytes of its basis row / its hand's gradient row, no LDS staging.
 typedef float lbs_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(64) void lbs_bwd2_kernel(ihmr_mano m, LbsWork wk, int N) {
+    TL_SCOPE(8);
     const int lane = threadIdx.x, l31 = lane & 31, kp = lane >> 5;
     const int e = blockIdx.x * 32 + l31, hand = blockIdx.y * 32 + l31, kg = blockIdx.z;
     const float* arow = m.posedirs + (size_t)min(e, NPF - 1) * NV3;
@@ -980,6 +982,7 @@ __global__ __launch_bounds__(64) void lbs_bwd2_kernel(ihmr_mano m, LbsWork wk, i
 #define LBS_B2_LDK 33
 #define LBS_B2_ROWS (160 + 64)
 __global__ __launch_bounds__(320) void lbs_bwd2_lds_kernel(ihmr_mano m, LbsWork wk, int N) {
+    TL_SCOPE(8);
     __shared__ float tile[2][LBS_B2_ROWS][LBS_B2_LDK];
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE, l31 = lane & 31, kp = lane >> 5;
     const int h0 = blockIdx.x * 64, kg = blockIdx.y;
@@ -1058,6 +1061,7 @@ __global__ __launch_bounds__(320) void lbs_bwd2_lds_kernel(ihmr_mano m, LbsWork 
 // then lanes 1..15 = joints.
 template <bool TWO_HAND>
 __global__ __launch_bounds__(64) void lbs_bwd3_kernel(LbsWork wk, int N, int B, float* __restrict__ d_pose) {
+    TL_SCOPE(9);
     __shared__ float dpf[192];
     const int h = blockIdx.x, j = threadIdx.x;
 #pragma unroll

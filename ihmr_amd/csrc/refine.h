@@ -279,6 +279,7 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
 #define OPT_SAMPLE_WORKERS (SDF_SAMPLE_THREADS - WAVE)
 __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void opt_sample_loss_kernel(ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,
                                                                              VertLayout vl, SdfWorkspace ws, int need_cam, MlpSelect sel) {
+    TL_SCOPE(10);
     __shared__ LossShared sh;
     __shared__ float red16[SDF_SAMPLE_THREADS / WAVE];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(128) void opt_adam_kernel(ihmr_opt_io io, OptWork w
 // hand's wrist shift reads the right hand's shape and the shared translation (optimize_model.py:196-206).
 __global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_opt_io io, OptWork wk, int B, ParamStep st,
                                                             int* inside_count) {
+    TL_SCOPE(7);
     __shared__ float sk[2][SK_STRIDE];
     const int b = blockIdx.x, tid = threadIdx.x;
     // the collision kernels of this iteration append to the inside-voxel counter: start it at zero
@@ -408,6 +410,7 @@ template <bool STEP, bool SKIN = false>
 __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_mano m, ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,
                                                                          VertLayout vl, SdfWorkspace ws, int need_cam, int need_mask,
                                                                          ParamStep st, int* inside_count) {
+    TL_SCOPE(3 + (STEP ? 1 : 0) + (SKIN ? 1 : 0));
     __shared__ LossShared sh;
     __shared__ float red16[SDF_SAMPLE_THREADS / WAVE];
     __shared__ LbsBwdShared bw[2];

@@ -83,7 +83,9 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     unsigned* lbits;           // [H][1024]  bit i of word (k,j): voxel (k,j,i) has a candidate list (cleared when the hand starts over)
     unsigned* rbits;           // [H][1024]  ... was REFUSED a list (too long) since the hand started over: searched in full every iteration, without
                                //            the list-building half of that search (its entry in inside_list carries SDF_ENT_REFUSED)
-    unsigned* lmap;            // [H][32768] voxel -> its list | (the triangle that was nearest the last time it was evaluated) << 16
+    uint2* lmap;               // [H][32768] voxel -> .x = its list | (the triangle that was nearest the last time it was evaluated) << 16,
+                               //            .y = that triangle's packed corner ids (fpk[triangle]: the list search starts with the exact
+                               //            distance to it -- with the ids here its corners are requested one round trip earlier)
                                //            (defined where lbits is set)
     unsigned short* lists;     // [H][SDF_LCAP_V][SDF_LCAP_L] triangle ids
     unsigned* inside_list_a;   // [xcd_cap] inside voxels of the hands whose lists are valid (aligned run per hand; inside_count[1])
@@ -120,7 +122,7 @@ __host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)H * (SDF_N
 #define SDF_LIST_SLACK 0.04f         // lists stay valid while no vertex of the hand has moved further than this (normalised frame)
 #endif
 __host__ __device__ inline size_t sdf_list_bytes(int H) {
-    return (size_t)H * ((size_t)NV3 * 4 + 16 + (size_t)4 * SDF_NCOL * 4 + (size_t)SDF_NVOX * 4 + (size_t)SDF_LCAP_V * SDF_LCAP_L * 2) +
+    return (size_t)H * ((size_t)NV3 * 4 + 16 + (size_t)4 * SDF_NCOL * 4 + (size_t)SDF_NVOX * 8 + (size_t)SDF_LCAP_V * SDF_LCAP_L * 2) +
            sdf_xcd_cap(H) * sizeof(unsigned) + 1024;
 }
 __host__ __device__ inline size_t sdf_ws_bytes(int H, bool lists = false) {
@@ -168,7 +170,7 @@ static inline SdfWorkspace sdf_carve(void* ws, int H, bool lists = false) {
         w.known = (unsigned*)p; p += (size_t)H * SDF_NCOL * 4;
         w.inside_k = (unsigned*)p; p += (size_t)H * SDF_NCOL * 4;
         w.inside_list_a = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
-        w.lmap = (unsigned*)p; p += (size_t)H * SDF_NVOX * 4;
+        w.lmap = (uint2*)p; p += (size_t)H * SDF_NVOX * 8;
         p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         w.lists = (unsigned short*)p;
     }
@@ -215,6 +217,10 @@ __device__ __forceinline__ float sdf_div(float a, const SdfDivisor& d) {
 // issuing wave's vmcnt only -- a workgroup barrier alone does not wait for them), then the barrier makes all waves' pieces visible
 // to all (the form of CK's block_sync_lds_direct_load).  n16 16-byte units by 256 threads.
 #define SDF_STAGE_CLOSE() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+// ... the same, but the wave's YOUNGEST vector-memory load may stay in flight (loads return in order: when at most one operation is
+// outstanding, every load older than the youngest -- the DMA pieces, issued first -- has returned; outstanding stores of an earlier
+// phase only make the wait longer).  The caller issues exactly such a load last (a prefetch nobody waits for here).
+#define SDF_STAGE_CLOSE_KEEP1() do { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); __syncthreads(); } while (0)
 __device__ __forceinline__ void sdf_stage_async(const void* __restrict__ src, char* dst_lds, int n16) {
     const int tid = threadIdx.x, wave = tid / WAVE;
     for (int base = wave * WAVE; base < n16; base += SDF_THREADS) {
@@ -345,6 +351,7 @@ template <bool DENSE, int PT>
 __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, const int32_t* __restrict__ faces_r,
                                                                     const int32_t* __restrict__ faces_l, SdfWorkspace ws,
                                                                     int collect_stats) {
+    TL_SCOPE(1);
     constexpr int CPT = SDF_NCOL / PT;             // adjacent grid columns owned by a thread
     constexpr int VPT = (NV + PT - 1) / PT;         // vertices owned by a thread
     __shared__ float vn[NV3];
@@ -988,6 +995,39 @@ struct SdfAcc {
     SDF_TK(long long tk[7] = {0, 0, 0, 0, 0, 0, 0};)      // items, front, (full: sphere passes), (list: walk), refine, exact, -
 };
 
+// What a list-search item needs first from memory -- its lane's list entry, the entry's map word and the corner ids of the triangle
+// that was nearest last time -- is two dependent round trips before the item's own loads (list pieces, corners) can even be
+// requested; a workgroup of the persistent grid lives for ~2.5 items, so those round trips were a fifth of its lifetime (stamps, round 5:
+// the front of a list item 11.3 k of its 26 k cycles).  Every item therefore requests them for the NEXT list item of its workgroup
+// (`ni`; the first three units of a workgroup are static, later ones are known a unit ahead) beside its own loads: they ride on
+// round trips the item pays anyway, and the next item starts with its pieces and corners.  `item` says whose data `pre` holds;
+// an item that finds another one loads its own (sdf_list_pre_sync: the first item of a workgroup).
+struct SdfPre {
+    unsigned ent;      // this lane's entry of inside_list_a (the K lanes of a group hold the same), 0xffffffff = padding
+    unsigned lw, pk;   // lmap[voxel] of the entry (zeros for padding)
+    int H, item;       // the item's hand (uniform); the item (uniform; -1: nothing valid)
+};
+// The map words are requested in one place (sdf_list_pre_issue) and turned into `pre` in another (sdf_list_pre_finish: the first
+// arithmetic on them, i.e. where the wave waits for them) -- at the END of the requesting item, before its stores: the load has had
+// the whole item to land, and the next item starts on registers nothing is pending on (a value still in flight across the loop's
+// back-edge makes hipcc wait for EVERYTHING outstanding at its first use).
+struct SdfPreLoad { unsigned ent; uint2 lw; int H; };
+// (loads only from addresses that are valid whatever `e0` / `ent` hold: a padding lane reads voxel 0 of hand H)
+__device__ __forceinline__ SdfPreLoad sdf_list_pre_issue(const SdfWorkspace& ws, unsigned e0, unsigned ent) {
+    const int H = __builtin_amdgcn_readfirstlane((int)(e0 >> 16));      // entry 0 of an item is always valid
+    return SdfPreLoad{ent, ws.lmap[(size_t)H * SDF_NVOX + (ent != 0xffffffffu ? (ent & 0xffffu) : 0u)], H};
+}
+__device__ __forceinline__ void sdf_list_pre_finish(const SdfPreLoad& l, int item, SdfPre& pre) {
+    const bool has = l.ent != 0xffffffffu;
+    pre.ent = l.ent; pre.lw = has ? l.lw.x : 0u; pre.pk = has ? l.lw.y : 0u; pre.H = l.H; pre.item = item;
+}
+__device__ __forceinline__ void sdf_list_pre_sync(const SdfWorkspace& ws, int item, SdfPre& pre) {
+    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+    const unsigned* g = ws.inside_list_a + (size_t)item * SDF_LIST_ITEM;
+    const unsigned e0 = g[0], ent = g[wave * (WAVE / SDF_LIST_K) + lane / SDF_LIST_K];
+    sdf_list_pre_finish(sdf_list_pre_issue(ws, e0, ent), item, pre);
+}
+
 // ------------------------------------------------------------------------------------- distance: full search
 // (one of the two searches of sdf_dist_kernel, below; grid-strided over its slots.)  The inside voxels of
 // the whole batch sit in one list (balanced work matters more here than L2 affinity: the per-sample counts vary
@@ -1000,7 +1040,8 @@ struct SdfAcc {
 // voxels per wave, two passes), 0 / 1: one half of it (two workgroups share the item when there are few: two voxels per wave = ONE
 // pass -- a small launch is as long as its longest item).  curH = the hand whose table the workgroup's LDS holds.
 template <bool STATS>
-__device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, int half, char* smem, int& curH, SdfAcc& acc) {
+__device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, int half, char* smem, int& curH, SdfAcc& acc, int ni,
+                                              SdfPre& pre) {
     const float4* const sph_s = reinterpret_cast<const float4*>(smem);                                  // [NFP] (centre, radius)
     const unsigned* const nrm_s = reinterpret_cast<const unsigned*>(smem + NFP * 16);                   // [SDF_NRM_N]
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
@@ -1197,7 +1238,16 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
 #pragma unroll 1
         for (int k = 0; k < nj; ++k)
             pair_pass(k == 0 ? j_ent0[0] : j_ent0[1], k == 0 ? j_ent1[0] : j_ent1[1], 2 * k, lidx_base + 8 * k);
+        // the entries of the workgroup's next list-search item (SdfPre; uniform branch): requested now -- the sphere passes' registers
+        // are free again --, their map words after the queue has been worked off
+        unsigned n_e0 = 0u, n_ent = 0xffffffffu;
+        if (ni >= 0) {
+            const unsigned* g = ws.inside_list_a + (size_t)ni * SDF_LIST_ITEM;
+            n_e0 = g[0]; n_ent = g[wave * (WAVE / SDF_LIST_K) + lane / SDF_LIST_K];
+        }
         flush();
+        SdfPreLoad nl{0xffffffffu, make_uint2(0u, 0u), 0};
+        if (ni >= 0) nl = sdf_list_pre_issue(ws, n_e0, n_ent);
         SDF_TK(tk[0] += 1; tk[1] += tk1 - tk0; tk[2] += (SDF_STAMP() - tk1) - (tk[4] + tk[5] - tk_r0);)
         SDF_CNT(st_full += (unsigned)(lane == 0 ? nmine : 0));
         SDF_CNT(st_build += (unsigned)(lane == 0 && mode == 0 ? nmine : 0));
@@ -1210,8 +1260,9 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
             const unsigned tri = (unsigned)(bst & 0xffffu) < (unsigned)NF ? (unsigned)(bst & 0xffffu) : 0u;
             const int lslot = mode == 0 ? lidx_base + 4 * lane : my_slot;
             if (mode >= 0 && lslot < SDF_LCAP_V)
-                ws.lmap[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = (unsigned)lslot | (tri << 16);
+                ws.lmap[(size_t)H * SDF_NVOX + (ent & 0xffffu)] = make_uint2((unsigned)lslot | (tri << 16), fpk[tri]);
         }
+        sdf_list_pre_finish(nl, ni, pre);       // (always assigned: nothing of `pre` is live across the sphere passes)
         SDF_WAVE_SYNC();
     }
 }
@@ -1229,7 +1280,7 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
 #define SDF_LIST_VPW (WAVE / SDF_LIST_K)          // voxels per wave
 #define SDF_LIST_PIECE (SDF_LCAP_L / SDF_LIST_K / 8)   // 16-byte loads per lane
 template <bool STATS>
-__device__ __forceinline__ void sdf_list_item(const SdfWorkspace& ws, int item, char* smem, int& curH, SdfAcc& acc) {
+__device__ __forceinline__ void sdf_list_item(const SdfWorkspace& ws, int item, int ni, char* smem, int& curH, SdfAcc& acc, SdfPre& pre) {
     const float4* const tab_s = reinterpret_cast<const float4*>(smem);                                  // [NFP] (centre, radius)
     const unsigned* const nrm_s = reinterpret_cast<const unsigned*>(smem + NFP * 16);                   // [SDF_NRM_N]
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
@@ -1240,34 +1291,51 @@ __device__ __forceinline__ void sdf_list_item(const SdfWorkspace& ws, int item, 
     unsigned& st_ref = acc.ref;
     SDF_TK(long long* const tk = acc.tk;)
     {
-        // the hand (entry 0 of an item is always valid); a new hand's table is requested first (global -> LDS, asynchronous) ...
+        // this item's entries, map words and bound-triangle corner ids: requested by the workgroup's previous item (SdfPre), or now
         SDF_TK(const long long tk0 = SDF_STAMP();)
-        const int H = __builtin_amdgcn_readfirstlane((int)(glist[item * SDF_LIST_ITEM] >> 16));
+        if (pre.item != item) sdf_list_pre_sync(ws, item, pre);          // (uniform; the first item of a workgroup)
+        const int H = pre.H;
         const bool stage = H != curH;          // uniform over the workgroup
+        // a new hand's table is requested first (global -> LDS, asynchronous) ...
         if (stage) {
             SDF_LDS_BARRIER();          // (the previous table's readers are done; LDS traffic only)
             sdf_stage_table(ws, H, smem);
         }
+        asm volatile("" ::: "memory");         // (the DMA requests are the wave's oldest: SDF_STAGE_CLOSE_KEEP1 below)
+        // ... then the entries of the workgroup's NEXT list item (none: this item's again -- valid addresses, nobody uses them) ...
+        const int nj = ni >= 0 ? ni : item;
+        const unsigned n_e0 = glist[(size_t)nj * SDF_LIST_ITEM], n_ent = glist[(size_t)nj * SDF_LIST_ITEM + wave * SDF_LIST_VPW + grp];
         // ... then this lane's voxel (the same for the K lanes of a group) and everything it needs from memory: all of it in flight
         // while the table goes to LDS
-        const unsigned ent = glist[item * SDF_LIST_ITEM + wave * SDF_LIST_VPW + grp];
+        const unsigned ent = pre.ent;
         const bool has = ent != 0xffffffffu;
         const unsigned vox = has ? (ent & 0xffffu) : 0u;
-        unsigned* const lword = ws.lmap + (size_t)H * SDF_NVOX + vox;
-        const unsigned lw = has ? *lword : 0u;
+        uint2* const lword = ws.lmap + (size_t)H * SDF_NVOX + vox;
+        const unsigned lw = pre.lw;
         const int nr = (int)(lw >> 16);
         const float4* vn4 = ws.vn4 + (size_t)H * SDF_NV4;
         const unsigned* fpk = ws.fpk[H >= ws.B ? 1 : 0];
+        // (a padding lane reads list 0 / vertex 0 of the hand and discards them: no load of this phase sits behind a branch, so that
+        // hipcc counts the outstanding loads exactly -- vmcnt(n), not vmcnt(0), at their first uses)
         const uint4* piece = reinterpret_cast<const uint4*>(ws.lists + ((size_t)H * SDF_LCAP_V + (lw & 0xffffu)) * SDF_LCAP_L) + sub * SDF_LIST_PIECE;
         uint4 ids4[SDF_LIST_PIECE];
-        constexpr unsigned PK = (unsigned)(NFP - 1) | ((unsigned)(NFP - 1) << 16);     // parked padding
 #pragma unroll
-        for (int c = 0; c < SDF_LIST_PIECE; ++c) ids4[c] = has ? piece[c] : make_uint4(PK, PK, PK, PK);
-        const unsigned pk0 = fpk[nr];
+        for (int c = 0; c < SDF_LIST_PIECE; ++c) ids4[c] = piece[c];
+        const unsigned pk0 = pre.pk;
         const float4 A0 = vn4[pk0 & 1023u], B0 = vn4[(pk0 >> 10) & 1023u], C0 = vn4[pk0 >> 20];
+        // the next item's map words: its entries were requested before this item's pieces and corners and land with them; the map
+        // words themselves are this phase's youngest load and stay in flight behind the item's work
+        __builtin_amdgcn_sched_barrier(0);
+        const SdfPreLoad nl = sdf_list_pre_issue(ws, n_e0, n_ent);
+        __builtin_amdgcn_sched_barrier(0);
         if (stage) {
-            SDF_STAGE_CLOSE();          // the table has landed (waits for this wave's other loads too: they were all in flight)
+            SDF_STAGE_CLOSE_KEEP1();    // the table has landed (waits for this wave's pieces and corners too: they were all in flight)
             curH = H;
+        }
+        constexpr unsigned PK = (unsigned)(NFP - 1) | ((unsigned)(NFP - 1) << 16);     // parked padding
+        if (!has) {
+#pragma unroll
+            for (int c = 0; c < SDF_LIST_PIECE; ++c) ids4[c] = make_uint4(PK, PK, PK, PK);
         }
         float px, py, pz;
         sdf_vox_centre((int)vox, px, py, pz);
@@ -1334,10 +1402,13 @@ __device__ __forceinline__ void sdf_list_item(const SdfWorkspace& ws, int item, 
         }
         flush();
         SDF_TK(tk[0] += 1; tk[1] += tk1 - tk0; tk[3] += (SDF_STAMP() - tk2) - (tk[4] + tk[5] - tk_r0);)
+        sdf_list_pre_finish(nl, ni, pre);          // (before this item's stores: nothing else is in flight)
         if (has && sub == 0) {
             const unsigned long long bst = w.best[grp];
             ws.phi[(size_t)H * SDF_NVOX + vox] = sqrtf(__uint_as_float((unsigned)(bst >> 32)));
-            reinterpret_cast<unsigned short*>(lword)[1] = (unsigned short)(bst & 0xffffu);
+            // the nearest triangle starts the voxel's next evaluation: its id and corner ids go to the map word when they change (rarely)
+            const unsigned nt = (unsigned)(bst & 0xffffu);
+            if ((int)nt != nr) *lword = make_uint2((lw & 0xffffu) | (nt << 16), fpk[nt]);
         }
         if (STATS) {
             const unsigned long long mh = __ballot(has && sub == 0);
@@ -1358,6 +1429,7 @@ __device__ __forceinline__ void sdf_list_item(const SdfWorkspace& ws, int item, 
 // the same table format, so a workgroup that moves from a hand's full-search item to its list items keeps the table.
 template <bool STATS>
 __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace ws) {
+    TL_SCOPE(2);
     __shared__ __attribute__((aligned(16))) char smem[SDF_DIST_LDS];
     __shared__ int s_next[2];
 #ifdef SDF_STAMPS
@@ -1391,23 +1463,39 @@ __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace w
     // carry riders are 15-20 us chains -- 47.7 -> 57.8 us per 512 samples even when they go first, 16.4 -> 27.5 us per 64.)
     int* const cursor = ws.inside_count + SDF_CURSOR;                     // zero on entry (zeroed with the list counters)
     SdfAcc acc;
-    int curH = -1, round = 0;
-    for (int unit = (int)blockIdx.x; unit < total; ++round) {              // uniform over the workgroup
-        const bool own_next = round == 0;                                  // the second unit is static
-        int nxt = 0;
-        if (!own_next && tid == 0) nxt = 2 * nwg + atomicAdd(cursor, 1);
-        if (unit < u_full) {
-            sdf_full_item<STATS>(ws, unit / split, split == 2 ? unit % 2 : -1, smem, curH, acc);
-        } else if (unit < u_pair) {
-            const int i0 = (unit - u_full) * pair;
-            for (int i = i0; i < i0 + pair; ++i) sdf_list_item<STATS>(ws, i, smem, curH, acc);
-        } else {
-            sdf_list_item<STATS>(ws, n_paired + (unit - u_pair), smem, curH, acc);
+    SdfPre pre{0xffffffffu, 0u, 0u, -1, -1};
+    int curH = -1;
+    // first list-search item of a unit (-1: a full-search unit, or none) and how many it has
+    auto list_first = [&](int u) { return (u < u_full || u >= total) ? -1 : (u < u_pair ? (u - u_full) * pair : n_paired + (u - u_pair)); };
+    // Units b, nwg + b and 2 nwg + b belong to workgroup b; every further one comes from the cursor, requested a unit AHEAD (at the top of
+    // the unit before the one it follows) so that a workgroup always knows its next unit: the last item of a unit requests the first
+    // loads of the next unit's first item (SdfPre).
+    int unit = (int)blockIdx.x, unext = nwg + (int)blockIdx.x, round = 0;
+    int nxt = 0;
+    auto request = [&]() { if (round > 0 && tid == 0) nxt = 3 * nwg + atomicAdd(cursor, 1); };          // the unit after `unext`
+    auto advance = [&]() {          // uniform over the workgroup
+        unit = unext;
+        if (round == 0) { unext = 2 * nwg + (int)blockIdx.x; }
+        else {
+            if (tid == 0) s_next[round & 1] = nxt;
+            __syncthreads();
+            unext = s_next[round & 1];
         }
-        if (own_next) { unit = nwg + (int)blockIdx.x; continue; }
-        if (tid == 0) s_next[round & 1] = nxt;
-        __syncthreads();
-        unit = s_next[round & 1];
+        ++round;
+    };
+    // (a workgroup's units come in ascending order: its full-search units first -- two loops, so that the list search's prefetched
+    // state is not live across the full search, which has no register to spare)
+    while (unit < u_full) {
+        request();
+        sdf_full_item<STATS>(ws, unit / split, split == 2 ? unit % 2 : -1, smem, curH, acc, list_first(unext), pre);
+        advance();
+    }
+    while (unit < total) {
+        request();
+        const int nfirst = list_first(unext);
+        const int i0 = list_first(unit), i1 = i0 + (unit < u_pair ? pair : 1);
+        for (int i = i0; i < i1; ++i) sdf_list_item<STATS>(ws, i, i + 1 < i1 ? i + 1 : nfirst, smem, curH, acc, pre);
+        advance();
     }
     const int lane = tid % WAVE;
     if (STATS) {

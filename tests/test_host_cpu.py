@@ -224,6 +224,22 @@ def test_committed_profiles_belong_to_the_committed_sources():
     assert any("_f7_" in f for f in hits) and any("baseline" in f for f in hits) and any("mlp" in f for f in hits), hits
 
 
+def test_bench_finds_the_encoder_traffic_in_the_committed_profile(monkeypatch):
+    """`secondary_configs.baseline.roofline.traffic` comes from the committed PMC profile of `bench.py --config baseline`: the stem is
+    found by its template MODE (round 4's line showed null: the filter still looked for a template argument the kernel no longer has)."""
+    import json as _json
+    import bench
+    from ihmr_amd import hip
+    prof = os.path.join(ROOT, "profiles")
+    metas = sorted(f for f in os.listdir(prof) if f.endswith("_baseline_meta.json") and f[:2] >= "r4")
+    assert metas
+    with open(os.path.join(prof, metas[-1])) as fh:
+        good = _json.load(fh)["srchash"]
+    monkeypatch.setattr(hip, "loaded_source_hash", lambda: good)
+    traffic, src = bench.encoder_traffic()
+    assert src and src.startswith("profiles/") and 2e9 < traffic < 3e10, (traffic, src)
+
+
 def test_committed_profile_carries_what_the_bench_line_quotes():
     """The rows `bench.py` reads from the committed profile of the driver's launch size exist and are plausible: HBM bytes per launch
     of the dominant kernel (`roofline.traffic`), its mean duration, and its vector-instruction count (`roofline.valu.issue_slots`)."""
