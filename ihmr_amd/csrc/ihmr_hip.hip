@@ -173,10 +173,11 @@ extern "C" int ihmr_mano_create(const ihmr_mano_arrays* h, ihmr_mano** out) {
         (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
         const void* tails[3] = {(const void*)opt_tail_kernel<true, true>, (const void*)opt_tail_kernel<true>, (const void*)opt_tail_kernel<false>};
         m->tail_fits = 1;
+        const int tail_dyn = opt_tail_dynamic_lds(m->nseg);
         for (const void* k : tails) {
             hipFuncAttributes fa;
-            if (hipFuncGetAttributes(&fa, k) != hipSuccess || (long)fa.sharedSizeBytes + 2 * dyn > (long)lds_max ||
-                hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * dyn) != hipSuccess)
+            if (hipFuncGetAttributes(&fa, k) != hipSuccess || (long)fa.sharedSizeBytes + tail_dyn > (long)lds_max ||
+                hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, tail_dyn) != hipSuccess)
                 m->tail_fits = 0;
         }
         (void)hipGetLastError();
@@ -474,7 +475,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     const int static_mask = ((pm & (IHMR_PB_ORIENT_R | IHMR_PB_POSE_R | IHMR_PB_SHAPE_R)) ? 0 : 1) |
                             ((pm & (IHMR_PB_ORIENT_L | IHMR_PB_POSE_L | IHMR_PB_SHAPE_L | IHMR_PB_TRANS | IHMR_PB_SHAPE_R)) ? 0 : 2);
     const bool pose_stage = (need_mask & 2) != 0;
-    const size_t tail_lds = (size_t)2 * m->nseg * 12 * sizeof(float);
+    const size_t tail_lds = (size_t)opt_tail_dynamic_lds(m->nseg);
     for (int it = 0; it < sg->n_iters; ++it) {
         // the first iteration of a stage starts the candidate lists over: the select step of the previous stage may have moved
         // the parameters by more than one optimizer step
@@ -1062,10 +1063,12 @@ extern "C" int ihmr_debug_conv_stamps(long long* host, int zero) {
 // experiment builds only (scripts/tail_stamps.py): zero = 1 clears, zero = 0 copies the 3 x 4096 x 8 phase sums of opt_tail_kernel out
 extern "C" int ihmr_debug_tail_stamps(long long* host, int zero) {
     HIP_TRY(hipDeviceSynchronize());
-    void* p;
+    void *p, *q;
     HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_tail_stamps)));
-    if (zero) { HIP_TRY(hipMemset(p, 0, sizeof(long long) * 3 * 4096 * 8)); return 0; }
+    HIP_TRY(hipGetSymbolAddress(&q, HIP_SYMBOL(g_samp_stamps)));
+    if (zero) { HIP_TRY(hipMemset(p, 0, sizeof(long long) * 3 * 4096 * 8)); HIP_TRY(hipMemset(q, 0, sizeof(long long) * 4096 * 8)); return 0; }
     HIP_TRY(hipMemcpy(host, p, sizeof(long long) * 3 * 4096 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host + 3 * 4096 * 8, q, sizeof(long long) * 4096 * 8, hipMemcpyDeviceToHost));      // the sampler's own phases
     return 0;
 }
 #endif

@@ -69,6 +69,10 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     float* phi;                // [H][32768]  (only the INSIDE voxels a sample reads are defined; the dense-grid diagnostic defines all)
     unsigned* inside_bits;     // [H][1024]   bit i of word (k,j): voxel (k,j,i) is read by a sample AND inside the mesh, i.e. phi holds its distance;
                                //             every other voxel is 0 by definition and is never written or read (round 4: was 128-byte rows of zeros)
+    unsigned* qcell;           // [B][2][778] per sampling entry (hand, query vertex of the OTHER hand): the grid cell the query falls into, as the
+                               //            prep kernel computed it while forming the needed-voxel mask -- SDF_QCELL_IN | (i0 + 1) | (j0 + 1) << 6 |
+                               //            (k0 + 1) << 12, or 0 for a query outside the grid.  The fused sampler starts from these words instead
+                               //            of redoing the normalisation of all 1556 queries (most of which touch no inside voxel)
     unsigned* inside_list;     // [xcd_cap] inside voxels of the whole batch: (hand << 16) | voxel id, 16-aligned run per hand
     int* inside_count;         // [SDF_NCTR] [0] entries in inside_list, [1] in inside_list_a; [SDF_CURSOR] the distance kernel's work cursor, on a
                                //            128-byte line of its own (the counters are read while the cursor is hammered)
@@ -107,6 +111,7 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
                                //    to grid_sample as it is); 0 (default): phi[z][y][x], the layout grid_sample's (x, y, z) addresses
 };
 
+#define SDF_QCELL_IN 0x80000000u
 #define SDF_ENT_REFUSED 0x80000000u  // inside_list entry: (hand << 16) | voxel, hand < 32768; 0xffffffff = padding
 #define SDF_NCTR 64
 #define SDF_CURSOR 32
@@ -135,6 +140,7 @@ __host__ __device__ inline size_t sdf_ws_bytes(int H, bool lists = false) {
     n += (size_t)H * SDF_NCOL * sizeof(unsigned);   // inside_bits
     n += sdf_xcd_cap(H) * sizeof(unsigned);
     n += 128 + SDF_NCTR * 4 + 256;
+    n += ((size_t)H * NV * sizeof(unsigned) + 255) & ~(size_t)255;      // qcell
     return (n + 255) & ~(size_t)255;
 }
 
@@ -153,6 +159,7 @@ static inline SdfWorkspace sdf_carve(void* ws, int H, bool lists = false) {
     w.inside_count = (int*)p; p += SDF_NCTR * 4;
     w.xcd_cap = (int)sdf_xcd_cap(H);
     w.inside_list = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
+    w.qcell = (unsigned*)p; p += ((size_t)H * NV * sizeof(unsigned) + 255) & ~(size_t)255;
     w.vn_ref = nullptr; w.hmode = nullptr; w.run_start = nullptr; w.hdisp = nullptr; w.lnext = nullptr; w.lbits = nullptr; w.rbits = nullptr; w.lmap = nullptr; w.lists = nullptr; w.known = nullptr; w.inside_k = nullptr;
     w.static_mask = 0; w.static_stage = 0;
     w.inside_list_a = nullptr;
@@ -360,6 +367,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     __shared__ unsigned parity[SDF_NCOL];
     __shared__ int cur[SDF_NCOL];
     __shared__ float red[6][PT / WAVE];
+    __shared__ float red_disp[PT / WAVE];   // per wave: how far its vertices have moved from the reference pose of the hand's candidate lists
     __shared__ int scratch[PT / WAVE];
     __shared__ unsigned rayq[SDF_RAYQ];            // (triangle | column << 11) pairs of the ray-parity phase (carrying the packed corner
                                                    // ids instead of the triangle, 8 bytes per pair, is slower: 44.0 -> 47.1 us per 1024 hands)
@@ -393,11 +401,11 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     }
     // face indices of this lane's (up to four) triangles (packed: one load each): issued early, consumed after the box is known
     constexpr int TRI_IT = (NFP + PT - 1) / PT;
-    int fidx[TRI_IT][3];
+    unsigned fpkw[TRI_IT];                // (kept packed: four registers instead of twelve live to the end of the kernel)
 #pragma unroll
     for (int it = 0; it < TRI_IT; ++it) {
         const unsigned pk = ws.fpk[hnd][min(tid + it * PT, NFP - 1)];
-        fidx[it][0] = (int)(pk & 1023u); fidx[it][1] = (int)((pk >> 10) & 1023u); fidx[it][2] = (int)(pk >> 20);
+        fpkw[it] = pk;
     }
     // state of the temporal candidate lists, requested now and used much later: the hand's reference pose (this thread's vertices)
     // and which voxels of this thread's two columns have a list
@@ -453,6 +461,10 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     if (!stat && tid < 4) ws.box[H * 4 + tid] = tid == 0 ? cx : (tid == 1 ? cy : (tid == 2 ? cz : sc));
     // ---- normalise own vertices into [-1,1]^3; which voxels will the other hand's vertices read?
     const SdfDivisor dsc = sdf_divisor(sc);
+    // (temporal candidate lists: the displacement of this thread's vertices from the lists' reference pose is taken here, where the
+    // normalised coordinates are in registers, and reduced across the workgroup by the barrier this phase ends with anyway)
+    const bool disp_on = lists_on && !stat && !ws.force_rebuild;
+    float dmax = 0.f;
 #pragma unroll
     for (int rep = 0; rep < VPT; ++rep) {
         const int v = tid + rep * PT;
@@ -461,6 +473,10 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
             const float nx = sdf_div(vn[3 * v] - cx, dsc), ny = sdf_div(vn[3 * v + 1] - cy, dsc), nz = sdf_div(vn[3 * v + 2] - cz, dsc);
             vn[3 * v] = nx; vn[3 * v + 1] = ny; vn[3 * v + 2] = nz;
             ws.vn4[(size_t)H * SDF_NV4 + v] = make_float4(nx, ny, nz, 0.f);     // the exact distance gathers triangle corners from here
+            if (disp_on) {
+                const float dx = nx - rf[rep][0], dy = ny - rf[rep][1], dz = nz - rf[rep][2];
+                dmax = fmaxf(dmax, sqrtf(dx * dx + dy * dy + dz * dz));
+            }
         }
         if (!DENSE) {
             const float qx0 = sdf_div(oq[rep][0] - cx, dsc), qy = sdf_div(oq[rep][1] - cy, dsc), qz0 = sdf_div(oq[rep][2] - cz, dsc);
@@ -468,8 +484,12 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
             const float ix = sdf_unnorm(qx, ws.align_corners), iy = sdf_unnorm(qy, ws.align_corners), iz = sdf_unnorm(qz, ws.align_corners);
             const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
             // completely outside the grid (or non-finite): contributes nothing
-            if (fx >= -1.0f && fx <= (float)(SDF_G - 1) && fy >= -1.0f && fy <= (float)(SDF_G - 1) && fz >= -1.0f &&
-                fz <= (float)(SDF_G - 1)) {
+            const bool in_grid = fx >= -1.0f && fx <= (float)(SDF_G - 1) && fy >= -1.0f && fy <= (float)(SDF_G - 1) && fz >= -1.0f &&
+                                 fz <= (float)(SDF_G - 1);
+            // the query's cell for the fused sampler (entry hnd * 778 + v of sample b)
+            ws.qcell[((size_t)b * 2 + hnd) * NV + v] =
+                in_grid ? (SDF_QCELL_IN | (unsigned)((int)fx + 1) | ((unsigned)((int)fy + 1) << 6) | ((unsigned)((int)fz + 1) << 12)) : 0u;
+            if (in_grid) {
                 const int i0 = (int)fx, j0 = (int)fy, k0 = (int)fz;
                 unsigned mi = 0;
                 if (i0 >= 0) mi |= 1u << i0;
@@ -483,6 +503,10 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
                     }
             }
         }
+    }
+    if (disp_on) {
+        dmax = wave_reduce_max(dmax);
+        if (lane == 0) red_disp[wave] = dmax;
     }
     SDF_LDS_BARRIER();
     // which columns of a row hold a needed voxel at all: a wave covers two rows per pass, one ballot gives both words
@@ -500,25 +524,11 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     if (stat && tid == 0) ws.hmode[H] = -1;        // (its new voxels are searched in full, without candidate lists)
     if (lists_on && !stat) {
         float* ref = ws.vn_ref + (size_t)H * NV3;
-        float dmax = 0.f;
-        if (!ws.force_rebuild) {
-#pragma unroll
-            for (int rep = 0; rep < VPT; ++rep) {
-                const int v = tid + rep * PT;
-                if (v < NV) {
-                    const float dx = vn[3 * v] - rf[rep][0], dy = vn[3 * v + 1] - rf[rep][1], dz = vn[3 * v + 2] - rf[rep][2];
-                    dmax = fmaxf(dmax, sqrtf(dx * dx + dy * dy + dz * dz));
-                }
-            }
-            dmax = wave_reduce_max(dmax);
-            if (lane == 0) red[0][wave] = dmax;       // `red` is free again (the box is in `box`)
-        }
-        SDF_LDS_BARRIER();
         bool reuse = !ws.force_rebuild;
         float moved = 0.f;
         if (reuse) {
-            float m = red[0][0];
-            for (int w = 1; w < PT / WAVE; ++w) m = fmaxf(m, red[0][w]);
+            float m = red_disp[0];
+            for (int w = 1; w < PT / WAVE; ++w) m = fmaxf(m, red_disp[w]);
             reuse = m <= SDF_LIST_SLACK - 1e-4f;        // (a NaN compares false: rebuild)
             moved = m * 1.0001f + 1e-6f;
         }
@@ -591,62 +601,6 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     float4* sph = ws.sph + (size_t)H * NFP;
     unsigned* nrm = ws.nrm + (size_t)H * NFP;
     unsigned long long st_tests = 0;
-    // (two loops over the lane's triangles -- records, then ray parity: together they would not fit the 64 registers of 8 waves / SIMD)
-#pragma unroll 1
-    for (int it = 0; it < (stat ? 0 : TRI_IT); ++it) {        // (a static hand keeps its records)
-        const int f = tid + it * PT;
-        if (f >= NFP) break;
-        const int fa = fidx[it][0], fb = fidx[it][1], fc = fidx[it][2];
-        const float a[3] = {vn[3 * fa], vn[3 * fa + 1], vn[3 * fa + 2]};
-        const float bb[3] = {vn[3 * fb], vn[3 * fb + 1], vn[3 * fb + 2]};
-        const float c[3] = {vn[3 * fc], vn[3 * fc + 1], vn[3 * fc + 2]};
-        const float e1x = bb[0] - a[0], e1y = bb[1] - a[1], e1z = bb[2] - a[2];
-        const float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
-        // ---- record for the distance kernel: minimum enclosing circle (centre m on the triangle, conservative radius) + normal.
-        //      Used for conservative culling only -- the minimum itself is evaluated exactly from the corners
-        {
-            const float e3x = c[0] - bb[0], e3y = c[1] - bb[1], e3z = c[2] - bb[2];
-            const float la = e3x * e3x + e3y * e3y + e3z * e3z;        // squared edge opposite a
-            const float lb = e2x * e2x + e2y * e2y + e2z * e2z;        // ... opposite b
-            const float lc = e1x * e1x + e1y * e1y + e1z * e1z;        // ... opposite c
-            const float nx = __builtin_fmaf(e1y, e2z, -(e1z * e2y)), ny = __builtin_fmaf(e1z, e2x, -(e1x * e2z)),
-                        nz = __builtin_fmaf(e1x, e2y, -(e1y * e2x));
-            const float n2 = nx * nx + ny * ny + nz * nz;
-            // well-conditioned: sin^2 of the angle at a >= 1e-4 (the normal's direction is then good to ~1e-5 in fp32)
-            const bool well = f < NF && n2 >= 1e-4f * (lb * lc) && n2 > 1e-30f;
-            const float wa = la * (lb + lc - la), wb = lb * (la + lc - lb), wc = lc * (la + lb - lc);
-            float mx, my, mz;
-            if (!well) {                                   // centroid: on the triangle whatever its shape
-                mx = (a[0] + bb[0] + c[0]) * (1.0f / 3.0f); my = (a[1] + bb[1] + c[1]) * (1.0f / 3.0f); mz = (a[2] + bb[2] + c[2]) * (1.0f / 3.0f);
-            } else if (wa <= 0.f) {                        // angle at a >= 90 degrees: midpoint of the opposite edge
-                mx = 0.5f * (bb[0] + c[0]); my = 0.5f * (bb[1] + c[1]); mz = 0.5f * (bb[2] + c[2]);
-            } else if (wb <= 0.f) {
-                mx = 0.5f * (a[0] + c[0]); my = 0.5f * (a[1] + c[1]); mz = 0.5f * (a[2] + c[2]);
-            } else if (wc <= 0.f) {
-                mx = 0.5f * (a[0] + bb[0]); my = 0.5f * (a[1] + bb[1]); mz = 0.5f * (a[2] + bb[2]);
-            } else {                                       // acute: circumcentre as a CONVEX combination of the corners (weights in (0,1))
-                const float inv_w = 1.0f / (wa + wb + wc);
-                const float ua = wa * inv_w, ub_ = wb * inv_w, uc = wc * inv_w;
-                mx = ua * a[0] + ub_ * bb[0] + uc * c[0]; my = ua * a[1] + ub_ * bb[1] + uc * c[1]; mz = ua * a[2] + ub_ * bb[2] + uc * c[2];
-            }
-            float r2 = 0.f;
-            {
-                float dx = a[0] - mx, dy = a[1] - my, dz = a[2] - mz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
-                dx = bb[0] - mx; dy = bb[1] - my; dz = bb[2] - mz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
-                dx = c[0] - mx; dy = c[1] - my; dz = c[2] - mz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
-            }
-            unsigned nw = SDF_NRM_NOPLANE;
-            if (well) {
-                const float inv_n = 511.0f / sqrtf(n2);
-                const int qx = (int)rintf(nx * inv_n), qy = (int)rintf(ny * inv_n), qz = (int)rintf(nz * inv_n);
-                nw = ((unsigned)qx & 1023u) | (((unsigned)qy & 1023u) << 10) | (((unsigned)qz & 1023u) << 20);
-            }
-            // padding triangles (f >= NF): parked at 1e18 with radius 0, so the distance kernel culls them by arithmetic alone
-            const bool real = f < NF;
-            sph[f] = make_float4(real ? mx : 1e18f, real ? my : 1e18f, real ? mz : 1e18f, real ? sqrtf(r2) * 1.0001f + 1e-6f : 0.0f);
-            nrm[f] = real ? nw : SDF_NRM_NOPLANE;
-        }
-    }
     SDF_TK(pk_[4] = SDF_STAMP();)
     // ---- ray parity as DENSE (triangle, needed column) pairs.  A triangle-parallel loop over the needed columns of each triangle's
     //      yz box is bound by its slowest lane (stamps: 5 us on average, 16 us for the slowest hand of a launch -- a palm triangle
@@ -663,7 +617,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
             const int f = tid + it * PT;
             cnt[it] = 0; jmk[it] = 0u; kr[it] = 0;
             if (f >= NF) continue;
-            const int fa = fidx[it][0], fb = fidx[it][1], fc = fidx[it][2];
+            const int fa = (int)(fpkw[it] & 1023u), fb = (int)((fpkw[it] >> 10) & 1023u), fc = (int)(fpkw[it] >> 20);
             const float ay = vn[3 * fa + 1], az = vn[3 * fa + 2], by = vn[3 * fb + 1], bz = vn[3 * fb + 2], cy2 = vn[3 * fc + 1], cz2 = vn[3 * fc + 2];
             const float e1y = by - ay, e1z = bz - az, e2y = cy2 - ay, e2z = cz2 - az;
             const float det = __builtin_fmaf(e1z, e2y, -(e1y * e2z));
@@ -813,6 +767,66 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
             const unsigned ent = ((unsigned)H << 16) | (unsigned)(col * SDF_G + i);
             if ((lb2[rep] >> i) & 1u) run_a[oa++] = ent;
             else run_b[ob++] = ent | (((rb2[rep] >> i) & 1u) ? SDF_ENT_REFUSED : 0u);
+        }
+    }
+    // ---- lane = triangle: records for the distance kernel (minimum enclosing circle + normal), LAST: only the distance kernel reads them,
+    //      and only for a hand that has handed it an inside voxel -- 22 % of the hands of a refinement have none (round 5: the records are
+    //      28 % of the kernel's instructions).  A hand that will be static in the stage's later iterations keeps its first iteration's
+    //      records and computes them whatever it found.
+    const bool need_records = !stat && (blk_both != 0u || (lists_on && ((ws.static_stage >> hnd) & 1) != 0));
+#pragma unroll 1
+    for (int it = 0; it < (need_records ? TRI_IT : 0); ++it) {
+        const int f = tid + it * PT;
+        if (f >= NFP) break;
+        const int fa = (int)(fpkw[it] & 1023u), fb = (int)((fpkw[it] >> 10) & 1023u), fc = (int)(fpkw[it] >> 20);
+        const float a[3] = {vn[3 * fa], vn[3 * fa + 1], vn[3 * fa + 2]};
+        const float bb[3] = {vn[3 * fb], vn[3 * fb + 1], vn[3 * fb + 2]};
+        const float c[3] = {vn[3 * fc], vn[3 * fc + 1], vn[3 * fc + 2]};
+        const float e1x = bb[0] - a[0], e1y = bb[1] - a[1], e1z = bb[2] - a[2];
+        const float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
+        // ---- record for the distance kernel: minimum enclosing circle (centre m on the triangle, conservative radius) + normal.
+        //      Used for conservative culling only -- the minimum itself is evaluated exactly from the corners
+        {
+            const float e3x = c[0] - bb[0], e3y = c[1] - bb[1], e3z = c[2] - bb[2];
+            const float la = e3x * e3x + e3y * e3y + e3z * e3z;        // squared edge opposite a
+            const float lb = e2x * e2x + e2y * e2y + e2z * e2z;        // ... opposite b
+            const float lc = e1x * e1x + e1y * e1y + e1z * e1z;        // ... opposite c
+            const float nx = __builtin_fmaf(e1y, e2z, -(e1z * e2y)), ny = __builtin_fmaf(e1z, e2x, -(e1x * e2z)),
+                        nz = __builtin_fmaf(e1x, e2y, -(e1y * e2x));
+            const float n2 = nx * nx + ny * ny + nz * nz;
+            // well-conditioned: sin^2 of the angle at a >= 1e-4 (the normal's direction is then good to ~1e-5 in fp32)
+            const bool well = f < NF && n2 >= 1e-4f * (lb * lc) && n2 > 1e-30f;
+            const float wa = la * (lb + lc - la), wb = lb * (la + lc - lb), wc = lc * (la + lb - lc);
+            float mx, my, mz;
+            if (!well) {                                   // centroid: on the triangle whatever its shape
+                mx = (a[0] + bb[0] + c[0]) * (1.0f / 3.0f); my = (a[1] + bb[1] + c[1]) * (1.0f / 3.0f); mz = (a[2] + bb[2] + c[2]) * (1.0f / 3.0f);
+            } else if (wa <= 0.f) {                        // angle at a >= 90 degrees: midpoint of the opposite edge
+                mx = 0.5f * (bb[0] + c[0]); my = 0.5f * (bb[1] + c[1]); mz = 0.5f * (bb[2] + c[2]);
+            } else if (wb <= 0.f) {
+                mx = 0.5f * (a[0] + c[0]); my = 0.5f * (a[1] + c[1]); mz = 0.5f * (a[2] + c[2]);
+            } else if (wc <= 0.f) {
+                mx = 0.5f * (a[0] + bb[0]); my = 0.5f * (a[1] + bb[1]); mz = 0.5f * (a[2] + bb[2]);
+            } else {                                       // acute: circumcentre as a CONVEX combination of the corners (weights in (0,1))
+                const float inv_w = 1.0f / (wa + wb + wc);
+                const float ua = wa * inv_w, ub_ = wb * inv_w, uc = wc * inv_w;
+                mx = ua * a[0] + ub_ * bb[0] + uc * c[0]; my = ua * a[1] + ub_ * bb[1] + uc * c[1]; mz = ua * a[2] + ub_ * bb[2] + uc * c[2];
+            }
+            float r2 = 0.f;
+            {
+                float dx = a[0] - mx, dy = a[1] - my, dz = a[2] - mz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+                dx = bb[0] - mx; dy = bb[1] - my; dz = bb[2] - mz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+                dx = c[0] - mx; dy = c[1] - my; dz = c[2] - mz; r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+            }
+            unsigned nw = SDF_NRM_NOPLANE;
+            if (well) {
+                const float inv_n = 511.0f / sqrtf(n2);
+                const int qx = (int)rintf(nx * inv_n), qy = (int)rintf(ny * inv_n), qz = (int)rintf(nz * inv_n);
+                nw = ((unsigned)qx & 1023u) | (((unsigned)qy & 1023u) << 10) | (((unsigned)qz & 1023u) << 20);
+            }
+            // padding triangles (f >= NF): parked at 1e18 with radius 0, so the distance kernel culls them by arithmetic alone
+            const bool real = f < NF;
+            sph[f] = make_float4(real ? mx : 1e18f, real ? my : 1e18f, real ? mz : 1e18f, real ? sqrtf(r2) * 1.0001f + 1e-6f : 0.0f);
+            nrm[f] = real ? nw : SDF_NRM_NOPLANE;
         }
     }
     SDF_TK(if (tid == 0 && H < 4096) { pk_[6] = SDF_STAMP(); for (int k = 0; k < 6; ++k) g_sdf_prep[H][k] += pk_[k + 1] - pk_[k]; g_sdf_prep[H][6] += (long long)blk_inside; g_sdf_prep[H][7] += 1; })
@@ -1683,6 +1697,175 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
         if (hand_type) mask = (hand_type[b * 2] + hand_type[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
         loss[b] = tot / ws.loss_div * mask;  // parent project: sum / num_hands^2
     }
+}
+
+struct SdfNoHook { __device__ __forceinline__ void operator()() const {} };
+// The sampler of the fused tail (opt_tail_kernel): the same values as sdf_sample_block, bit for bit, from what the collision kernels
+// of the iteration have already worked out.
+//   * the prep kernel stored every query's grid cell (SdfWorkspace::qcell) while forming the needed-voxel mask: the 1556 normalisations
+//     (a third of the old sampler's instructions) are not redone;
+//   * the inside-voxel bitmaps of the sample's two hands (2 x 4 KB) are on their way into LDS by DMA, requested by the whole workgroup
+//     before this call: after the first batch of loads every wave waits for its own requests and a workgroup barrier publishes the
+//     pieces (EVERY wave of the workgroup has to arrive there: the caller's loss wave does, opt_loss_wave); after_mid() = the caller's
+//     further DMA requests, issued behind that barrier so that nobody waits for them here;
+//   * a query none of whose eight cell corners is an inside voxel -- 94 % of them -- has value 0 and gradient 0: the old code computed
+//     exactly +0 for it (0 * w sums), so it loads nothing more and skips the arithmetic; the others load their
+//     vertex, box and phi values in ONE round trip (the phi addresses follow from the cell word) and run sdf_sample_block's
+//     expressions.  A degenerate hand (box scale outside [1e-6, 1e6]: the oracle's infinities / NaNs) takes the full path for every entry.
+// Two dependent global round trips instead of three, and a fraction of the arithmetic.
+#ifdef TAIL_STAMPS
+__device__ long long g_samp_stamps[4096][8];
+#define SAMP_TK(k) do { samp_t_[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#define SAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define SAMP_TK(k)
+#define SAMP_DRAIN()
+#endif
+template <class AfterMid>
+__device__ __forceinline__ void sdf_sample_fused(const VertLayout& vl, const SdfWorkspace& ws, float* __restrict__ loss, int B, float gs,
+                                                 const float* __restrict__ hand_type, float* red16, int b, int nworkers,
+                                                 float* g_lds_r, float* g_lds_l, const unsigned* bits_lds, AfterMid after_mid) {
+    const int tid = threadIdx.x;
+    float acc = 0.f;
+#ifdef TAIL_STAMPS
+    long long samp_t_[8];
+    SAMP_TK(0);
+#endif
+    // ---- the cell words of this thread's entries tid, tid + nworkers, ... and both boxes
+    unsigned cw[SDF_SAMPLE_NIT];
+    bool on[SDF_SAMPLE_NIT];
+    int hn[SDF_SAMPLE_NIT], vx[SDF_SAMPLE_NIT];
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        const int e = tid + it * nworkers;
+        on[it] = e < 2 * NV;
+        const int ee = on[it] ? e : 0;
+        hn[it] = ee / NV; vx[it] = ee % NV;
+        cw[it] = ws.qcell[(size_t)b * 2 * NV + ee];
+    }
+    const float4 box0 = *reinterpret_cast<const float4*>(ws.box + (size_t)b * 4), box1 = *reinterpret_cast<const float4*>(ws.box + ((size_t)B + b) * 4);
+    __builtin_amdgcn_sched_barrier(0);
+    SAMP_TK(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    after_mid();
+    SAMP_TK(2);
+    // ---- which of a cell's eight corners hold a distance (bitmap words from LDS)
+    const bool fast0 = box0.w >= 1e-6f && box0.w <= 1e6f, fast1 = box1.w >= 1e-6f && box1.w <= 1e6f;
+    unsigned m8[SDF_SAMPLE_NIT];
+    bool nz[SDF_SAMPLE_NIT];
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        const unsigned c = cw[it];
+        const int i0 = (int)(c & 63u) - 1, j0 = (int)((c >> 6) & 63u) - 1, k0 = (int)((c >> 12) & 63u) - 1;
+        unsigned m = 0u;
+        if (on[it] && (c & SDF_QCELL_IN)) {
+            const unsigned* ib = bits_lds + hn[it] * SDF_NCOL;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int j = j0 + (c4 & 1), k = k0 + (c4 >> 1);
+                if (j >= 0 && j < SDF_G && k >= 0 && k < SDF_G) {
+                    const unsigned wbits = ib[k * SDF_G + j];
+                    const unsigned b0 = i0 >= 0 ? ((wbits >> (i0 & 31)) & 1u) : 0u, b1 = i0 + 1 < SDF_G ? ((wbits >> ((i0 + 1) & 31)) & 1u) : 0u;
+                    m |= (b0 << (2 * c4)) | (b1 << (2 * c4 + 1));
+                }
+            }
+        }
+        m8[it] = m;
+        nz[it] = on[it] && (m != 0u || !(hn[it] ? fast1 : fast0));
+    }
+    SAMP_TK(3);
+    // ---- the entries that touch an inside voxel: vertex + phi values, one round trip
+    float qv[SDF_SAMPLE_NIT][3], pv[SDF_SAMPLE_NIT][8];
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        qv[it][0] = qv[it][1] = qv[it][2] = 0.f;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) pv[it][c8] = 0.f;
+        if (nz[it]) {
+            const float* q = vl.hand(b, 1 - hn[it]) + 3 * vx[it];
+            qv[it][0] = q[0]; qv[it][1] = q[1]; qv[it][2] = q[2];
+            const unsigned c = cw[it];
+            const int i0 = (int)(c & 63u) - 1, j0 = (int)((c >> 6) & 63u) - 1, k0 = (int)((c >> 12) & 63u) - 1;
+            const float* phi = ws.phi + (size_t)(hn[it] * B + b) * SDF_NVOX;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int j = j0 + (c4 & 1), k = k0 + (c4 >> 1);
+                const bool b0 = (m8[it] >> (2 * c4)) & 1u, b1 = (m8[it] >> (2 * c4 + 1)) & 1u;
+                const float* row = phi + (k * SDF_G + j) * SDF_G;
+                if (b0 && b1) {
+                    typedef float sdf_f2u __attribute__((ext_vector_type(2), aligned(4)));
+                    const sdf_f2u two = *reinterpret_cast<const sdf_f2u*>(row + i0);
+                    pv[it][2 * c4] = two.x; pv[it][2 * c4 + 1] = two.y;
+                } else if (b0) {
+                    pv[it][2 * c4] = row[i0];
+                } else if (b1) {
+                    pv[it][2 * c4 + 1] = row[i0 + 1];
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SAMP_DRAIN();
+    SAMP_TK(4);
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        if (!on[it]) continue;
+        const int hnd = hn[it], v = vx[it];
+        float val = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+        if (nz[it]) {           // sdf_sample_block's expressions, operation for operation
+            const float4 bx = hnd ? box1 : box0;
+            const float cx = bx.x, cy = bx.y, cz = bx.z, sc = bx.w;
+            const SdfDivisor dsc = sdf_divisor(sc);
+            const float nx0 = sdf_div(qv[it][0] - cx, dsc), nz0 = sdf_div(qv[it][2] - cz, dsc);
+            const float ix = sdf_unnorm(ws.swap_xz ? nz0 : nx0, ws.align_corners), iy = sdf_unnorm(sdf_div(qv[it][1] - cy, dsc), ws.align_corners),
+                        iz = sdf_unnorm(ws.swap_xz ? nx0 : nz0, ws.align_corners);
+            const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+            const bool inr = x0 >= -1.0f && x0 <= (float)(SDF_G - 1) && y0 >= -1.0f && y0 <= (float)(SDF_G - 1) && z0 >= -1.0f && z0 <= (float)(SDF_G - 1);
+            if (inr) {
+                const int i0 = (int)x0, j0 = (int)y0, k0 = (int)z0;
+                const float fx = ix - x0, fy = iy - y0, fz = iz - z0;
+                const float wx1 = fx, wx0 = (x0 + 1.0f) - ix, wy1 = fy, wy0 = (y0 + 1.0f) - iy, wz1 = fz, wz0 = (z0 + 1.0f) - iz;
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const int di = c8 & 1, dj = (c8 >> 1) & 1, dk = c8 >> 2;
+                    const int i = i0 + di, j = j0 + dj, k = k0 + dk;
+                    if (i >= 0 && i < SDF_G && j >= 0 && j < SDF_G && k >= 0 && k < SDF_G) {
+                        const float p = pv[it][c8];
+                        const float wx = di ? wx1 : wx0, wy = dj ? wy1 : wy0, wz = dk ? wz1 : wz0;
+                        val += p * (wx * wy * wz);
+                        gx += (di ? p : -p) * (wy * wz);
+                        gy += (dj ? p : -p) * (wx * wz);
+                        gz += (dk ? p : -p) * (wx * wy);
+                    }
+                }
+            }
+            const float chain = (0.5f * (float)(ws.align_corners ? SDF_G - 1 : SDF_G)) / sc;
+            gx *= chain; gy *= chain; gz *= chain;
+            if (ws.swap_xz) { const float t = gx; gx = gz; gz = t; }
+        }
+        // (an entry that takes no part: val = +0 and gradient = +0, what the arithmetic above gives for eight zero corners and a finite chain)
+        float* g = (hnd ? g_lds_r : g_lds_l) + 3 * v;       // raw hand frame: the left hand's x negated, as lbs_bwd1_hand's staging does
+        const float g0 = gs * gx;
+        g[0] = hnd ? g0 : -g0; g[1] = gs * gy; g[2] = gs * gz;
+        acc += val;
+    }
+    SAMP_TK(5);
+    // fixed-order block sum: DPP inside each wave, the wave totals through LDS
+    const float wsum = wave_reduce_sum_dpp(acc);
+    if (tid % WAVE == 0) red16[tid / WAVE] = wsum;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int wv = 0; wv < SDF_SAMPLE_THREADS / WAVE; ++wv) tot += red16[wv];
+        float mask = 1.0f;
+        if (hand_type) mask = (hand_type[b * 2] + hand_type[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
+        loss[b] = tot / ws.loss_div * mask;  // parent project: sum / num_hands^2
+    }
+#ifdef TAIL_STAMPS
+    SAMP_TK(6);
+    if (tid == 0 && b < 4096) { for (int k = 0; k < 6; ++k) g_samp_stamps[b][k] += samp_t_[k + 1] - samp_t_[k]; g_samp_stamps[b][7] += 1; }
+#endif
 }
 
 // seam B: grid = B, block = SDF_SAMPLE_THREADS (512)

@@ -33,9 +33,15 @@ for sid, stage in enumerate(m.strategy):
         m.run_stage(s)
     L.ihmr_debug_tail_stamps(None, 1)
     m.run_stage(stage)
-    raw = np.zeros(3 * 4096 * 8, np.int64)
+    raw = np.zeros(4 * 4096 * 8, np.int64)
     L.ihmr_debug_tail_stamps(raw.ctypes.data, 0)
-    raw = raw.reshape(3, 4096, 8)
+    samp = raw[3 * 4096 * 8:].reshape(4096, 8)
+    raw = raw[:3 * 4096 * 8].reshape(3, 4096, 8)
+    sm = samp[samp[:, 7] > 0]
+    if len(sm):
+        u = sm[:, :6] / sm[:, 7:8] / 2403.0
+        print(f"stage {sid} sampler (thread 0, all tail launches): " + "; ".join(f"{n} {u[:, k].mean():.2f}" for k, n in enumerate(
+            ["issue first loads", "they land (+ bitmap barrier)", "bitmap words", "phi lands", "values + gradients", "block sum"])))
     for form, label in enumerate(("<false,false>", "<true,false>", "<true,true>")):
         r = raw[form][raw[form][:, 7] > 0]
         if not len(r):
