@@ -30,11 +30,69 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 vector == FP32 (f32-input)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 
 
-def make_opt(B, epoch, freq, rank):
+def make_opt(B, epoch, freq, rank, asset="mitten"):
+    """`asset`: "mitten" = the default synthetic MANO-shaped model (every test, every headline number); "fingers" = the same model on
+    a mesh with a palm and five finger tubes (ihmr_amd/assets.py: the geometry-sensitivity asset)."""
     return types.SimpleNamespace(isTrain=False, dist=False, process_rank=rank, batchSize=B, inputSize=224, num_joints=42,
                                  total_params_dim=122, cam_params_dim=3, pose_params_dim=96, shape_params_dim=20,
-                                 trans_params_dim=3, model_root="", strategy="opt_default", save_mid_freq=freq,
-                                 optimizer="adam", opt_epoch=epoch)
+                                 trans_params_dim=3, model_root="" if asset == "mitten" else f"synthetic:{asset}", strategy="opt_default",
+                                 save_mid_freq=freq, optimizer="adam", opt_epoch=epoch)
+
+
+def geometry_report(asset, B, epoch, freq, steps=12, fuse=6):
+    """Throughput and collision-work statistics of the refinement on one synthetic asset, measured the same way for every asset
+    (two launch sequences of `fuse` batches on two streams, `steps` batches in all; NOT the headline's schedule): images/s, inside
+    voxels per sample and iteration, share of inside voxels searched in full, voxels refused a candidate list (list overflow: more
+    than 192 triangles within the list bound) per sample and iteration.  "fingers" uses the interlocked batch generator."""
+    from ihmr_amd import two_hand
+    from ihmr_amd.optimize_model import OptimizeModel
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    inter = asset != "mitten"
+    def model(g):
+        o = make_opt(B, epoch, freq, -1, asset)
+        o.fuse_batches = g
+        return OptimizeModel(o)
+    one = model(1)
+    fwd = lambda p, s_, t: two_hand.forward_from_packed(one.mano_models["right"], p.cuda(), s_.cuda(), t.cuda())[2]
+    bs = [synthetic_opt_batch(B, fwd, seed=1234 + 1000 * i, interlock=inter) for i in range(fuse)]
+    inp = {k: torch.cat([b[k] for b in bs]).cuda() for k in bs[0]}
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    mdls = [model(fuse) for _ in streams]
+    def pass_():
+        hs = []
+        for m, st in zip(mdls, streams):
+            with torch.cuda.stream(st):
+                m.set_input(inp); m.init_optimize()
+        for stage in one.strategy:
+            for m, st in zip(mdls, streams):
+                with torch.cuda.stream(st):
+                    m.run_stage(stage)
+        for m, st in zip(mdls, streams):
+            with torch.cuda.stream(st):
+                m.forward_losses(m.default_loss_weights); hs.append(m.get_pred_result_async())
+        return [h.wait() for h in hs]
+    pass_(); pass_()
+    torch.cuda.synchronize()
+    reps = max(1, steps // (2 * fuse))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = pass_()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # work counters: one batch, untimed
+    one.set_input({k: v[:B] for k, v in inp.items()}); one.init_optimize()
+    one.sdf_counters_start()
+    for stage in one.strategy:
+        one.run_stage(stage)
+    c = one.sdf_counters_stop()
+    n_it = 4 * (epoch + 1)
+    per = lambda k: c[k] / (B * n_it)
+    return dict(asset=asset, batch_generator="interlocked" if inter else "default", images_per_s=2 * fuse * reps * B / dt,
+                inside_voxels_per_sample_iteration=per("inside_voxels"), full_search_share=c["voxels_full_search"] / max(c["inside_voxels"], 1),
+                refused_lists_per_sample_iteration=per("lists_refused"), refused_share_of_full_searches=c["lists_refused"] / max(c["voxels_full_search"], 1),
+                rebuilt_share=c["voxels_rebuilt"] / max(c["inside_voxels"], 1),
+                mean_penetration_depth_m=float(np.mean(res[0]["collision_loss_origin_scale"])),
+                schedule=f"2 streams x {fuse} batches of {B}, {reps} pass(es)")
 
 
 def cpu_model_string():
@@ -594,6 +652,9 @@ def main():
     ap.add_argument("--rccl-selftest", action="store_true",
                     help="under torch.distributed.run: run the package's collectives (metric all-reduce, MAX, all-gather, bucketed gradient "
                          "all-reduce) on device tensors through the process group's backend and report the checks in the line")
+    ap.add_argument("--asset", type=str, default="mitten", choices=["mitten", "fingers"],
+                    help="synthetic MANO-shaped model of the run: the default blob, or the five-finger mesh with interlocked batches "
+                         "(geometry sensitivity; the default run reports both under `geometry`)")
     ap.add_argument("--config", type=str, default="opt", choices=["opt", "baseline", "mlp"],
                     help="opt = the driver's bench line (IHMR-OPT); baseline / mlp = one of the secondary BASELINE.json configs alone")
     args = ap.parse_args()
@@ -619,6 +680,11 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     assert torch.cuda.is_available(), "bench.py needs an MI355X: the hot path has no CPU fallback"
+    # one process per GPU on one node: keep each rank's launch thread on the cores next to its GPU (IHMR_PIN_NUMA=0 switches it off)
+    numa_pin = None
+    if world > 1 and os.environ.get("IHMR_PIN_NUMA", "1") != "0":
+        from ihmr_amd import dist as _D
+        numa_pin = _D.pin_to_gpu_numa_node(torch.cuda.current_device())
 
     import ctypes as C
     from ihmr_amd import hip, two_hand
@@ -636,7 +702,7 @@ def main():
     # (hardware-queue counts etc.) involved.
     # --batch 512 --streams 1 --fuse 1 is the reference's recipe verbatim: ONE sequence over a real batch of 512.
     def make_model(fuse, batch=B):
-        o = make_opt(batch, args.epoch, freq, rank if world > 1 else -1)
+        o = make_opt(batch, args.epoch, freq, rank if world > 1 else -1, args.asset)
         o.fuse_batches = fuse
         return OptimizeModel(o)
 
@@ -645,7 +711,8 @@ def main():
     pool = {(0, 1): model}                       # (stream, batches per launch sequence) -> instance, built on demand
     fwd = lambda p, s, t: two_hand.forward_from_packed(model.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
     # G DISTINCT synthetic batches (seed 1234 + 1000 i + rank): a launch sequence that carries g batches carries batches 0..g-1
-    batches_cpu = [synthetic_opt_batch(B, fwd, seed=1234 + 1000 * i + rank, first_index=(rank * G + i) * B) for i in range(G)]
+    batches_cpu = [synthetic_opt_batch(B, fwd, seed=1234 + 1000 * i + rank, first_index=(rank * G + i) * B, interlock=args.asset != "mitten")
+                   for i in range(G)]
     batch_cpu = batches_cpu[0]
     inputs, inputs_host = {}, {}
     for g in range(1, G + 1):
@@ -654,6 +721,8 @@ def main():
         inputs[g] = {k: v.cuda() for k, v in cat.items()}      # resident in HBM before timing
     batch = inputs[1]
     torch.cuda.synchronize()
+
+    host_submit = [0.0]                          # seconds of host submission work per step of the last run_steps()
 
     def plan(n):
         """n batches -> per stream a list of job sizes (batches fused into one launch sequence, <= G): the streams get
@@ -682,6 +751,8 @@ def main():
         res = None
         sizes = plan(n)
         pending = []                               # export handles of the previous round
+        t_wait = 0.0                               # host time spent WAITING for the GPU (export handles): everything else is submission
+        t_begin = time.perf_counter()
         for r in range(max((len(q) for q in sizes), default=0) + 1):
             jobs = [(instance(i, q[r]), streams[i], src[q[r]]) for i, q in enumerate(sizes) if r < len(q)]
             for mdl, st, inp in jobs:
@@ -699,9 +770,14 @@ def main():
                     # device -> host export of every batch, as the reference's loop does; queued behind the refinement
                     # on its stream and collected one round later, so the host never leaves the GPU without work
                     handles.append(mdl.get_pred_result_async())
+            tw = time.perf_counter()
             for h in pending:
                 res = h.wait()
+            t_wait += time.perf_counter() - tw
             pending = handles
+        # host-side submission cost of the run: wall time of this thread minus the time it sat in the export waits (graph launches,
+        # input staging, export requests; a queue that is full blocks inside a launch and counts -- the upper bound is the honest one)
+        host_submit[0] = (time.perf_counter() - t_begin - t_wait) / max(n, 1)
         return res
 
     extras = rank == 0 and world == 1 and not args.no_extras
@@ -736,6 +812,16 @@ def main():
         return dt, r
 
     run_steps(max(args.warmup, 0))
+    # ---- host submission cost (what decides whether N ranks x S streams scale on one node's CPUs): the SAME K steps with the GPU
+    #      synchronised out of the picture as far as the loop allows -- the thread's wall time minus its waits for export handles.
+    #      Measured on a pass of its own so that the timed region below stays exactly the contract's
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    submit_ms = 1000.0 * host_submit[0]
+    if dist is not None:
+        t = torch.tensor([submit_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        submit_ms = float(t.item())
     # (experiment builds only, -DIHMR_TIMELINE + IHMR_TIMELINE_OUT=<file.npy>: workgroup records of the timed region, scripts/timeline_wg.py)
     tl_out = os.environ.get("IHMR_TIMELINE_OUT") if hasattr(hip.lib(), "ihmr_debug_timeline") else None
     if tl_out:
@@ -854,8 +940,14 @@ def main():
         del big2
         del big, big_in
 
+    # ---- geometry sensitivity: the same refinement on the blob and on the five-finger mesh with interlocked hands, one schedule for both
+    geometry = None
+    if extras and B == 64:
+        geometry = [geometry_report(a, B, args.epoch, freq) for a in ("mitten", "fingers")]
+        geometry.append(dict(throughput_ratio_fingers_over_mitten=geometry[1]["images_per_s"] / geometry[0]["images_per_s"]))
+
     cpu, parity = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.asset == "mitten":
         cpu, oracle_out = cpu_baseline(batch_cpu, args.epoch, freq)
         parity = parity_vs_oracle(batch_cpu, oracle_out, -1)
     second = None
@@ -894,13 +986,19 @@ def main():
             # throughput figure: whole-run time / (steps x iterations) with streams x fuse batches in flight -- NOT the duration of
             # one refinement iteration (that is latency.ms_per_refine_iter)
             ms_per_refine_iter_amortised=amortised, higher_is_better=True, scaling="weak", vs_baseline=None,
+            # multi-GPU readiness measurable on one GPU: the launch thread's work per step (max over ranks).  A rank keeps its GPU fed
+            # as long as this stays below the GPU time of a step (ms_per_step of a one-GPU run: on 8 GPUs every rank has its own)
+            host_submit_ms_per_step=submit_ms, host_submit_fraction_of_step=submit_ms / ms_per_step if world == 1 else None,
+            host_cpu_affinity=numa_pin,
             dtype="f32", data="synthetic",
             config=dict(workload=f"IHMR-OPT opt_default epoch={args.epoch} ({n_iters} refine iterations + final forward), "
-                                 f"save_mid_freq={freq}, batch {B}/GPU, synthetic MANO-shaped asset seed 0",
+                                 f"save_mid_freq={freq}, batch {B}/GPU, synthetic MANO-shaped asset seed 0"
+                                 + ("" if args.asset == "mitten" else f" [{args.asset} mesh, interlocked batches: NOT the headline workload]"),
                         global_batch=world * B, refine_iters=n_iters, batches_in_flight_per_gpu=S * G, launch_streams=S,
                         max_batches_per_launch_sequence=G, distinct_batches=G,
                         parallelism=f"dp{world} (independent samples, no collective)"),
             roofline=roofline, cpu_baseline=cpu, latency=latency, h2d_inclusive=h2d, large_batch=large, secondary_configs=second,
+            geometry=geometry,
             # LBS + losses + Adam are nominally HBM work -- 78 KB of algorithmic traffic per sample and
             # iteration -- and in practice bound by the dependent kernel boundaries of an iteration (3 / 3 / 4 / 7 launches by stage)
             lbs_losses_adam=dict(bound="hbm", algorithmic_bytes_per_sample_iteration=78e3, kernel_launches_per_iteration=4.25,
@@ -915,6 +1013,9 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out))
     if dist is not None:
+        # rank 0's single-stream roofline passes run while the other ranks wait HERE (a barrier they expect), not inside
+        # destroy_process_group's teardown with its shorter patience
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -79,6 +79,127 @@ def _mitten_mesh(rng: np.random.RandomState):
     return verts, faces
 
 
+# ----------------------------------------------------------------------------- second synthetic asset: a hand WITH fingers
+# The mitten above is a blob: a penetrating hand meets one convex-ish volume (~118 inside voxels per sample of the benchmark batch).
+# Real MANO hands have five fingers that interlock, i.e. many thin penetration volumes, long candidate lists between neighbouring
+# fingers, more voxels that are refused a list.  `synthetic_mano(kind="fingers")` is the same MANO-shaped model (778 vertices, 1538
+# faces, one open 16-edge wrist loop, same tree / weights / blend-shape construction) on a mesh with a palm and five finger tubes, so
+# that throughput and list statistics can be quoted for that geometry too (bench.py --asset fingers).
+# finger slots along the knuckle line from +y to -y: thumb, index, middle, ring, pinky; MANO chain of each slot (joint order
+# index, middle, pinky, ring, thumb: loss_utils.py:139-145)
+_FINGER_SLOT_CHAIN = [4, 0, 1, 3, 2]
+_FINGER_BASE = np.array([[0.058, 0.043, 0.0], [0.096, 0.027, 0.0], [0.100, 0.009, 0.0], [0.096, -0.009, 0.0], [0.088, -0.027, 0.0]])
+_FINGER_DIR = np.array([[0.62, 0.78, 0.05], [1.0, 0.10, 0.0], [1.0, 0.02, 0.0], [1.0, -0.07, 0.0], [1.0, -0.16, 0.0]])
+_FINGER_LEN = np.array([0.058, 0.074, 0.080, 0.074, 0.060])
+_FINGER_RAD = np.array([0.0095, 0.0080, 0.0082, 0.0078, 0.0070])
+_FINGER_RINGS = [8, 10, 10, 9, 8]            # rings beyond the base loop (+ a pole each)
+_PALM_RINGS = [16, 17, 19, 21, 24, 28, 32, 36, 40, 44]   # wrist (the open boundary) ... last ring before the knuckle loop
+
+
+def _loop_strip(A, B):
+    """Triangles between two closed vertex loops of the same circulation (lengths may differ): len(A) + len(B) faces."""
+    na, nb = len(A), len(B)
+    faces, i, j = [], 0, 0
+    while i < na or j < nb:
+        if j >= nb or (i < na and (i + 1) * nb <= (j + 1) * na):
+            faces.append([A[i % na], A[(i + 1) % na], B[j % nb]]); i += 1
+        else:
+            faces.append([A[i % na], B[(j + 1) % nb], B[j % nb]]); j += 1
+    return faces
+
+
+def _fingers_mesh(rng: np.random.RandomState):
+    """Palm tube (wrist ring of 16 -> rings growing to 44) -> knuckle loop whose five lobes are the base loops of five finger tubes
+    (neighbouring lobes meet in ONE web vertex) -> finger rings -> poles.  A triangulated disk with one boundary loop of 16 edges:
+    F = 2 V - 2 - 16 whatever the ring sizes, which are chosen so that V = 778."""
+    verts, faces = [], []
+    add = lambda p: (verts.append(np.asarray(p, np.float64)), len(verts) - 1)[1]
+    ang = lambda n, k: 2 * np.pi * k / n
+    # palm rings (planar ellipses, circulation +y -> +z -> -y -> -z)
+    x_k = 0.088
+    rings = []
+    for r, n in enumerate(_PALM_RINGS):
+        u = r / len(_PALM_RINGS)
+        x = x_k * u
+        wy = 0.027 + 0.020 * np.sin(u * np.pi / 2) ** 0.8
+        wz = 0.0125 + 0.0035 * np.sin(np.pi * u)
+        yc = 0.004 * u          # the thumb side bulges
+        rings.append([add([x, yc + wy * np.cos(ang(n, k)), wz * np.sin(ang(n, k))]) for k in range(n)])
+    # fingers: orthonormal frame per finger (d = axis, e1 ~ +y side, e2 ~ +z dorsal)
+    a = 4                        # vertices per half loop: a finger loop has 2 a + 2 = 10
+    frames = []
+    for i in range(5):
+        d = _FINGER_DIR[i] / np.linalg.norm(_FINGER_DIR[i])
+        e2 = np.array([0.0, 0.0, 1.0]); e2 = e2 - (e2 @ d) * d; e2 /= np.linalg.norm(e2)
+        e1 = np.cross(e2, d)      # points to +y for d = +x
+        frames.append((d, e1, e2))
+    # web vertices: outer side of the thumb, between neighbours, outer side of the pinky (on the finger bases' mid-plane)
+    web = []
+    for i in range(6):
+        if i == 0:
+            p = _FINGER_BASE[0] + frames[0][1] * _FINGER_RAD[0]
+        elif i == 5:
+            p = _FINGER_BASE[4] - frames[4][1] * _FINGER_RAD[4]
+        else:
+            p = 0.5 * ((_FINGER_BASE[i - 1] - frames[i - 1][1] * _FINGER_RAD[i - 1]) + (_FINGER_BASE[i] + frames[i][1] * _FINGER_RAD[i]))
+            p = p - np.array([0.004, 0.0, 0.0])     # the web sits a little proximal of the knuckles
+        web.append(add(p))
+    dors, palm_arcs = [], []
+    for i in range(5):
+        d, e1, e2 = frames[i]
+        th = [np.pi * (q + 1) / (a + 1) for q in range(a)]           # from the +y side over the top to the -y side
+        dors.append([add(_FINGER_BASE[i] + _FINGER_RAD[i] * (np.cos(t) * e1 + np.sin(t) * e2)) for t in th])
+        # palmar arc in the knuckle loop's direction: from the -y side under the finger back to the +y side
+        palm_arcs.append([add(_FINGER_BASE[i] + _FINGER_RAD[i] * (np.cos(np.pi + t) * e1 + np.sin(np.pi + t) * e2)) for t in th])
+    K = []
+    for i in range(5):
+        K += [web[i]] + dors[i]
+    K += [web[5]]
+    for i in range(4, -1, -1):
+        K += palm_arcs[i] + ([web[i]] if i > 0 else [])
+    # palm strips
+    for r in range(len(rings) - 1):
+        faces += _loop_strip(rings[r], rings[r + 1])
+    faces += _loop_strip(rings[-1], K)
+    # finger tubes
+    for i in range(5):
+        d, e1, e2 = frames[i]
+        n = 2 * a + 2
+        prev = [web[i]] + dors[i] + [web[i + 1]] + palm_arcs[i]
+        for q in range(_FINGER_RINGS[i]):
+            t = (q + 1) / (_FINGER_RINGS[i] + 0.6)
+            rad = _FINGER_RAD[i] * (1.0 - 0.30 * t ** 2)
+            c = _FINGER_BASE[i] + d * (_FINGER_LEN[i] * t)
+            cur = [add(c + rad * (np.cos(ang(n, k)) * e1 + np.sin(ang(n, k)) * e2)) for k in range(n)]
+            faces += _loop_strip(prev, cur)
+            prev = cur
+        pole = add(_FINGER_BASE[i] + d * _FINGER_LEN[i])
+        for k in range(n):
+            faces.append([prev[k], prev[(k + 1) % n], pole])
+    verts = np.array(verts)
+    faces = np.array(faces, dtype=np.int64)
+    assert verts.shape == (NUM_VERTS, 3) and faces.shape == (NUM_FACES, 3), (verts.shape, faces.shape)
+    # orientation: outward (positive signed volume of the surface closed by the wrist disk is enough to tell)
+    vol = np.einsum("ij,ij->i", verts[faces[:, 0]], np.cross(verts[faces[:, 1]], verts[faces[:, 2]])).sum()
+    if vol < 0:
+        faces = faces[:, ::-1].copy()
+    verts = verts + 0.0003 * rng.standard_normal(verts.shape)
+    return verts, faces
+
+
+def _joint_layout_fingers():
+    """16 rest joints inside the palm / finger tubes of `_fingers_mesh` + the five tips in the reference's order."""
+    J = np.zeros((16, 3))
+    J[0] = [0.012, 0.0, 0.0]
+    tips = np.zeros((5, 3))
+    for slot, chain in enumerate(_FINGER_SLOT_CHAIN):
+        d = _FINGER_DIR[slot] / np.linalg.norm(_FINGER_DIR[slot])
+        for k, frac in enumerate((0.02, 0.40, 0.70)):
+            J[1 + 3 * chain + k] = _FINGER_BASE[slot] + d * (_FINGER_LEN[slot] * frac)
+        tips[chain] = _FINGER_BASE[slot] + d * _FINGER_LEN[slot]
+    return J, tips[[4, 0, 1, 3, 2]]          # reference tip order (optimize_model.py:99): thumb, index, middle, ring, pinky
+
+
 def _joint_layout():
     """16 rest joints (metres) inside the mitten: wrist + 5 chains of 3 (MANO order:
     index, middle, pinky, ring, thumb -- see the finger table at reference loss_utils.py:139-145)."""
@@ -97,13 +218,20 @@ def _joint_layout():
     return J, tips_ref_order
 
 
-def synthetic_mano(is_rhand: bool = True, seed: int = 0) -> Dict[str, np.ndarray]:
+def synthetic_mano(is_rhand: bool = True, seed: int = 0, kind: str = "mitten") -> Dict[str, np.ndarray]:
     """Deterministic MANO-shaped arrays. The left model is the x-mirror of the right one (same
     ``shapedirs`` x-sign as the right, so that the reference's sign fix at
-    ``optimize_model.py:109-113`` triggers exactly as it does for the real files)."""
+    ``optimize_model.py:109-113`` triggers exactly as it does for the real files).
+    ``kind``: "mitten" (the default asset of every test and benchmark: a pole-and-rings blob) or "fingers" (palm + five finger tubes:
+    the geometry-sensitivity asset, same sizes and construction of everything but the mesh)."""
     rng = np.random.RandomState(seed)
-    verts, faces = _mitten_mesh(rng)
-    J, tips = _joint_layout()
+    if kind == "fingers":
+        verts, faces = _fingers_mesh(rng)
+        J, tips = _joint_layout_fingers()
+    else:
+        assert kind == "mitten", kind
+        verts, faces = _mitten_mesh(rng)
+        J, tips = _joint_layout()
 
     # put the reference's hard-coded tip vertex ids at the ends of the finger chains
     perm = np.arange(NUM_VERTS)
@@ -267,7 +395,9 @@ def load_mano_pkl(path: str) -> Dict[str, np.ndarray]:
 
 
 def get_mano_arrays(model_path: str | None, is_rhand: bool, seed: int = 0) -> Dict[str, np.ndarray]:
-    """Real file if it exists, else the synthetic asset (the only case exercised in this build)."""
+    """Real file if it exists, else the synthetic asset (the only case exercised in this build).  A model root of
+    ``synthetic:fingers`` (``opt.model_root``; the path then reads ``synthetic:fingers/MANO_RIGHT.pkl``) selects the finger asset."""
     if model_path and osp.isfile(model_path):
         return load_mano_pkl(model_path)
-    return synthetic_mano(is_rhand=is_rhand, seed=seed)
+    kind = "fingers" if model_path and "synthetic:fingers" in model_path else "mitten"
+    return synthetic_mano(is_rhand=is_rhand, seed=seed, kind=kind)

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "ihmr_common.h"
@@ -18,9 +19,14 @@
 #include "evaluate.h"
 #include "train.h"
 #include "train_conv.h"
+#include "copy_pack.h"
 
+// bench.py's per-kernel timer -- the library's ONE piece of process-global state (include/ihmr_hip.h says so): the pointer and the
+// list of pending event pairs are shared by every stream and thread of the process, guarded by g_timer_mutex; while no timer is set
+// (the default) nothing here is touched.  (a,b) brackets one in-loop launch of kernel slot `k` (k < 0: an EMPTY pair, the cost of
+// two event records)
 static ihmr_kernel_timer* g_timer = nullptr;
-// bench.py's per-kernel timer: (a,b) brackets one in-loop launch of kernel slot `k` (k < 0: an EMPTY pair, the cost of two event records)
+static std::mutex g_timer_mutex;
 struct TimedPair { hipEvent_t a, b; int k; };
 static std::vector<TimedPair> g_pending;
 static int timed_mark(hipEvent_t* ev, hipStream_t st) {
@@ -33,13 +39,13 @@ static int timed_begin(hipEvent_t* cur, hipStream_t st) {
     hipEvent_t e0, e1;
     if (int rc = timed_mark(&e0, st)) return rc;
     if (int rc = timed_mark(&e1, st)) return rc;
-    g_pending.push_back(TimedPair{e0, e1, -1});
+    { std::lock_guard<std::mutex> lk(g_timer_mutex); g_pending.push_back(TimedPair{e0, e1, -1}); }
     return timed_mark(cur, st);
 }
 static int timed_next(hipEvent_t* cur, int k, hipStream_t st) {
     hipEvent_t e;
     if (int rc = timed_mark(&e, st)) return rc;
-    g_pending.push_back(TimedPair{*cur, e, k});
+    { std::lock_guard<std::mutex> lk(g_timer_mutex); g_pending.push_back(TimedPair{*cur, e, k}); }
     return timed_mark(cur, st);      // (a fresh start mark: every event belongs to exactly one pair)
 }
 
@@ -299,6 +305,8 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
                       const uint32_t* fpk_l, int B, SdfWorkspace ws, float robustifier, float* loss, float* per_vert, float* origin, float* dval, bool dense, hipStream_t st) {
     // the inside-voxel counter is zero on entry (faces_to_soa_kernel on seam B, the skeleton kernel of the iteration
     // on seam C); the prep kernel appends to it
+    // an inside-list entry is (hand << 16) | voxel with bit 31 reserved (SDF_ENT_REFUSED): hand ids stay below 32768
+    if (B <= 0 || 2 * B > SDF_MAX_HANDS) return -1;
     // small launches: the 1024-thread form (half the chain per thread), see sdf_collision.h
     const bool small = 2 * B <= SDF_PREP_SMALL_MAX_HANDS;
     ws.fpk[0] = fpk_r; ws.fpk[1] = fpk_l; ws.B = B;
@@ -353,7 +361,7 @@ __global__ void faces_to_soa_kernel(const int32_t* __restrict__ aos, int32_t* __
 extern "C" int ihmr_sdf_collision_ex(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
                                      float robustifier, const ihmr_sdf_options* options, float* loss, float* per_vert,
                                      float* origin_scale, float* dval, void* workspace, void* stream) {
-    if (!workspace || B <= 0) return -1;
+    if (!workspace || B <= 0 || 2 * B > SDF_MAX_HANDS) return -1;
     hipStream_t st = (hipStream_t)stream;
     SdfWorkspace ws = sdf_carve(workspace, 2 * B);
     if (options) {
@@ -378,7 +386,7 @@ extern "C" int ihmr_sdf_collision(const int32_t* faces_right, const int32_t* fac
 
 extern "C" int ihmr_sdf_dense_grid(const int32_t* faces_right, const int32_t* faces_left, const float* hand_verts, int B,
                                    float* phi, void* workspace, void* stream) {
-    if (!workspace || B <= 0) return -1;
+    if (!workspace || B <= 0 || 2 * B > SDF_MAX_HANDS) return -1;
     hipStream_t st = (hipStream_t)stream;
     SdfWorkspace ws = sdf_carve(workspace, 2 * B);
     int32_t* soa = (int32_t*)((char*)workspace + sdf_ws_bytes(2 * B));
@@ -439,7 +447,7 @@ static int opt_forward(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
 
 extern "C" int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                                        const ihmr_opt_weights* w, void* stream) {
-    if (!m || !io || !w || B <= 0) return -1;
+    if (!m || !io || !w || B <= 0 || 2 * B > SDF_MAX_HANDS) return -1;
     hipStream_t st = (hipStream_t)stream;
     OptWork wk = opt_carve(io->workspace, B);
     int rc = opt_forward(m, m_left, io, wk, B, *w, kNoStep, st);
@@ -449,7 +457,7 @@ extern "C" int ihmr_opt_forward_losses(const ihmr_mano* m, const ihmr_mano* m_le
 
 extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B,
                                   const ihmr_opt_weights* w, const ihmr_opt_stage* sg, void* stream) {
-    if (!m || !io || !w || !sg || B <= 0 || sg->n_iters <= 0 || sg->save_freq <= 0) return -1;
+    if (!m || !io || !w || !sg || B <= 0 || 2 * B > SDF_MAX_HANDS || sg->n_iters <= 0 || sg->save_freq <= 0) return -1;
     if (sg->param_mask <= 0 || sg->param_mask > 255 || sg->select_loss < 0 || sg->select_loss > 2) return -1;
     if (sg->optimizer != IHMR_OPTIM_ADAM && sg->optimizer != IHMR_OPTIM_SGD) return -1;
     hipStream_t st = (hipStream_t)stream;
@@ -578,7 +586,7 @@ extern "C" int ihmr_mlp_stage_head(const ihmr_mlp_net* net, const ihmr_mlp_table
 
 extern "C" int ihmr_mlp_forward_select(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, const ihmr_opt_weights* w,
                                        const ihmr_mlp_tables* t, const ihmr_mlp_stage* stage, int mode, void* workspace, void* stream) {
-    if (!m || !io || !w || !workspace || B <= 0 || mode < 0 || mode > 2 || (mode && !t)) return -1;
+    if (!m || !io || !w || !workspace || B <= 0 || 2 * B > SDF_MAX_HANDS || mode < 0 || mode > 2 || (mode && !t)) return -1;
     MlpSelect sel;
     memset(&sel, 0, sizeof(sel));
     if (mode) { if (int rc = mlp_fill_select(sel, t, stage, mode, workspace)) return rc; }
@@ -750,9 +758,22 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
     // first 1 x 1 of every bottleneck from 28 x 28 down (100, 196 or 392 tiles: 0.4-1.5 per CU) -- are shared evenly by two workers per CU.
     // Measured per layer (scripts/prof_encoder_layers.sh, round 4): 3 x 3 layers 175-187 -> 144-158 us, 1 x 1 layers with K >= 1024
     // 90-155 -> 77-141 us; with 32 K steps the fix-up's traffic eats the gain (85 -> 88 us), so those keep one workgroup per tile.
-    int sk_workers = 512, sk_max_tiles = 768, sk_min_nk = 64;
+    // Workers: two per CU of THIS device, a multiple of 8 (conv_streamk_kernel numbers them by XCD), at most 512 (the workspace
+    // contract of include/ihmr_hip.h: two 64 KB tile slots per worker = 64 MiB)
+    static int sk_workers_dev[64] = {0};
+    int sk_dev = 0;
+    HIP_TRY(hipGetDevice(&sk_dev));
+    if (sk_workers_dev[sk_dev & 63] == 0) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sk_dev));
+        sk_workers_dev[sk_dev & 63] = std::max(8, std::min(512, 2 * (cus > 0 ? cus : 256) / 8 * 8));
+    }
+    int sk_workers = sk_workers_dev[sk_dev & 63], sk_max_tiles = 768, sk_min_nk = 64;
 #ifdef IHMR_TUNING_BUILD
-    if (const char* f = getenv("IHMR_CONV_SK")) sscanf(f, "%d %d %d", &sk_max_tiles, &sk_min_nk, &sk_workers);   // "<max tiles> <min K steps> <workers>"
+    if (const char* f = getenv("IHMR_CONV_SK")) {   // "<max tiles> <min K steps> <workers>"
+        sscanf(f, "%d %d %d", &sk_max_tiles, &sk_min_nk, &sk_workers);
+        if (sk_workers < 8 || sk_workers % 8 != 0) return -1;
+    }
 #endif
     const long sk_tiles = blocks(0);
     if (fast && pick == 0 && M > 64 && Cout % 128 == 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 && sk_tiles >= 64 && sk_tiles <= sk_max_tiles && nk >= sk_min_nk &&
@@ -931,6 +952,8 @@ extern "C" int ihmr_conv_wgrad(const float* x, const float* dy, float* dw, int N
                                size_t workspace_bytes, void* stream) {
     if (!x || !dy || !dw || !workspace || N <= 0 || Cin % 4 || lddy % 4 || ldx % 4 || ldw < Cout) return -1;
     hipStream_t st = (hipStream_t)stream;
+    // (conv_wgrad_kernel splits a pixel index by a float-reciprocal product with a +-1 correction: exact below 2^23 pixels)
+    if ((long)N * Ho * Wo >= (1L << 23)) return -1;
     const int M = N * Ho * Wo, K = kh * kw * Cin;
     const bool wide_n = Cout > 64, wide_m = K > 64;
     const int BMv = wide_m ? 128 : 64, BNv = wide_n ? 128 : 64;
@@ -1009,12 +1032,37 @@ extern "C" int ihmr_preprocess_images(const uint8_t* pixels, const int64_t* offs
     return (int)hipGetLastError();
 }
 
+extern "C" int ihmr_copy_segments(const ihmr_copy_seg* segs, int n, void* stream) {
+    if (!segs || n <= 0 || n > IHMR_COPY_MAX_SEGS) return -1;
+    CopySegTable t;
+    memset(&t, 0, sizeof(t));
+    long biggest = 0;
+    for (int i = 0; i < n; ++i) {
+        const ihmr_copy_seg& g = segs[i];
+        if (!g.src || !g.dst || g.rows <= 0 || g.width <= 0 || g.src_ld < g.width || g.dst_ld < g.width) return -1;
+        if (((uintptr_t)g.src | (uintptr_t)g.dst) & 3u) return -1;
+        t.s[i] = g;
+        biggest = std::max(biggest, (long)g.rows * g.width);
+    }
+    const unsigned bx = (unsigned)std::max<long>(1, std::min<long>(64, (biggest + 1023) / 1024));
+    hipLaunchKernelGGL(copy_segments_kernel, dim3(bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ihmr_root_align_joints(const float* joints4, float* out4, int B, void* stream) {
+    if (!joints4 || !out4 || B <= 0) return -1;
+    hipLaunchKernelGGL(root_align_joints_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, joints4, out4, B);
+    return (int)hipGetLastError();
+}
+
 extern "C" int ihmr_set_kernel_timer(ihmr_kernel_timer* t) {
+    std::lock_guard<std::mutex> lk(g_timer_mutex);
     g_timer = t;
     return 0;
 }
 
 extern "C" int ihmr_flush_kernel_timer(void) {
+    std::lock_guard<std::mutex> lk(g_timer_mutex);
     for (auto& p : g_pending) {
         float ms = 0.f;
         HIP_TRY(hipEventSynchronize(p.b));

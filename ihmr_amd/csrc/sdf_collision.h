@@ -37,7 +37,9 @@
 #define SDF_NCOL (SDF_G * SDF_G)   // 1024 columns (k,j)
 #define SDF_RAYQ 4096               // (triangle, needed column) pairs per window of the prep kernel's ray-parity queue (a hand has ~1000)
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
+#ifndef SDF_DIST_WG_PER_CU
 #define SDF_DIST_WG_PER_CU 4          // sdf_dist_kernel: 40 KB LDS, <= 128 VGPRs; its grid is persistent: this many workgroups per CU
+#endif
 #ifndef SDF_ITEM_RUN
 #define SDF_ITEM_RUN 2
 #endif
@@ -113,6 +115,7 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
 
 #define SDF_QCELL_IN 0x80000000u
 #define SDF_ENT_REFUSED 0x80000000u  // inside_list entry: (hand << 16) | voxel, hand < 32768; 0xffffffff = padding
+#define SDF_MAX_HANDS 32768          // ... so a launch takes at most 16384 samples (every entry point checks: ihmr_hip.hip)
 #define SDF_NCTR 64
 #define SDF_CURSOR 32
 #define SDF_NZERO 3                  // counters that have to be zero before the prep kernel: sdf_zero_counter(c, i), i < SDF_NZERO
@@ -1444,6 +1447,9 @@ __device__ __forceinline__ void sdf_list_item(const SdfWorkspace& ws, int item, 
 template <bool STATS>
 __global__ __launch_bounds__(SDF_THREADS, 4) void sdf_dist_kernel(SdfWorkspace ws) {
     TL_SCOPE(2);
+#ifdef SDF_SPIN      // experiment: pure residency (no instruction issued) added to every workgroup's life -- does throughput follow the occupied wave-time?
+    for (int i_ = 0; i_ < SDF_SPIN; ++i_) __builtin_amdgcn_s_sleep(127);
+#endif
     __shared__ __attribute__((aligned(16))) char smem[SDF_DIST_LDS];
     __shared__ int s_next[2];
 #ifdef SDF_STAMPS

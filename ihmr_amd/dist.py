@@ -43,6 +43,39 @@ def init_dist(backend: str | None = None):
     return rank, world
 
 
+def pin_to_gpu_numa_node(device_index: int):
+    """Best-effort CPU affinity for a one-process-per-GPU rank: restrict this process to the cores of the NUMA node its GPU hangs off
+    (``/sys/bus/pci/devices/<bdf>/numa_node`` -> ``/sys/devices/system/node/node<k>/cpulist``).  A rank's host work is graph launches
+    and small copies (bench.py: ``host_submit_ms_per_step``); on a two-socket node eight unpinned ranks migrate across sockets and
+    their submission latency (PCIe doorbells, pinned-buffer reads) goes through the inter-socket link.  Returns a short description,
+    or None when the topology cannot be read (nothing is changed then).  INTEGRATION.md "Multi-GPU launch" shows the equivalent
+    ``numactl`` line for launchers that prefer to pin from outside."""
+    try:
+        import ctypes
+        hiprt = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hiprt.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+            return None
+        bdf = buf.value.decode()
+        path = f"/sys/bus/pci/devices/{str(bdf).lower()}/numa_node"
+        if not os.path.isfile(path):
+            return None
+        node = int(open(path).read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return f"GPU {device_index} ({bdf}) -> NUMA node {node}: {len(cpus)} cores"
+    except Exception:       # (no sysfs, no permission, exotic torch build: run unpinned)
+        return None
+
+
 def shard_indices(num_samples: int, batch_size: int, rank: int, world: int):
     """Contiguous per-rank slices of the padded index list; returns (indices, is_padding) for this rank."""
     per_round = batch_size * world

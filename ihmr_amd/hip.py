@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "ihmr_adam_step", "ihmr_bn_workspace_bytes", "ihmr_bn_train_forward", "ihmr_bn_train_backward", "ihmr_conv_wgrad",
     "ihmr_dilate2", "ihmr_interleave2", "ihmr_pack_dgrad_weight", "ihmr_maxpool3x3s2_backward", "ihmr_avgpool_relu_backward", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer",
     "ihmr_mlp_workspace_bytes", "ihmr_mlp_stage_head", "ihmr_mlp_forward_select", "ihmr_opt_forward_verts",
-    "ihmr_debug_force_lbs_bwd2_streaming", "ihmr_version",
+    "ihmr_debug_force_lbs_bwd2_streaming", "ihmr_version", "ihmr_copy_segments", "ihmr_root_align_joints",
 ]
 
 
@@ -58,6 +58,43 @@ class OptIO(C.Structure):
         ("norm_batch", C.c_int), ("sdf_align_corners", C.c_int), ("sdf_loss_divisor", C.c_float), ("sdf_swap_xz", C.c_int),
         ("sdf_no_candidate_lists", C.c_int), ("sdf_no_static_reuse", C.c_int),
         ("no_fused_tail", C.c_int)]
+
+
+class CopySeg(C.Structure):
+    """``ihmr_copy_seg``: one 2-D strided copy of 32-bit words (rows, width, leading dimensions in dwords)."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("width", C.c_int), ("src_ld", C.c_int), ("dst_ld", C.c_int)]
+
+
+COPY_MAX_SEGS = 32
+
+
+def copy_segments(pairs):
+    """``pairs``: (src, dst) device tensors of equal shape and 4- or 8-byte element type -- dst may be a strided 2-D view (a column
+    slice of a packed matrix), src too; everything else contiguous.  One launch (``ihmr_copy_segments``) per 32 pairs."""
+    segs = []
+    for src, dst in pairs:
+        assert src.shape == dst.shape and src.dtype == dst.dtype and src.is_cuda and dst.is_cuda, (src.shape, dst.shape, src.dtype, dst.dtype)
+        k = src.element_size() // 4
+        assert k in (1, 2)
+
+        def geom(t):
+            if t.is_contiguous():
+                return 1, t.numel() * k, t.numel() * k
+            assert t.dim() == 2 and t.stride(1) == 1, "a strided operand must be a column slice of a row-major matrix"
+            return t.shape[0], t.shape[1] * k, t.stride(0) * k
+        (rs, ws, ls), (rd, wd, ld) = geom(src), geom(dst)
+        if (rs, ws) != (rd, wd):                 # one side flat, the other a 2-D slice: describe both as the slice's rows
+            rows, width = (rd, wd) if rd > 1 else (rs, ws)
+            ls = ls if rs > 1 else width
+            ld = ld if rd > 1 else width
+        else:
+            rows, width = rs, ws
+        segs.append(CopySeg(src.data_ptr(), dst.data_ptr(), rows, width, ls, ld))
+    L, st = lib(), stream_ptr()
+    for i in range(0, len(segs), COPY_MAX_SEGS):
+        chunk = segs[i:i + COPY_MAX_SEGS]
+        arr = (CopySeg * len(chunk))(*chunk)
+        check(L.ihmr_copy_segments(arr, len(chunk), st), "ihmr_copy_segments")
 
 
 class SdfOptions(C.Structure):
@@ -257,6 +294,8 @@ def lib():
         L.ihmr_opt_sdf_counters.argtypes = [C.POINTER(OptIO), i, vp, i]
         L.ihmr_set_kernel_timer.argtypes = [C.POINTER(KernelTimer)]
         L.ihmr_flush_kernel_timer.argtypes = []
+        L.ihmr_copy_segments.argtypes = [C.POINTER(CopySeg), i, vp]
+        L.ihmr_root_align_joints.argtypes = [vp, vp, i, vp]
         L.ihmr_version.restype = C.c_char_p
         _LIB = L
     return _LIB

@@ -53,7 +53,9 @@ _WS = {}
 
 def _splitk_workspace(device):
     """128 MB of scratch per (device, stream) for the partial sums of ihmr_conv_igemm (split-K layers: ksplit x M x Cout floats;
-    Stream-K layers: two 64 KB tile slots per worker, 512 workers)."""
+    Stream-K layers: two 64 KB tile slots per worker, 512 workers).  Per STREAM on purpose: convolutions of two streams run
+    concurrently (two instances in flight) and each needs its own scratch; a hipGraph capture runs on its own stream and so owns
+    one more buffer, which lives as long as the captured graph replays into it."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _WS:
         _WS[key] = torch.empty(32 * 1024 * 1024, device=device, dtype=torch.float32)
@@ -153,9 +155,13 @@ class InterHandEncoder(nn.Module):
             self._pack(dev)
         P = self._packed
         B, C, H, W = main_input.shape
-        x = getattr(self, "_nhwc4", None)                                  # NHWC, 3 -> 4 channels (layout plumbing only); channel 3 stays zero
+        # NHWC, 3 -> 4 channels (layout plumbing only); channel 3 stays zero.  One staging buffer per launch stream: two forwards of one
+        # module on two streams (two instances in flight share the weights) must not write the same buffer
+        cache = self.__dict__.setdefault("_nhwc4", {})
+        skey = torch.cuda.current_stream(dev).cuda_stream
+        x = cache.get(skey)
         if x is None or x.shape[:3] != (B, H, W) or x.device != dev:
-            x = self._nhwc4 = torch.zeros(B, H, W, 4, device=dev)
+            x = cache[skey] = torch.zeros(B, H, W, 4, device=dev)
         x[..., :3].copy_(main_input.permute(0, 2, 3, 1))
         # stem: conv 7x7/2 + BN + ReLU, max-pool 3x3/2
         y, H, W = conv_igemm(x, P["stem"], B, H, W, ldx=4, act=1)

@@ -27,7 +27,11 @@ import torch
 
 
 def synthetic_opt_batch(batch_size: int, forward_fn: Callable, seed: int = 1234, first_index: int = 0,
-                        with_image: bool = False, with_feat: bool = False) -> Dict[str, torch.Tensor]:
+                        with_image: bool = False, with_feat: bool = False, interlock: bool = False) -> Dict[str, torch.Tensor]:
+    """``interlock`` (for the finger asset, ``assets.synthetic_mano(kind="fingers")``): instead of two hands lying on each other, the
+    left hand keeps its native direction (the mirrored model points to -x) and comes from the front, its wrist ~26 cm ahead of the
+    right wrist and half a finger pitch to the side: the fingers of one hand sit between -- and, with the random pose noise, in --
+    the fingers of the other.  Same random draws as the default batch (which is unchanged), other means."""
     rng = np.random.RandomState(seed)
     B = batch_size
     f32 = np.float32
@@ -39,6 +43,9 @@ def synthetic_opt_batch(batch_size: int, forward_fn: Callable, seed: int = 1234,
     init_cam = (np.array([5.0, 0.0, 0.0]) + rng.normal(0.0, 0.05, size=(B, 3))).astype(f32)
     init_trans = (rng.uniform(-1.0, 1.0, size=(B, 3)) * np.array([0.02, 0.02, 0.012])
                   + np.array([0.0, 0.0, 0.034])).astype(f32)
+    if interlock:
+        init_pose[:, 48:51] -= np.array([0.0, 0.0, 0.97 * math.pi], f32)          # no half turn: the left hand points at the right one
+        init_trans = (init_trans - np.array([0.0, 0.0, 0.034], f32)) * np.array([1.0, 0.5, 0.5], f32) + np.array([0.26, 0.009, 0.002], f32)
 
     pose_star = init_pose + rng.normal(0.0, 0.1, size=(B, 96)).astype(f32)
     shape_star = init_shape + rng.normal(0.0, 0.2, size=(B, 20)).astype(f32)

@@ -234,8 +234,9 @@ int ihmr_opt_sdf_counters(const ihmr_opt_io* io, int B, unsigned long long* out1
  * workspace (optional, device, workspace_bytes): scratch for partial sums.  Layers too small to fill the GPU (Linear layers: up to 32)
  * split their K loop over up to min(32, workspace_bytes / (M*Cout*4)) workgroups.  Layers with >= 64 K steps of 16 and 64..768 tiles
  * of 128 x 128 (at batch 64: every 3 x 3 layer and the long 1 x 1 layers from 28 x 28 down) run in Stream-K form when
- * workspace_bytes >= 64 MiB + 4 KiB (512 workers x two 64 KB tile slots): the workers share tiles x K steps evenly and a fix-up launch adds
- * a tile's pieces in ascending K order.  Every form sums in a fixed order: results are bit-identical from run to run; they differ between
+ * workspace_bytes >= workers x 128 KiB (two 64 KB tile slots per worker; workers = two per CU of the device, a multiple of 8, at most
+ * 512: 64 MiB on an MI355X -- exactly what the launcher checks): the workers share tiles x K steps evenly and a fix-up launch adds
+ * a tile's pieces in ascending K order.  A caller with a smaller workspace gets the split-K form (different last bits, see below).  Every form sums in a fixed order: results are bit-identical from run to run; they differ between
  * forms (i.e. with and without a workspace) in the last bits. */
 int ihmr_conv_igemm(const float* x, const float* w, const float* bias, const float* residual, float* y, int N, int H, int W,
                     int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int ldx, int ldw, int ldy, int ldr,
@@ -261,6 +262,19 @@ int ihmr_eval_metrics(const float* pred_joints_3d, const float* gt_joints_3d, co
 int ihmr_eval_mpvpe(const float* pred_right, const float* pred_left, const float* gt_right, const float* gt_left,
                     const float* root_weights, const float* mano_params_weight, const float* sample_scale, int B,
                     double* out4, void* stream);
+
+/* ------------------------------------------------------------------ packed transfers (round 5)
+ * MLPModel.set_input (models/mlp_model.py:120-170) and get_pred_result (:702-719) move 17 + 13 small tensors one copy at a time; one
+ * launch does a whole table of them.  A segment = a 2-D strided copy of 32-bit words: dst[r * dst_ld + c] = src[r * src_ld + c] for
+ * r < rows, c < width (all four in dwords; a contiguous tensor: rows = 1, width = its dword count; an int64 tensor counts two dwords
+ * per element).  n <= IHMR_COPY_MAX_SEGS, device pointers, 4-byte aligned, no overlap between a segment's source and any destination. */
+#define IHMR_COPY_MAX_SEGS 32
+typedef struct ihmr_copy_seg { const void* src; void* dst; int rows, width, src_ld, dst_ld; } ihmr_copy_seg;
+int ihmr_copy_segments(const ihmr_copy_seg* segs, int n, void* stream);
+/* The export's GT joints (mlp_model.py:530-531: the annotation, root-aligned in place by the 3-D loss, loss_utils.py:90-98):
+ * joints4 (B,42,4) [x,y,z,weight] -> out4 (B,42,4), every joint minus its sample's root joint (joint 0 if its weight > 0.5, joint 21
+ * if < 1e-7, none otherwise). */
+int ihmr_root_align_joints(const float* joints4, float* out4, int B, void* stream);
 
 /* ------------------------------------------------------------------ IHMR-MLP training step */
 /* Gradient of the training objective `MLPModel.compute_loss(stage['loss_weights'])` (models/mlp_model.py:514-583)
@@ -353,7 +367,10 @@ int ihmr_preprocess_images(const uint8_t* pixels, const int64_t* offsets, const 
                            int B, int final_size, float* img_out, uint8_t* img_u8, const float* joints_in,
                            float* joints_out, void* stream);
 
-/* per-kernel timing hook for bench.py: when non-NULL, the library records hipEvents on the launch stream around the three
+/* per-kernel timing hook for bench.py -- the ONE piece of PROCESS-GLOBAL state of this library (everything else is stateless apart
+ * from the model handle): the timer pointer and the pending event pairs are shared by every stream and every thread of the process
+ * (a mutex makes concurrent callers safe, it does not separate their measurements); callers that do not set a timer never touch it.
+ * When non-NULL, the library records hipEvents on the launch stream around the three
  * large kernels of a refinement iteration and accumulates here (host pointer, read after ihmr_flush_kernel_timer()):
  * slot IHMR_TIMED_SDF_PREP = sdf_prep_kernel, IHMR_TIMED_SDF_DIST = sdf_dist_kernel (every collision evaluation), IHMR_TIMED_OPT_TAIL =
  * the per-sample tail launch of a fused-loop iteration (opt_tail_kernel, any instantiation).  ms[k] / n[k]: summed event-to-event
@@ -389,7 +406,9 @@ int ihmr_flush_kernel_timer(void);
  * All pointers device pointers. */
 typedef struct ihmr_mlp_net { const float* w[4]; const float* b[4]; int ldw[4]; int k_out; int col[122]; } ihmr_mlp_net;
 typedef struct ihmr_mlp_tables {
-    const int64_t* idx;        /* (B) dataset index of every batch row */
+    const int64_t* idx;        /* (B) dataset index of every batch row -- PRECONDITION: distinct within a batch (the reference's OptDataset gives
+                                * padded copies their own positions, opt_dataset.py:38-51): two rows with one index would race on that row of the
+                                * "prev" tables below (keep / reject reads then writes prev_loss / prev_final without ordering between rows) */
     uint8_t* data_idxs_all;    /* (num_data) */
     float* img_feat_all;       /* (num_data,1024) */
     float* prev_final;         /* (num_data,122) */

@@ -27,11 +27,11 @@ TIP_IDS = [744, 320, 443, 554, 671]  # optimize_model.py:99
 
 
 # ----------------------------------------------------------------------------- opt_utils.py
-def gather_params_losses(mid_results, stage):
-    """opt_utils.py:70-98: stack the snapshots -> (S,B,...)."""
+def gather_params_losses(mid_results, stage, dtype=torch.float32):
+    """opt_utils.py:70-98: stack the snapshots -> (S,B,...)  (`.float()` in the reference; `dtype` = float64 for the arbiter run)."""
     names_l = [n for n, _ in stage["filter_loss"]] + [stage["select_loss"]]
-    all_params = {n: torch.stack([m[n] for m in mid_results]).float() for n in stage["update_params"]}
-    all_losses = {n: torch.stack([m[n] for m in mid_results]).float() for n in names_l}
+    all_params = {n: torch.stack([m[n] for m in mid_results]).to(dtype) for n in stage["update_params"]}
+    all_losses = {n: torch.stack([m[n] for m in mid_results]).to(dtype) for n in names_l}
     return all_params, all_losses
 
 
@@ -61,16 +61,21 @@ def select_params(all_params, all_losses, select_loss_name):
 # ----------------------------------------------------------------------------- optimize_model.py
 class OptimizeRef:
     def __init__(self, mano_right_arrays, mano_left_arrays, batch_size, strategy, save_mid_freq=1,
-                 default_loss_weights=None, record=False, optimizer="adam", smplx_create=None, sdf_loss_cls=None, device="cpu"):
+                 default_loss_weights=None, record=False, optimizer="adam", smplx_create=None, sdf_loss_cls=None, device="cpu",
+                 dtype=torch.float32):
         """``smplx_create`` / ``sdf_loss_cls`` / ``device``: the two third-party seams of the reference
         (``smplx.create``, ``sdf.SDFLoss``) can be filled with another implementation -- the tests use
         this to run THIS reference-shaped loop (autograd + torch.optim) over the product's seam-A / seam-B modules on the
-        GPU, i.e. the import-swap integration route of INTEGRATION.md.  Default: the CPU restatements."""
+        GPU, i.e. the import-swap integration route of INTEGRATION.md.  Default: the CPU restatements.
+        ``dtype=torch.float64``: the ARBITER -- the same loop, MANO layer and voxel grid in double precision (float32 inputs converted
+        exactly): two float32 implementations of 200 Adam steps end a few 1e-5 m apart, and their distances from this run say whether
+        that is the arithmetic or an implementation (tests/test_gpu_parity.py, bench.py: parity.vs_f64)."""
         self.batch_size = batch_size
+        self.dtype = dtype
         self.device = torch.device(device)
         if smplx_create is None:
-            self.mano_right = ManoRef(mano_right_arrays, batch_size=2 * batch_size)
-            self.mano_left = ManoRef(mano_left_arrays, batch_size=2 * batch_size)
+            self.mano_right = ManoRef(mano_right_arrays, batch_size=2 * batch_size, dtype=dtype)
+            self.mano_left = ManoRef(mano_left_arrays, batch_size=2 * batch_size, dtype=dtype)
         else:   # optimize_model.py:102-108
             self.mano_right = smplx_create("", "mano", use_pca=False, is_rhand=True, batch_size=2 * batch_size)
             self.mano_left = smplx_create("", "mano", use_pca=False, is_rhand=False, batch_size=2 * batch_size)
@@ -96,7 +101,7 @@ class OptimizeRef:
 
     # optimize_model.py:120-168
     def set_input(self, data):
-        f = lambda k: data[k].detach().clone().float().to(self.device)
+        f = lambda k: data[k].detach().clone().float().to(self.device).to(self.dtype)
         self.hand_type_array = f("hand_type_array")
         self.joints_2d = f("joints_2d")
         self.joints_3d = f("joints_3d")
@@ -219,7 +224,7 @@ class OptimizeRef:
                         j3d_batch=self.joints_3d_loss_p_batch.detach().clone().cpu().numpy(),
                         coll_batch=self.collision_loss_batch.detach().clone().cpu().numpy()))
                 optimizer.step()
-            all_params, all_losses = gather_params_losses(mid, stage)
+            all_params, all_losses = gather_params_losses(mid, stage, self.dtype)
             all_losses = filter_by_losses(all_losses, stage["filter_loss"])
             sel, idxs = select_params(all_params, all_losses, stage["select_loss"])
             self.selected.append(idxs.cpu().numpy().copy())

@@ -67,13 +67,38 @@ def _lib():
     return _LIB
 
 
+_LIB64 = None
+
+
+def _lib64():
+    """The float64 build of the same C source (oracle/sdf_grid_f64.c): the arbiter of the parity tests."""
+    global _LIB64
+    if _LIB64 is None:
+        so = osp.join(_HERE, "liboracle_sdf_f64.so")
+        srcs = [osp.join(_HERE, "sdf_grid.c"), osp.join(_HERE, "sdf_grid_f64.c")]
+        if not osp.isfile(so) or osp.getmtime(so) < max(osp.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_sdf_f64.so"], stdout=subprocess.DEVNULL)
+        lib = ctypes.CDLL(so)
+        lib.ihmr_oracle_sdf_grid_f64.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        lib.ihmr_oracle_sdf_grid_f64.restype = None
+        _LIB64 = lib
+    return _LIB64
+
+
 def sdf_grid(verts_n: torch.Tensor, faces: torch.Tensor, grid: int = GRID) -> torch.Tensor:
-    """verts_n (H,V,3) float32 normalised to [-1,1]; faces (F,3) int32 -> phi (H,G,G,G)."""
-    v = np.ascontiguousarray(verts_n.detach().cpu().numpy(), dtype=np.float32)
+    """verts_n (H,V,3) normalised to [-1,1]; faces (F,3) int32 -> phi (H,G,G,G).  float32 vertices: the float32 grid (the spec the HIP
+    kernels match bit for bit); float64 vertices: the same algorithm in double precision (the arbiter)."""
+    f64 = verts_n.dtype == torch.float64
+    dt = np.float64 if f64 else np.float32
+    v = np.ascontiguousarray(verts_n.detach().cpu().numpy(), dtype=dt)
     f = np.ascontiguousarray(faces.cpu().numpy(), dtype=np.int32)
     H, V, _ = v.shape
-    phi = np.empty((H, grid, grid, grid), dtype=np.float32)
-    _lib().ihmr_oracle_sdf_grid(v.ctypes.data, f.ctypes.data, H, V, f.shape[0], grid, phi.ctypes.data)
+    phi = np.empty((H, grid, grid, grid), dtype=dt)
+    if f64:
+        _lib64().ihmr_oracle_sdf_grid_f64(v.ctypes.data, f.ctypes.data, H, V, f.shape[0], grid, phi.ctypes.data)
+    else:
+        _lib().ihmr_oracle_sdf_grid(v.ctypes.data, f.ctypes.data, H, V, f.shape[0], grid, phi.ctypes.data)
     return torch.from_numpy(phi)
 
 

@@ -43,3 +43,23 @@ cap_w, cap_v = 256 * 4 * 8, 256 * 4 * 512
 print(f"mean resident waves {tot_w.mean():.0f} of {cap_w} slots; mean VGPR residency {100 * tot_v.mean() / cap_v:.1f} % of the register file")
 f = tot_v / cap_v
 print("register-file residency: " + ", ".join(f"< {int(100 * x)} %: {100 * (f < x).mean():.1f} % of the time" for x in (0.1, 0.25, 0.5, 0.75, 0.9)))
+
+# ---- an excerpt of the residency time series (argv[2] = start ms, default the middle; 2 us per row, 150 rows): VGPR share per kind
+if len(sys.argv) > 2 or True:
+    start = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else T / 2
+    res = 2.0
+    rows = 150
+    names = [KIND.get(k, (str(k), 128))[0][:9] for k in sorted(set(kind))]
+    print("t_us   " + " ".join(f"{n:>9s}" for n in names) + "   total% (of the register file)")
+    series = {}
+    for k in sorted(set(kind)):
+        m = kind == k
+        vg = KIND.get(k, (str(k), 128))[1]
+        d = np.zeros(rows + 2)
+        a = np.clip(((t0[m] - start) / res).astype(int), 0, rows + 1); bb = np.clip(((t1[m] - start) / res).astype(int) + 1, 0, rows + 1)
+        live = (t1[m] > start) & (t0[m] < start + rows * res)
+        np.add.at(d, a[live], waves[m][live] * vg); np.add.at(d, bb[live], -waves[m][live] * vg)
+        series[k] = np.cumsum(d)[:rows] / cap_v * 100
+    for r in range(rows):
+        vals = [series[k][r] for k in sorted(series)]
+        print(f"{r * res:6.0f} " + " ".join(f"{v:9.1f}" for v in vals) + f"   {sum(vals):6.1f}")

@@ -50,6 +50,20 @@ def test_bench_with_eight_ranks_runs_config_5_code_path():
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 512 and d["steps"] == 8 and d["warmup"] == 3 and d["scaling"] == "weak"
     assert d["config"]["parallelism"].startswith("dp8") and d["value"] > 0 and d["cpu_baseline"] is None
     assert abs(d["value"] - 512 * 8 / (d["ms_per_step"] * 8 / 1000.0)) < 1e-6 * d["value"]     # whole-job images / max-over-ranks time
+    # host submission cost, max over the 8 ranks (round 5): what a rank's launch thread spends per step must stay below the GPU time
+    # of a step on a GPU of its own (2.7 ms, BENCH_r04) -- here with the eight ranks contending for one GPU's queues AND one host
+    assert 0.0 < d["host_submit_ms_per_step"] < 2.7, d["host_submit_ms_per_step"]
+
+
+def test_host_submission_cost_is_a_fraction_of_a_step():
+    """One rank: the launch thread's work per step (graph launches, input staging, export requests; bench.py:
+    host_submit_ms_per_step) against the step's GPU time."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-extras", "--no-work-counters"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(f"[bench] host submit {d['host_submit_ms_per_step']:.3f} ms per step of {d['ms_per_step']:.3f} ms")
+    assert 0.0 < d["host_submit_ms_per_step"] < 0.5 * d["ms_per_step"]
 
 
 def test_run_optimize_eight_ranks_with_padding_equals_one_process():

@@ -132,8 +132,8 @@ def test_lbs_dense_weight_asset_matches_oracle(mano_arrays):
 
 
 # ----------------------------------------------------------------------------------- seam B (collision)
-def _two_hand_verts(mano_arrays, B, seed):
-    """(B,2,778,3) penetrating hand pairs from the oracle forward on the synthetic batch."""
+def _two_hand_verts(mano_arrays, B, seed, interlock=False):
+    """(B,2,778,3) penetrating hand pairs from the oracle forward on the synthetic batch (interlock: the finger asset's batch generator)."""
     from oracle.opt_ref import OptimizeRef
     from ihmr_amd.synthetic import synthetic_opt_batch
     right, left = mano_arrays
@@ -147,7 +147,7 @@ def _two_hand_verts(mano_arrays, B, seed):
         fwd.out = orc.get_mano_output()
         return fwd.out[2]
 
-    batch = synthetic_opt_batch(B, fwd, seed=seed)
+    batch = synthetic_opt_batch(B, fwd, seed=seed, interlock=interlock)
     fwd(batch["init_pose_params"], batch["init_shape_params"], batch["init_hand_trans"][:, 0, :3])
     rv, lv, _ = fwd.out
     return torch.stack([rv, lv], dim=1).contiguous(), batch
@@ -164,12 +164,32 @@ def test_sdf_dense_grid_bit_exact(mano_arrays, squash):
     projects every vertex onto a sphere about the hand's centre: voxels near the centre are (nearly) equidistant from
     all 1538 triangles, so the bounding-sphere cull keeps more triangles than the per-wave survivor list holds and the
     distance kernel takes its overflow path."""
+    B = 2
+    hv, _ = _two_hand_verts(mano_arrays, B, 77)
+    _dense_grid_check(mano_arrays, hv, squash)
+
+
+@pytest.fixture(scope="module")
+def finger_arrays():
+    """The geometry-sensitivity asset (round 5): the same MANO-shaped model on a mesh with a palm and five finger tubes."""
+    from ihmr_amd.assets import synthetic_mano
+    return synthetic_mano(True, kind="fingers"), synthetic_mano(False, kind="fingers")
+
+
+def test_sdf_dense_grid_bit_exact_on_the_finger_asset(finger_arrays):
+    """The same bit-for-bit grid test on the five-finger mesh with interlocked hands (thin tubes, webs between the fingers, many
+    more triangles per voxel neighbourhood than the blob) and on the default pose distribution."""
+    for interlock in (True, False):
+        hv, _ = _two_hand_verts(finger_arrays, 2, 77, interlock=interlock)
+        _dense_grid_check(finger_arrays, hv, None)
+
+
+def _dense_grid_check(mano_arrays, hv, squash):
     import ctypes as C
     from ihmr_amd import hip
     from oracle import sdf_ref
     right, left = mano_arrays
-    B = 2
-    hv, _ = _two_hand_verts(mano_arrays, B, 77)
+    B = hv.shape[0]
     if squash == "ball":
         c = hv.mean(dim=2, keepdim=True)
         d = hv - c
@@ -267,23 +287,54 @@ def test_sdf_disjoint_hands_zero(mano_arrays):
 
 
 # ----------------------------------------------------------------------------------- seam C (OPT loop)
-def _make_opt(B, strategy="opt_default", epoch=4, save_mid_freq=2):
+def _make_opt(B, strategy="opt_default", epoch=4, save_mid_freq=2, model_root=""):
     import types
     return types.SimpleNamespace(isTrain=False, dist=False, process_rank=-1, batchSize=B, inputSize=224, num_joints=42,
                                  total_params_dim=122, cam_params_dim=3, pose_params_dim=96, shape_params_dim=20,
-                                 trans_params_dim=3, model_root="", strategy=strategy, save_mid_freq=save_mid_freq,
+                                 trans_params_dim=3, model_root=model_root, strategy=strategy, save_mid_freq=save_mid_freq,
                                  optimizer="adam", opt_epoch=epoch)
 
 
-def _oracle_and_model(mano_arrays, B, epoch, freq, seed=1234, record=True):
+def _oracle_and_model(mano_arrays, B, epoch, freq, seed=1234, record=True, fingers=False):
+    """fingers: `mano_arrays` is the finger asset -- the product loads the same asset (model_root "synthetic:fingers") and the batch
+    comes from the interlocked generator."""
     from ihmr_amd.optimize_model import OptimizeModel
     from ihmr_amd.strategies import make_opt_strategy
     from oracle.opt_ref import OptimizeRef
     right, left = mano_arrays
-    _, batch = _two_hand_verts(mano_arrays, B, seed)
+    _, batch = _two_hand_verts(mano_arrays, B, seed, interlock=fingers)
     orc = OptimizeRef(right, left, B, make_opt_strategy(epoch), save_mid_freq=freq, record=record)
-    model = OptimizeModel(_make_opt(B, epoch=epoch, save_mid_freq=freq))
+    model = OptimizeModel(_make_opt(B, epoch=epoch, save_mid_freq=freq, model_root="synthetic:fingers" if fingers else ""))
     return orc, model, batch
+
+
+ARBITER_KEYS = (("joints", "pred_joints_3d"), ("right verts", "pred_right_hand_verts"), ("left verts", "pred_left_hand_verts"),
+                ("penetration depth", "collision_loss_origin_scale"))
+
+
+def _f64_arbiter(mano_arrays, B, epoch, freq, batch):
+    """The oracle's loop in FLOAT64 (MANO layer, losses, Adam and the voxel grid in double precision; the float32 inputs converted
+    exactly) on the same batch: the reference trajectory both float32 implementations are measured against."""
+    from ihmr_amd.strategies import make_opt_strategy
+    from oracle.opt_ref import OptimizeRef
+    right, left = mano_arrays
+    arb = OptimizeRef(right, left, B, make_opt_strategy(epoch), save_mid_freq=freq, dtype=torch.float64)
+    arb.set_input(batch); arb.init_optimize(); arb.optimize()
+    return arb.get_pred_result(), np.stack(arb.selected), arb
+
+
+def _arbiter_distances(tag, g, r, a, same):
+    """max |hip - f64| and max |oracle32 - f64| per key over the samples `same` (every stage picked the same snapshot in all three
+    runs).  The HIP path may sit at most 1.5 x as far from the float64 trajectory as the float32 oracle does (+ 2e-6 m: both
+    distances are at float32 resolution when the trajectories have not separated)."""
+    out = {}
+    for name, key in ARBITER_KEYS:
+        d_hip = float(np.abs(g[key][same].astype(np.float64) - a[key][same]).max())
+        d_o32 = float(np.abs(r[key][same].astype(np.float64) - a[key][same]).max())
+        out[name] = (d_hip, d_o32)
+        print(f"[parity] {tag} {name} [m]: max|hip - f64| = {d_hip:.3e}, max|oracle32 - f64| = {d_o32:.3e} (ratio {d_hip / max(d_o32, 1e-30):.2f})")
+        assert d_hip <= 1.5 * d_o32 + 2e-6, (tag, name, d_hip, d_o32)
+    return out
 
 
 def test_opt_forward_losses_match_oracle(mano_arrays):
@@ -696,8 +747,18 @@ def test_opt_mixed_parameter_stage_trajectory(mano_arrays):
 def test_opt_batch64_matches_oracle(mano_arrays):
     """IHMR-OPT at the benchmark's batch size (64 samples = 128 hands: the launch shapes the bench line is measured
     with), 4 stages x 5 iterations, snapshot every 2, against the oracle."""
+    _batch64_trajectory(mano_arrays, fingers=False)
+
+
+def test_opt_batch64_matches_oracle_on_the_finger_asset(finger_arrays):
+    """The same trajectory test on the five-finger mesh with interlocked hands (round 5: the geometry the blob cannot show -- thin
+    penetration volumes between fingers, long candidate lists, more refused voxels)."""
+    _batch64_trajectory(finger_arrays, fingers=True)
+
+
+def _batch64_trajectory(mano_arrays, fingers):
     B, epoch, freq = 64, 4, 2
-    orc, model, batch = _oracle_and_model(mano_arrays, B, epoch, freq, seed=6464, record=False)
+    orc, model, batch = _oracle_and_model(mano_arrays, B, epoch, freq, seed=6464, record=False, fingers=fingers)
     torch.set_num_threads(max(1, min(32, (__import__("os").cpu_count() or 8))))
     orc.set_input(batch); orc.init_optimize(); orc.optimize()
     model.set_input(batch); model.init_optimize(); model.optimize()
@@ -721,7 +782,9 @@ def test_opt_headline_workload_matches_oracle(mano_arrays):
     """BASELINE.json's metric config itself -- IHMR-OPT, batch 64, opt_default at epoch 49 = 4 x 50 = 200 refinement iterations,
     snapshot every 10 (what bench.py times) -- against the oracle (minutes of CPU time): selection indices identical; the metrics
     north_star names (MPJPE, mean per-vertex distance, mean penetration depth) within 1e-4; element by element within 3e-4 with
-    at least 99.9 % of the elements within 1e-4 (see the comment at the assertion)."""
+    at least 99.9 % of the elements within 1e-4 (see the comment at the assertion).  Round 5: the element-wise bar is JUSTIFIED by a
+    float64 arbiter -- the same loop in double precision: the float32 oracle itself sits as far from it as the HIP path does
+    (asserted: max |hip - f64| <= 1.5 x max |oracle32 - f64| per key, over the samples whose selections agree in all three runs)."""
     B, epoch, freq = 64, 49, 10
     orc, model, batch = _oracle_and_model(mano_arrays, B, epoch, freq, seed=1234, record=False)
     torch.set_num_threads(max(1, min(32, (__import__("os").cpu_count() or 8))))
@@ -750,6 +813,14 @@ def test_opt_headline_workload_matches_oracle(mano_arrays):
     print(f"[parity] headline: mean penetration depth ref={mp_ref:.6e} got={mp_got:.6e}; MPJPE ref={mpjpe(r):.6e} got={mpjpe(g):.6e}; "
           f"mean per-vertex distance HIP vs oracle {mpvpe:.3e}")
     assert abs(mp_ref - mp_got) < 1e-4 and abs(mpjpe(r) - mpjpe(g)) < 1e-4 and mpvpe < 1e-4
+    # ---- the arbiter: who is how far from the float64 trajectory?
+    a, sel_f64, _ = _f64_arbiter(mano_arrays, B, epoch, freq, batch)
+    same = np.all(sel_f64 == sel_ref, axis=0) & np.all(sel_f64 == sel_got, axis=0)
+    print(f"[parity] headline arbiter: selections of all three runs agree on {int(same.sum())} of {B} samples "
+          f"(hip vs f64 differ at {int((sel_got != sel_f64).sum())}, oracle32 vs f64 at {int((sel_ref != sel_f64).sum())} of {sel_f64.size} (stage, sample) pairs)")
+    assert same.sum() >= B - 4 and (sel_got != sel_f64).sum() <= (sel_ref != sel_f64).sum() + 2
+    _arbiter_distances("headline arbiter", g, r, a, same)
+    assert abs(float(a["collision_loss_origin_scale"].mean()) - mp_got) < 1e-4 and abs(mpjpe(a) - mpjpe(g)) < 1e-4
 
 
 @pytest.mark.slow
@@ -766,6 +837,9 @@ def test_opt_reference_default_schedule_matches_oracle(mano_arrays):
     orc.set_input(batch); orc.init_optimize(); orc.optimize()
     r = orc.get_pred_result()
     sel_ref = np.stack(orc.selected)
+    # the float64 arbiter of the same schedule (round 5): where the two float32 runs pick different snapshots, is either of them "right"?
+    a, sel_f64, arb = _f64_arbiter(mano_arrays, B, epoch, freq, batch)
+    print(f"[parity] 4x301 arbiter: oracle32 picks another snapshot than float64 at {int((sel_ref != sel_f64).sum())} of {sel_f64.size} (stage, sample) pairs")
     o2 = _make_opt(B, epoch=epoch, save_mid_freq=freq)
     o2.sdf_no_candidate_lists = True
     outs, sels = {}, {}
@@ -788,6 +862,18 @@ def test_opt_reference_default_schedule_matches_oracle(mano_arrays):
             print(f"[parity]    stage {st_i} sample {b_i}: oracle loss at the HIP choice {tab[sel[st_i, b_i]]:.6e}, oracle minimum {tab.min():.6e}")
             assert tab[sel[st_i, b_i]] <= tab.min() + max(1e-2 * tab.min(), 2e-4), (name, st_i, b_i, tab[sel[st_i, b_i]], tab.min())
         assert len(diff) <= sel.size // 8
+        # against the arbiter: the HIP path disagrees with the float64 run about as often as the float32 oracle does (near-ties flip
+        # either way), every such choice is a near-tie in the ARBITER's own table too, and on the samples where all three agree the
+        # HIP path is not further from the float64 trajectory than 1.5 x the float32 oracle's distance
+        d64 = np.argwhere(sel != sel_f64)
+        print(f"[parity] 4x301 [{name}]: selection differs from float64 at {len(d64)} pairs (oracle32: {int((sel_ref != sel_f64).sum())})")
+        for st_i, b_i in d64:
+            tab = arb.select_table[st_i][:, b_i]
+            assert tab[sel[st_i, b_i]] <= tab.min() + max(1e-2 * tab.min(), 2e-4), (name, "f64", st_i, b_i, tab[sel[st_i, b_i]], tab.min())
+        assert len(d64) <= max((sel_ref != sel_f64).sum() + 2, sel.size // 8)
+        same3 = np.all(sel == sel_ref, axis=0) & np.all(sel == sel_f64, axis=0)
+        if same3.any():
+            _arbiter_distances(f"4x301 [{name}] arbiter", g, r, a, same3)
         # element by element only where every stage picked the oracle's snapshot (another snapshot = parameters ten optimizer steps
         # apart: measured 7e-4 m on a joint): 3e-4 after 1204 Adam steps (see test_opt_headline_workload_matches_oracle); the
         # metrics north_star names over ALL samples at its 1e-4
