@@ -27,6 +27,13 @@ import numpy as np
 import torch
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 vector == FP32 (f32-input) MFMA dense peak
+# Shader cycles one wave64 vector instruction occupies its SIMD's issue port, calibrated (round 5; scripts/microbench_issue,
+# profiles/r5_issue_rates.txt, four waves per SIMD): v_fma / v_mul / v_add_f32 and v_add_u32 2.4-2.5, shifts / 3-operand logic / packed
+# fp32 4.2, compare + select 3.1, rcp / sqrt 8.2; weighted with the static instruction mix of the three large kernels
+# (scripts/isa_mix.py: 2.84 / 3.17 / 3.1-3.2) = 3.0.  Round 4 priced every vector instruction at 4 (a 16-lane SIMD): its issue_slots
+# fractions were a third too high.  A LONE wave issues one vector instruction per ~5 cycles: a SIMD needs two or more waves that are
+# not waiting to reach this rate.
+VALU_ISSUE_CYCLES = 3.0
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 
 
@@ -306,11 +313,12 @@ def kernel_rooflines(args, B, plan, instance, inputs, hip):
             n_inst = float(sq[0]["SQ_INSTS_VALU_per_launch"]) if sq and sq[0].get("SQ_INSTS_VALU_per_launch") else None
         issue = None
         if n_inst and main_ms:
-            # vector-ALU ISSUE slots: SQ_INSTS_VALU x 4 cycles (a wave64 instruction holds its 16-lane SIMD for four cycles) /
-            # (1024 SIMDs x the cycles of this run's launch at the 2.4 GHz peak clock): how busy the vector pipes are with
-            # instructions of ANY kind (a lower bound: the sustained clock is below the peak clock)
-            issue = dict(valu_wave_instructions_per_launch=n_inst, simds=1024, cycles_per_wave_instruction=4, clock_ghz=2.4,
-                         frac=n_inst * 4.0 / (1024.0 * main_ms * 1e-3 * 2.4e9))
+            # vector-ALU ISSUE slots: SQ_INSTS_VALU x the calibrated cycles per wave64 instruction of this instruction mix
+            # (VALU_ISSUE_CYCLES above) / (1024 SIMDs x the cycles of this run's launch at the 2.4 GHz peak clock): how busy the vector
+            # pipes are with instructions of ANY kind (a lower bound: the sustained clock is below the peak clock)
+            issue = dict(valu_wave_instructions_per_launch=n_inst, simds=1024, cycles_per_wave_instruction=VALU_ISSUE_CYCLES, clock_ghz=2.4,
+                         calibration="profiles/r5_issue_rates.txt (scripts/microbench_issue) x the kernels' static instruction mix (scripts/isa_mix.py)",
+                         frac=n_inst * VALU_ISSUE_CYCLES / (1024.0 * main_ms * 1e-3 * 2.4e9))
         ctr_bw = traffic / (main_ms * 1e-3) / 1e9 if (traffic and main_ms) else None
         main_bytes = next((p["algorithmic_bytes_per_launch"] for p in pk["by_launch_size"] if p["batches_per_launch"] == g_main), None)
         kernels.append(dict(
