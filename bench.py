@@ -426,6 +426,28 @@ def encoder_traffic():
     return sum(float(r["hbm_bytes_per_launch"]) * int(r["launches"]) for r in rows) / fwd, "profiles/" + os.path.basename(prefix) + "_pmc_traffic.csv"
 
 
+def encoder_mfma_busy():
+    """MFMA-busy share of every convolution kernel AND launch shape (= groups of layers) of one encoder forward, from the committed SQ
+    counter profile of `bench.py --config baseline` of the loaded library: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / 32 (the profile's
+    `mfma_busy_frac` column / 32, the normalisation of DESIGN.md section 9), with the launches per forward and the kernel-trace
+    duration; longest groups first.  [] without such a profile."""
+    prefix, meta = committed_profile(None, "baseline")
+    if prefix is None:
+        return []
+    sq = profile_rows(prefix, "pmc_sq", "conv_")
+    kt = {(r["kernel"], r["workgroups"]): r for r in profile_rows(prefix, "kernel_stats", "conv_")}
+    stem = [r for r in sq if r["kernel"].startswith("conv_igemm_kernel") and r["kernel"].rstrip().endswith(", 2>")]
+    fwd = sum(int(r["launches"]) for r in stem) or 1
+    out = []
+    for r in sq:
+        if not r.get("mfma_busy_frac"):
+            continue
+        k = kt.get((r["kernel"], r["workgroups"]))
+        out.append(dict(kernel=r["kernel"], workgroups=int(r["workgroups"]), launches_per_forward=int(r["launches"]) / fwd,
+                        mfma_busy=float(r["mfma_busy_frac"]) / 32.0, avg_us=float(k["avg_us"]) if k else None))
+    return sorted(out, key=lambda d: -(d["avg_us"] or 0) * d["launches_per_forward"])
+
+
 def secondary(config, with_cpu=True):
     """BASELINE.json configs[1] / configs[2] (parity-test cases, NOT the driver's metric): IHMR-Baseline batch 64 and
     IHMR-MLP batch 128 inference on one MI355X with the CPU oracle timed beside them on a bounded sample (BASELINE.md
@@ -508,6 +530,7 @@ def secondary(config, with_cpu=True):
                                             "in the first milliseconds of a burst to 2.33-2.34 GHz in a sustained run (this figure: 45 passes back to back)",
                                  peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=8.2e9 * B / enc_dt / 1e12 / FP32_PEAK_TFLOPS,
                                  traffic=enc_traffic, traffic_unit="bytes per encoder forward (64 images)", traffic_source=enc_traffic_src,
+                                 mfma_busy_by_layer_group=encoder_mfma_busy(),
                                  hbm=dict(achieved=(enc_traffic / enc_dt / 1e9) if enc_traffic else None, peak=HBM_PEAK_GBS, unit="GB/s",
                                           frac=(enc_traffic / enc_dt / 1e9 / HBM_PEAK_GBS) if enc_traffic else None,
                                           note="counter bytes of the profile / this run's encoder time"),

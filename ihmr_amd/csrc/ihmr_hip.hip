@@ -333,8 +333,12 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
         dist_blocks = SDF_DIST_WG_PER_CU * (cus > 0 ? cus : 256);
     }
     if (timed) { if (int rc = timed_next(&tcur, IHMR_TIMED_SDF_PREP, st)) return rc; }
-    if (g_collect_stats) hipLaunchKernelGGL(sdf_dist_kernel<true>, dim3(dist_blocks), dim3(SDF_THREADS), 0, st, ws);
-    else hipLaunchKernelGGL(sdf_dist_kernel<false>, dim3(dist_blocks), dim3(SDF_THREADS), 0, st, ws);
+    int nblk = dist_blocks;
+#ifdef IHMR_TUNING_BUILD
+    if (const char* e = getenv("IHMR_DIST_BLOCKS_PER_SAMPLE")) nblk = std::max(64, std::min(dist_blocks, atoi(e) * B));
+#endif
+    if (g_collect_stats) hipLaunchKernelGGL(sdf_dist_kernel<true>, dim3(nblk), dim3(SDF_THREADS), 0, st, ws);
+    else hipLaunchKernelGGL(sdf_dist_kernel<false>, dim3(nblk), dim3(SDF_THREADS), 0, st, ws);
     // (the launch the refinement really runs is the one that is timed: a second launch would find the work cursor spent)
     if (timed) { if (int rc = timed_next(&tcur, IHMR_TIMED_SDF_DIST, st)) return rc; (void)hipEventDestroy(tcur); }
     if (loss)

@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: prediction-file schema, refinement-batch construction, strategy plumbing."""
 import os
+import sys
 import types
 import numpy as np
 import torch
@@ -238,6 +239,26 @@ def test_bench_finds_the_encoder_traffic_in_the_committed_profile(monkeypatch):
     monkeypatch.setattr(hip, "loaded_source_hash", lambda: good)
     traffic, src = bench.encoder_traffic()
     assert src and src.startswith("profiles/") and 2e9 < traffic < 3e10, (traffic, src)
+
+
+def test_profiles_readme_table_is_generated_from_the_committed_csv_files():
+    """profiles/README.md quotes per-kernel durations, instruction counts and HBM bytes of the round's final profile series; round 4's
+    table had drifted from its csv files.  The rows of the current series are generated (scripts/profiles_table.py) and must stand in
+    the README verbatim."""
+    import json as _json
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import profiles_table
+    from ihmr_amd import hip
+    cur = hip._source_hash()
+    prof = os.path.join(ROOT, "profiles")
+    series = sorted({f[:-len("_f7_meta.json")] for f in os.listdir(prof) if f.endswith("_f7_meta.json")
+                     and _json.load(open(os.path.join(prof, f)))["srchash"] == cur})
+    assert series, "no profile series of the committed sources"
+    readme = open(os.path.join(prof, "README.md")).read()
+    rows = profiles_table.table(series[-1])
+    assert len(rows) >= 2
+    for r in rows:
+        assert r in readme, r[:160]
 
 
 def test_committed_profile_carries_what_the_bench_line_quotes():
