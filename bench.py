@@ -737,7 +737,8 @@ def main():
         o.fuse_batches = fuse
         return OptimizeModel(o)
 
-    streams = [torch.cuda.Stream() for _ in range(S)]
+    _prio = [int(x) for x in os.environ.get("IHMR_STREAM_PRIORITIES", "").split(",") if x.strip()]      # (experiment knob: per-stream priorities)
+    streams = [torch.cuda.Stream(priority=_prio[i % len(_prio)]) if _prio else torch.cuda.Stream() for i in range(S)]
     model = make_model(1)                        # single-batch instance: latency figures, size-1 jobs of stream 0
     pool = {(0, 1): model}                       # (stream, batches per launch sequence) -> instance, built on demand
     fwd = lambda p, s, t: two_hand.forward_from_packed(model.mano_models["right"], p.cuda(), s.cuda(), t.cuda())[2]
