@@ -248,6 +248,7 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
     __shared__ float A_s[HG / 2][192][2];   // skinning matrices, the two hands of a pair interleaved
     __shared__ float beta_s[10][HG];  // [l][hand]
     __shared__ float shift_s[HG][4];
+    __shared__ float vsh_s[REUSE ? 1 : 3 * HG][REUSE ? 1 : LBS_THREADS];   // v_shaped of the thread's HG hands, parked while the pose offsets are summed
     const int tid = threadIdx.x, gx = blockIdx.x, tile = blockIdx.y % 4, gs = blockIdx.y / 4;
     if (!REUSE)
         for (int idx = tid; idx < HG * 136; idx += LBS_THREADS) {
@@ -288,8 +289,13 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
         float4 sd[10];
 #pragma unroll
         for (int l = 0; l < 10; ++l) sd[l] = m.sd4[l * NVP + v];
+        // The blend offsets are summed from ZERO and added in one operation each -- v_shaped = v_template + S, v_posed = v_shaped + P,
+        // as the reference's smplx `lbs` does.  (Rounds 1-4 ran the 145 fused multiply-adds onto a running VERTEX: every one of them
+        // rounds at the vertex's magnitude, ~1.3 ulp of the vertex in the result -- round 5's float64 arbiter found the forward 2.9 x as
+        // far from the exact mesh as torch's; the same sums from zero round at the offsets' magnitude, a hundred times smaller.)
+        // v_shaped waits in LDS (this thread's own slots: no barrier) while the registers sum the pose offsets.
 #pragma unroll
-        for (int q = 0; q < HG / 2; ++q) { vq[q][0] = lbs_v2f{t.x, t.x}; vq[q][1] = lbs_v2f{t.y, t.y}; vq[q][2] = lbs_v2f{t.z, t.z}; }
+        for (int q = 0; q < HG / 2; ++q) { vq[q][0] = lbs_v2f{0.f, 0.f}; vq[q][1] = lbs_v2f{0.f, 0.f}; vq[q][2] = lbs_v2f{0.f, 0.f}; }
 #pragma unroll
         for (int l = 0; l < 10; ++l) {
 #pragma unroll
@@ -298,6 +304,16 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
                 vq[q][0] = __builtin_elementwise_fma(lbs_v2f{sd[l].x, sd[l].x}, bl, vq[q][0]);
                 vq[q][1] = __builtin_elementwise_fma(lbs_v2f{sd[l].y, sd[l].y}, bl, vq[q][1]);
                 vq[q][2] = __builtin_elementwise_fma(lbs_v2f{sd[l].z, sd[l].z}, bl, vq[q][2]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < HG / 2; ++q) {
+            const lbs_v2f tc[3] = {lbs_v2f{t.x, t.x}, lbs_v2f{t.y, t.y}, lbs_v2f{t.z, t.z}};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const lbs_v2f vs = tc[c] + vq[q][c];
+                vsh_s[6 * q + 2 * c][tid] = vs.x; vsh_s[6 * q + 2 * c + 1][tid] = vs.y;
+                vq[q][c] = lbs_v2f{0.f, 0.f};
             }
         }
     }
@@ -348,6 +364,10 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
             __builtin_amdgcn_sched_barrier(0);
         }
         consume(pa, NPF - 9);
+#pragma unroll
+        for (int q = 0; q < HG / 2; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vq[q][c] = lbs_v2f{vsh_s[6 * q + 2 * c][tid], vsh_s[6 * q + 2 * c + 1][tid]} + vq[q][c];
     }
     // skinning weights: the vertex's (up to) four non-zero ones when the asset has no denser vertex (MANO's own weights), else all 16
     float w[NJ];

@@ -323,12 +323,11 @@ def _f64_arbiter(mano_arrays, B, epoch, freq, batch):
     return arb.get_pred_result(), np.stack(arb.selected), arb
 
 
-def _arbiter_distances(tag, g, r, a, same, max_ratio=None):
+def _arbiter_distances(tag, g, r, a, same, max_ratio=None, worst_ratio=None):
     """|hip - f64| and |oracle32 - f64| per key over the samples `same` (every stage picked the same snapshot in all three runs): mean,
-    99.9th percentile and maximum of both, printed side by side.  Asserted: BOTH float32 implementations lie within north_star's
-    1e-4 of the float64 trajectory on at least 99.9 % of the elements and within 3e-4 everywhere (the bar the HIP-vs-oracle32
-    comparison uses, now against the arbiter); `max_ratio`: the HIP path's MEAN distance from the float64 trajectory at most that many
-    times the float32 oracle's (+ 1e-7 m)."""
+    99.9th percentile and maximum of both, printed side by side.  Asserted: the HIP path lies within north_star's 1e-4 of the float64
+    trajectory everywhere; `worst_ratio`: max |hip - f64| <= worst_ratio x max |oracle32 - f64| + 2e-6 m per key (the
+    round-4 review's criterion: 1.5); `max_ratio`: the same for the MEAN distances (+ 1e-7 m)."""
     out = {}
     for name, key in ARBITER_KEYS:
         e_hip = np.abs(g[key][same].astype(np.float64) - a[key][same]).ravel()
@@ -340,8 +339,9 @@ def _arbiter_distances(tag, g, r, a, same, max_ratio=None):
               f"(ratios {out[name][0][0] / max(out[name][1][0], 1e-30):.2f} / {out[name][0][1] / max(out[name][1][1], 1e-30):.2f} / "
               f"{out[name][0][2] / max(out[name][1][2], 1e-30):.2f})")
     for name, (h, o) in out.items():
-        for who, (mean, p999, mx) in (("hip", h), ("oracle32", o)):
-            assert p999 <= 1e-4 and mx <= 3e-4, (tag, name, who, mean, p999, mx)
+        assert h[2] <= 1e-4, (tag, name, "hip", h)          # (the float32 oracle's own distance is printed, not asserted: it is the checker)
+        if worst_ratio is not None:
+            assert h[2] <= worst_ratio * o[2] + 2e-6, (tag, name, "max distance from the float64 trajectory", h[2], o[2])
         if max_ratio is not None:
             assert h[0] <= max_ratio * o[0] + 1e-7, (tag, name, "mean distance from the float64 trajectory", h[0], o[0])
     return out
@@ -791,10 +791,9 @@ def _batch64_trajectory(mano_arrays, fingers):
 def test_opt_headline_workload_matches_oracle(mano_arrays):
     """BASELINE.json's metric config itself -- IHMR-OPT, batch 64, opt_default at epoch 49 = 4 x 50 = 200 refinement iterations,
     snapshot every 10 (what bench.py times) -- against the oracle (minutes of CPU time): selection indices identical; the metrics
-    north_star names (MPJPE, mean per-vertex distance, mean penetration depth) within 1e-4; element by element within 3e-4 with
-    at least 99.9 % of the elements within 1e-4 (see the comment at the assertion).  Round 5: a float64 ARBITER -- the same loop in
-    double precision -- says how far each float32 implementation is from the exact trajectory: both within 1e-4 at the 99.9th
-    percentile (3e-4 everywhere); the HIP path 2.2-2.8 x as far as torch's float32 on average (see the comment at the call)."""
+    north_star names (MPJPE, mean per-vertex distance, mean penetration depth) within 1e-4, and every element within 1e-4 (round 5;
+    3e-4 before).  A float64 ARBITER -- the same loop in double precision -- says how far each float32 implementation is from the
+    exact trajectory: the HIP path at most 1.5 x as far as torch's float32 per key (measured: 0.03-0.5 x)."""
     B, epoch, freq = 64, 49, 10
     orc, model, batch = _oracle_and_model(mano_arrays, B, epoch, freq, seed=1234, record=False)
     torch.set_num_threads(max(1, min(32, (__import__("os").cpu_count() or 8))))
@@ -805,10 +804,10 @@ def test_opt_headline_workload_matches_oracle(mano_arrays):
     sel_ref, sel_got = np.stack(orc.selected), torch.stack(model.selected_history).cpu().numpy()
     print(f"[parity] headline: selection agreement {float((sel_ref == sel_got).mean()):.4f}")
     assert np.array_equal(sel_ref, sel_got)
-    # north_star's bar is on the METRICS (MPJPE / MPVPE / penetration depth within 1e-4): asserted at 1e-4 below.  Element by
-    # element, 200 Adam steps amplify summation-order rounding (the update m / sqrt(v) is scale-free, so a gradient component at
-    # round-off level moves its parameter by +-lr whichever way it rounds): measured worst vertex 1.2e-4 m (one vertex of one
-    # sample in 64 x 1556), worst joint 9.2e-5 m.  Per element: 3e-4, and at least 99.9 % of the elements within 1e-4.
+    # north_star's bar (MPJPE / MPVPE / penetration depth within 1e-4) holds ELEMENT BY ELEMENT since round 5: 200 Adam steps amplify
+    # summation-order rounding (the update m / sqrt(v) is scale-free), and rounds 1-4 measured a worst vertex of 1.2e-4 m against the
+    # float32 oracle (bar: 3e-4 with 99.9 % within 1e-4); with the skinning kernel's blend offsets summed from zero the worst vertex is
+    # 3.6e-5 m, the worst joint 2.9e-5 m -- most of which is the float32 ORACLE's own distance from the exact trajectory (arbiter below).
     worst = {}
     for name, key in (("joints", "pred_joints_3d"), ("right verts", "pred_right_hand_verts"), ("left verts", "pred_left_hand_verts"),
                       ("penetration depth", "collision_loss_origin_scale")):
@@ -816,7 +815,7 @@ def test_opt_headline_workload_matches_oracle(mano_arrays):
         worst[name] = float(e.max())
         frac = float((e <= 1e-4).mean())
         print(f"[parity] headline {name} [m]: max|err|={e.max():.3e}, within 1e-4: {100 * frac:.4f} %")
-        assert e.max() <= 3e-4 and frac >= 0.999, name
+        assert e.max() <= 1e-4, name
     mp_ref, mp_got = float(r["collision_loss_origin_scale"].mean()), float(g["collision_loss_origin_scale"].mean())
     mpjpe = lambda x: float(np.linalg.norm(x["pred_joints_3d"] - x["gt_joints_3d"][..., :3], axis=-1).mean())
     mpvpe = float(np.mean([np.linalg.norm(g[k] - r[k], axis=-1).mean() for k in ("pred_right_hand_verts", "pred_left_hand_verts")]))
@@ -829,12 +828,13 @@ def test_opt_headline_workload_matches_oracle(mano_arrays):
     print(f"[parity] headline arbiter: selections of all three runs agree on {int(same.sum())} of {B} samples "
           f"(hip vs f64 differ at {int((sel_got != sel_f64).sum())}, oracle32 vs f64 at {int((sel_ref != sel_f64).sum())} of {sel_f64.size} (stage, sample) pairs)")
     assert same.sum() >= B - 4 and (sel_got != sel_f64).sum() <= (sel_ref != sel_f64).sum() + 2
-    # measured (round 5): the HIP path's mean distance from the float64 trajectory is 2.2-2.8 x the float32 oracle's on joints and
-    # vertices (4.2e-7 against 1.7e-7 m on the joints), its 99.9th percentile 4.4e-5 against 1.8e-5 m, its maximum 1.2e-4 against
-    # 3.7e-5 m: torch's float32 reductions (pairwise, blocked) lose less than the kernels' lane-sequential sums before Adam's
-    # scale-free update amplifies both.  NOT within the 1.5 x the round-4 review hoped for; asserted: both runs within 1e-4 of the
-    # float64 trajectory at the 99.9th percentile and 3e-4 everywhere, the HIP mean at most 4 x the oracle's
-    _arbiter_distances("headline arbiter", g, r, a, same, max_ratio=4.0)
+    # Round 5 history: the first arbiter run found the HIP path 2.2-2.8 x (mean) and up to 6 x (99.9th percentile) as far from the float64
+    # trajectory as torch's float32 (worst vertex 1.17e-4 m) -- the skinning kernel ran its 145 blend-shape FMAs onto a running VERTEX,
+    # rounding at the vertex's magnitude each time (scripts/experiments/gradient_error_vs_f64.py: forward 2.9 x torch's error).  With the
+    # offsets summed from zero (csrc/mano_lbs.h) the HIP path is CLOSER to the float64 trajectory than the float32 oracle: joints 2.9e-6
+    # against 3.0e-5 m, left vertices 1.1e-6 against 3.7e-5 m at the worst element.  Asserted: the review's criterion (max distance
+    # <= 1.5 x the oracle's, per key) and the same for the means
+    _arbiter_distances("headline arbiter", g, r, a, same, max_ratio=1.5, worst_ratio=1.5)
     assert abs(float(a["collision_loss_origin_scale"].mean()) - mp_got) < 1e-4 and abs(mpjpe(a) - mpjpe(g)) < 1e-4
 
 
@@ -890,16 +890,16 @@ def test_opt_reference_default_schedule_matches_oracle(mano_arrays):
         assert len(d64) <= max((sel_ref != sel_f64).sum() + 2, sel.size // 8)
         same3 = np.all(sel == sel_ref, axis=0) & np.all(sel == sel_f64, axis=0)
         if same3.any():
-            _arbiter_distances(f"4x301 [{name}] arbiter", g, r, a, same3, max_ratio=6.0)
+            _arbiter_distances(f"4x301 [{name}] arbiter", g, r, a, same3, max_ratio=4.0, worst_ratio=2.0)
         # element by element only where every stage picked the oracle's snapshot (another snapshot = parameters ten optimizer steps
         # apart: measured 7e-4 m on a joint): 3e-4 after 1204 Adam steps (see test_opt_headline_workload_matches_oracle); the
         # metrics north_star names over ALL samples at its 1e-4
         same = np.all(sel == sel_ref, axis=0)
         assert same.sum() >= B - len(diff)
-        _report(f"4x301 [{name}] joints [m]", g["pred_joints_3d"][same], r["pred_joints_3d"][same], atol=3e-4)
-        _report(f"4x301 [{name}] right verts [m]", g["pred_right_hand_verts"][same], r["pred_right_hand_verts"][same], atol=3e-4)
-        _report(f"4x301 [{name}] left verts [m]", g["pred_left_hand_verts"][same], r["pred_left_hand_verts"][same], atol=3e-4)
-        _report(f"4x301 [{name}] penetration depth [m]", g["collision_loss_origin_scale"][same], r["collision_loss_origin_scale"][same], atol=3e-4)
+        _report(f"4x301 [{name}] joints [m]", g["pred_joints_3d"][same], r["pred_joints_3d"][same], atol=1e-4)
+        _report(f"4x301 [{name}] right verts [m]", g["pred_right_hand_verts"][same], r["pred_right_hand_verts"][same], atol=1e-4)
+        _report(f"4x301 [{name}] left verts [m]", g["pred_left_hand_verts"][same], r["pred_left_hand_verts"][same], atol=1e-4)
+        _report(f"4x301 [{name}] penetration depth [m]", g["collision_loss_origin_scale"][same], r["collision_loss_origin_scale"][same], atol=1e-4)
         mpjpe = lambda x: float(np.linalg.norm(x["pred_joints_3d"] - x["gt_joints_3d"][..., :3], axis=-1).mean())
         mpv = float(np.mean([np.linalg.norm(g[k] - r[k], axis=-1).mean() for k in ("pred_right_hand_verts", "pred_left_hand_verts")]))
         pen = abs(float(g["collision_loss_origin_scale"].mean()) - float(r["collision_loss_origin_scale"].mean()))
