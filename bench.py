@@ -46,7 +46,7 @@ def make_opt(B, epoch, freq, rank, asset="mitten"):
                                  save_mid_freq=freq, optimizer="adam", opt_epoch=epoch)
 
 
-def geometry_report(asset, B, epoch, freq, steps=12, fuse=6):
+def geometry_report(asset, B, epoch, freq, steps=24, fuse=6):
     """Throughput and collision-work statistics of the refinement on one synthetic asset, measured the same way for every asset
     (two launch sequences of `fuse` batches on two streams, `steps` batches in all; NOT the headline's schedule): images/s, inside
     voxels per sample and iteration, share of inside voxels searched in full, voxels refused a candidate list (list overflow: more
@@ -170,6 +170,12 @@ def cpu_baseline(batch_cpu, epoch_full, freq, n_samples=32, iters_per_stage=8):
         if not short:
             oracle_out = dict(result=orc.get_pred_result(), selected=[np.asarray(x).copy() for x in orc.selected], n_samples=n_samples,
                               iters_per_stage=iters_per_stage)
+            # the float64 ARBITER of the same sample (untimed, not part of the baseline): the same loop in double precision -- how far is
+            # each float32 implementation from the exact trajectory?  (parity.vs_f64)
+            arb = OptimizeRef(synthetic_mano(True), synthetic_mano(False), n_samples, strat, save_mid_freq=1, dtype=torch.float64)
+            arb.set_input(sub); arb.init_optimize(); arb.optimize()
+            oracle_out["result_f64"] = arb.get_pred_result()
+            oracle_out["selected_f64"] = [np.asarray(x).copy() for x in arb.selected]
         runs[threads] = dict(seconds=t_total, forward_backward_evaluations=evals, images_per_s=n_samples / (t_total / evals * full_iters),
                              ms_per_refine_iter=1000.0 * t_total / evals)
     best = max(runs, key=lambda k: runs[k]["images_per_s"])
@@ -203,7 +209,19 @@ def parity_vs_oracle(batch_cpu, oracle_out, rank):
     pen_h, pen_o = float(np.mean(got["collision_loss_origin_scale"])), float(np.mean(ref["collision_loss_origin_scale"]))
     # MPJPE of both sides against the synthetic annotation, the reference's metric (root-aligned joints are what both export)
     mp = lambda r: float(np.mean(np.linalg.norm(r["pred_joints_3d"] - r["gt_joints_3d"][..., :3], axis=-1)))
+    vs_f64 = None
+    if "result_f64" in oracle_out:
+        a = oracle_out["result_f64"]
+        same = np.all(np.stack(sel) == np.stack(oracle_out["selected_f64"]), axis=0) & np.all(np.stack(sel) == np.stack(oracle_out["selected"]), axis=0)
+        dist = lambda x, k: np.abs(x[k][same].astype(np.float64) - a[k][same])
+        vs_f64 = dict(note="float64 arbiter: the oracle's loop in double precision on the same sample; distances over the samples whose "
+                           "selections agree in all three runs", samples_compared=int(same.sum()))
+        for name, k in (("joints", "pred_joints_3d"), ("right_verts", "pred_right_hand_verts"), ("left_verts", "pred_left_hand_verts"),
+                        ("pen_depth", "collision_loss_origin_scale")):
+            dh, do = dist(got, k), dist(ref, k)
+            vs_f64[name] = dict(hip_max_m=float(dh.max()), hip_mean_m=float(dh.mean()), oracle32_max_m=float(do.max()), oracle32_mean_m=float(do.mean()))
     return dict(sample=f"{n} samples x {4 * it} refine iterations (+ final forward), snapshot every iteration: the cpu_baseline sample",
+                vs_f64=vs_f64,
                 max_abs_joint_m=err("pred_joints_3d"), max_abs_vertex_m=verts, max_abs_pen_depth_m=err("collision_loss_origin_scale"),
                 selection_agreement=agree, mean_penetration_depth_m=dict(hip=pen_h, oracle=pen_o, abs_diff=abs(pen_h - pen_o)),
                 mpjpe_m=dict(hip=mp(got), oracle=mp(ref), abs_diff=abs(mp(got) - mp(ref))), tolerance_m=1e-4,
