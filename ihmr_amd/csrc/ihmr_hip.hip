@@ -223,22 +223,34 @@ extern "C" size_t ihmr_mano_workspace_bytes(int N) { return lbs_ws_bytes(N); }
 
 // the skinning launch (REUSE: the workspace holds v_posed of the current pose and shape parameters, see lbs_skin_kernel)
 // small launches: four instead of eight hands per skin workgroup (half the chain per thread)
-template <bool TWO_HAND, bool REUSE>
-static void lbs_skin_launch_mode(const ihmr_mano* m, int N, int B, float* verts, float* joints, const LbsWork& wk, hipStream_t st) {
+template <bool TWO_HAND, int MODE>
+static void lbs_skin_launch_mode(const ihmr_mano* m, int N, int B, float* verts, float* joints, const LbsWork& wk, float* pose_off, hipStream_t st) {
     const bool small = N <= LBS_SMALL_MAX_HANDS;
     const int hg8 = 8 * (small ? LBS_HG_SMALL : LBS_HG);
     const dim3 skin_grid(8, 4 * ((N + hg8 - 1) / hg8));
-    if (small) hipLaunchKernelGGL((lbs_skin_kernel<TWO_HAND, REUSE, LBS_HG_SMALL>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B,
-                                  verts, joints, wk.v_posed);
-    else hipLaunchKernelGGL((lbs_skin_kernel<TWO_HAND, REUSE, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
-                            joints, wk.v_posed);
+    if (small) hipLaunchKernelGGL((lbs_skin_kernel<TWO_HAND, MODE, LBS_HG_SMALL>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B,
+                                  verts, joints, wk.v_posed, pose_off);
+    else hipLaunchKernelGGL((lbs_skin_kernel<TWO_HAND, MODE, LBS_HG>), skin_grid, dim3(LBS_THREADS), 0, st, *m, (const float*)wk.skel, N, B, verts,
+                            joints, wk.v_posed, pose_off);
 }
+// skin modes of the callers: FULL (both blends), REUSE (v_posed kept: lbs_skin_kernel), FULL_STORE_P (both blends + the pose offsets P stored:
+// the first iteration of a stage that moves the shape but not the finger pose), KEEP_P (the later iterations of such a stage: no pose rows read)
 #define LBS_SKIN_FULL 0
 #define LBS_SKIN_REUSE 1
+#define LBS_SKIN_KEEP_P 2
+#define LBS_SKIN_FULL_STORE_P 3
+static int g_force_full_skin = 0;    // checker switch: ihmr_debug_force_full_skin
 template <bool TWO_HAND>
 static void lbs_skin_launch(const ihmr_mano* m, int mode, int N, int B, float* verts, float* joints, const LbsWork& wk, hipStream_t st) {
-    if (mode == LBS_SKIN_REUSE) lbs_skin_launch_mode<TWO_HAND, true>(m, N, B, verts, joints, wk, st);
-    else lbs_skin_launch_mode<TWO_HAND, false>(m, N, B, verts, joints, wk, st);
+    if (g_force_full_skin && (mode == LBS_SKIN_KEEP_P || mode == LBS_SKIN_FULL_STORE_P)) mode = LBS_SKIN_FULL;
+    if (mode == LBS_SKIN_REUSE) lbs_skin_launch_mode<TWO_HAND, LBS_MODE_REUSE>(m, N, B, verts, joints, wk, nullptr, st);
+    else if (mode == LBS_SKIN_KEEP_P) lbs_skin_launch_mode<TWO_HAND, LBS_MODE_KEEP_P>(m, N, B, verts, joints, wk, wk.pose_off, st);
+    else lbs_skin_launch_mode<TWO_HAND, LBS_MODE_FULL>(m, N, B, verts, joints, wk, mode == LBS_SKIN_FULL_STORE_P ? wk.pose_off : nullptr, st);
+}
+extern "C" int ihmr_debug_force_full_skin(int force) {
+    const int prev = g_force_full_skin;
+    g_force_full_skin = force ? 1 : 0;
+    return prev;
 }
 
 static void lbs_forward_launch(const ihmr_mano* m, bool two_hand, const float* orient, const float* pose, const float* betas,
@@ -475,7 +487,11 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     ParamStep step{0, 0.f, 0.f, 1.f, -1, 1, 0};   // iteration 0: no step yet, zero the optimizer state
     // a stage that moves neither the finger pose nor the shape keeps v_posed: computed in its first iteration, reused after
     const bool vposed_fixed = (pm & (IHMR_PB_POSE_R | IHMR_PB_POSE_L | IHMR_PB_SHAPE_R | IHMR_PB_SHAPE_L)) == 0;
-    const int keep_mode = vposed_fixed ? LBS_SKIN_REUSE : LBS_SKIN_FULL;
+    // ... and a stage that moves the shape but not the finger pose keeps the pose offsets P: stored by its first iteration's skinning, reused
+    // after (lbs_skin_kernel MODE KEEP_P: the 1.8 MB pose basis is not read again; the same bits, test_skin_keeps_pose_offsets_bit_identically)
+    const bool pose_fixed = (pm & (IHMR_PB_POSE_R | IHMR_PB_POSE_L)) == 0;
+    const int keep_mode = vposed_fixed ? LBS_SKIN_REUSE : (pose_fixed ? LBS_SKIN_KEEP_P : LBS_SKIN_FULL);
+    const int first_mode = (!vposed_fixed && pose_fixed) ? LBS_SKIN_FULL_STORE_P : LBS_SKIN_FULL;
     // The tail of an iteration -- sampling + losses, LBS backward of both hands, and in the stages that do not move the finger pose also the
     // optimizer step + next skeletons -- is ONE launch per sample (opt_tail_kernel): 4 launches per iteration instead of 6 (finger-pose
     // stage, whose backward continues with a batch-wide GEMM: 7 instead of 8); in a stage that keeps v_posed the same launch also skins
@@ -499,7 +515,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
             // head (optimizer step of the previous iteration + skeletons): stand-alone in the first iteration (zero the optimizer state,
             // first skeletons) and in the finger-pose stage; otherwise the tail of iteration it - 1 has done it
             // ... and in a stage that keeps v_posed (translation, orientation) the tail has skinned the next vertices as well: 3 launches
-            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? LBS_SKIN_FULL : (vposed_fixed ? -1 : keep_mode), it == 0 ? 2 : 1,
+            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? first_mode : (vposed_fixed ? -1 : keep_mode), it == 0 ? 2 : 1,
                                  /*head=*/it == 0 || pose_stage, /*tail=*/false, static_mask);
             if (rc) return rc;
             SdfWorkspace ws = opt_sdf_ws(io, wk, B, it == 0 ? 2 : 1, static_mask);
@@ -521,7 +537,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
                 lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
                                     wk.lbs, st, /*bwd1_done=*/true);
         } else {
-            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? LBS_SKIN_FULL : keep_mode, it == 0 ? 2 : 1, true, true, static_mask);   // applies the step of iteration it - 1 first
+            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? first_mode : keep_mode, it == 0 ? 2 : 1, true, true, static_mask);   // applies the step of iteration it - 1 first
             if (rc) return rc;
             if (need_mask)
                 lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,

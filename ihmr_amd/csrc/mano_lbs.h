@@ -49,11 +49,12 @@ struct LbsWork {       // carved from the caller's workspace
     float* dvp;        // [N][2334]
     float* chain;      // [N][192]: dR [16][9] from the chain, dJ [16][3]
     float* dpf_part;   // [LBS_KG][N][136]
+    float* pose_off;   // [N][2334] the pose-blend offsets P of the hands' current finger poses (round 5; see lbs_skin_kernel MODE 2)
 };
 
 static inline size_t lbs_ws_bytes(int N) {
-    size_t n = (size_t)N * (SK_STRIDE + 2 * NV3 + 192 + LBS_KG * 136) * sizeof(float);
-    return ((n + 255) & ~(size_t)255) + 5 * 256;
+    size_t n = (size_t)N * (SK_STRIDE + 3 * NV3 + 192 + LBS_KG * 136) * sizeof(float);
+    return ((n + 255) & ~(size_t)255) + 6 * 256;
 }
 
 static inline LbsWork lbs_carve(void* ws, int N) {
@@ -65,6 +66,7 @@ static inline LbsWork lbs_carve(void* ws, int N) {
     w.dvp = take((size_t)N * NV3 * 4);
     w.chain = take((size_t)N * 192 * 4);
     w.dpf_part = take((size_t)LBS_KG * N * 136 * 4);
+    w.pose_off = take((size_t)N * NV3 * 4);
     return w;
 }
 
@@ -239,18 +241,26 @@ __device__ __forceinline__ int lbs_group_hand(int x, int s, int i) { return x + 
 // neither -- translation, global orientation: optimize_model.py:393-407 -- after its first iteration): both blends are
 // skipped and the stored values (the bits a recomputation would give) are skinned with the new joint transforms.  The two
 // blends are 2/3 of the kernel's arithmetic and all of its L2 traffic (1.8 MB of basis rows per 8 hands and vertex tile).
-template <bool TWO_HAND, bool REUSE = false, int HG = LBS_HG>
+// MODE (round 5): LBS_MODE_FULL both blends (pose_off_ws != nullptr: the pose offsets P are stored as well); LBS_MODE_REUSE as above;
+// LBS_MODE_KEEP_P: pose_off_ws holds P of exactly these finger poses (a stage that moves the shape but not the pose, after its first
+// iteration): v_shaped = v_template + S is recomputed, the 135 pose rows are NOT read -- v_posed = v_shaped + P with the stored P is
+// the very operation the full kernel ends with, on the same bits (that is what summing the offsets from zero bought besides accuracy).
+#define LBS_MODE_FULL 0
+#define LBS_MODE_REUSE 1
+#define LBS_MODE_KEEP_P 2
+template <bool TWO_HAND, int MODE = LBS_MODE_FULL, int HG = LBS_HG>
 __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, const float* __restrict__ skel, int N, int B,
                                                                float* __restrict__ verts, float* __restrict__ joints,
-                                                               float* __restrict__ v_posed_ws) {
+                                                               float* __restrict__ v_posed_ws, float* __restrict__ pose_off_ws) {
+    constexpr bool REUSE = MODE == LBS_MODE_REUSE, KEEP_P = MODE == LBS_MODE_KEEP_P;
     TL_SCOPE(6);
     __shared__ float4 pfT[136][HG / 4];   // [e][hands 0-3 | 4-7]
     __shared__ float A_s[HG / 2][192][2];   // skinning matrices, the two hands of a pair interleaved
     __shared__ float beta_s[10][HG];  // [l][hand]
     __shared__ float shift_s[HG][4];
-    __shared__ float vsh_s[REUSE ? 1 : 3 * HG][REUSE ? 1 : LBS_THREADS];   // v_shaped of the thread's HG hands, parked while the pose offsets are summed
+    __shared__ float vsh_s[MODE != LBS_MODE_FULL ? 1 : 3 * HG][MODE != LBS_MODE_FULL ? 1 : LBS_THREADS];   // v_shaped of the thread's HG hands, parked while the pose offsets are summed
     const int tid = threadIdx.x, gx = blockIdx.x, tile = blockIdx.y % 4, gs = blockIdx.y / 4;
-    if (!REUSE)
+    if (MODE == LBS_MODE_FULL)
         for (int idx = tid; idx < HG * 136; idx += LBS_THREADS) {
             const int hh = idx / 136, e = idx % 136, hid = lbs_group_hand<HG>(gx, gs, hh);
             const float v = (hid < N && e < NPF) ? skel[(size_t)hid * SK_STRIDE + SK_PF + e] : 0.f;
@@ -309,18 +319,24 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
 #pragma unroll
         for (int q = 0; q < HG / 2; ++q) {
             const lbs_v2f tc[3] = {lbs_v2f{t.x, t.x}, lbs_v2f{t.y, t.y}, lbs_v2f{t.z, t.z}};
+            const int h0 = lbs_group_hand<HG>(gx, gs, 2 * q), h1 = lbs_group_hand<HG>(gx, gs, 2 * q + 1);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const lbs_v2f vs = tc[c] + vq[q][c];
-                vsh_s[6 * q + 2 * c][tid] = vs.x; vsh_s[6 * q + 2 * c + 1][tid] = vs.y;
-                vq[q][c] = lbs_v2f{0.f, 0.f};
+                if (KEEP_P) {       // v_posed = v_shaped + P, P as the full kernel stored it
+                    const lbs_v2f pc = {pose_off_ws[((size_t)min(h0, N - 1) * NV + v) * 3 + c], pose_off_ws[((size_t)min(h1, N - 1) * NV + v) * 3 + c]};
+                    vq[q][c] = vs + pc;
+                } else {
+                    vsh_s[6 * q + 2 * c][tid] = vs.x; vsh_s[6 * q + 2 * c + 1][tid] = vs.y;
+                    vq[q][c] = lbs_v2f{0.f, 0.f};
+                }
             }
         }
     }
     // pose blend: v_posed = v_shaped + pose_feature . posedirs.  The basis rows are fetched 9 at a time into two
     // register batches, the next batch in flight while the current one is consumed (explicit batches +
     // scheduling barriers: left alone, hipcc issues one load per use and waits vmcnt(0) on each).
-    if (!REUSE) {
+    if (MODE == LBS_MODE_FULL) {
         // a basis row is fetched as two aligned float pairs (x,y) (z,pad): packed FMAs take their broadcast operand
         // straight from either half of such a pair, no register shuffling between the load and its use
         struct Row { lbs_v2f xy, zw; };
@@ -364,6 +380,18 @@ __global__ __launch_bounds__(LBS_THREADS) void lbs_skin_kernel(ihmr_mano m, cons
             __builtin_amdgcn_sched_barrier(0);
         }
         consume(pa, NPF - 9);
+        if (pose_off_ws) {          // (uniform) a stage that keeps the finger pose reuses P from its second iteration on
+#pragma unroll
+            for (int q = 0; q < HG / 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int h = lbs_group_hand<HG>(gx, gs, 2 * q + i);
+                    if (h < N) {
+                        float* dstp = pose_off_ws + ((size_t)h * NV + v) * 3;
+                        dstp[0] = i ? vq[q][0].y : vq[q][0].x; dstp[1] = i ? vq[q][1].y : vq[q][1].x; dstp[2] = i ? vq[q][2].y : vq[q][2].x;
+                    }
+                }
+        }
 #pragma unroll
         for (int q = 0; q < HG / 2; ++q)
 #pragma unroll

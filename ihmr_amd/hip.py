@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "ihmr_adam_step", "ihmr_bn_workspace_bytes", "ihmr_bn_train_forward", "ihmr_bn_train_backward", "ihmr_conv_wgrad",
     "ihmr_dilate2", "ihmr_interleave2", "ihmr_pack_dgrad_weight", "ihmr_maxpool3x3s2_backward", "ihmr_avgpool_relu_backward", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer",
     "ihmr_mlp_workspace_bytes", "ihmr_mlp_stage_head", "ihmr_mlp_forward_select", "ihmr_opt_forward_verts",
-    "ihmr_debug_force_lbs_bwd2_streaming", "ihmr_version", "ihmr_copy_segments", "ihmr_root_align_joints",
+    "ihmr_debug_force_lbs_bwd2_streaming", "ihmr_debug_force_full_skin", "ihmr_version", "ihmr_copy_segments", "ihmr_root_align_joints",
 ]
 
 

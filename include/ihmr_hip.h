@@ -431,6 +431,10 @@ int ihmr_opt_forward_verts(const ihmr_mano* m, const ihmr_opt_io* io, int B, voi
  * (lbs_bwd2_kernel) at every launch size; 0 restores the default (the LDS-tiled form lbs_bwd2_lds_kernel from 256 hands on).  The two
  * forms produce the same bits (tests/test_gpu_parity.py::test_lbs_bwd2_forms_are_bit_identical).  Returns the previous value. */
 int ihmr_debug_force_lbs_bwd2_streaming(int force);
+/* checker switch (tests only): force = 1 makes every stage skin with both blends in every iteration; 0 restores the default (a stage that
+ * moves the shape but not the finger pose stores the pose-blend offsets in its first iteration and reuses them after: no pose rows read).
+ * The two produce the same bits (tests/test_gpu_parity.py::test_skin_keeps_pose_offsets_bit_identically).  Returns the previous value. */
+int ihmr_debug_force_full_skin(int force);
 
 const char* ihmr_version(void);
 

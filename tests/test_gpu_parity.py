@@ -1162,6 +1162,36 @@ def test_lbs_bwd2_forms_are_bit_identical(mano_arrays):
         assert np.array_equal(a[k], b[k]), f"{k}: the two forms of the pose-gradient GEMM differ"
 
 
+@pytest.mark.parametrize("B", [24, 160])
+def test_skin_keeps_pose_offsets_bit_identically(mano_arrays, B):
+    """Round 5: a stage that moves the shape but not the finger pose (opt_default's fourth) stores the pose-blend offsets P in its first
+    iteration's skinning launch and reuses them after -- `v_posed = (v_template + S) + P` with the stored P is the operation the full
+    kernel ends with, on the same bits.  opt_default (the shape stage with and without its snapshots' selection) at a small launch
+    (4 hands per skin workgroup) and a large one (8), with the reuse and with `ihmr_debug_force_full_skin`: optimizer state, snapshot
+    losses, selection and every export bit for bit."""
+    from ihmr_amd import hip
+    from ihmr_amd.optimize_model import OptimizeModel
+    _, batch = _two_hand_verts(mano_arrays, B, 515)
+    outs = []
+    try:
+        for force in (0, 1):
+            hip.lib().ihmr_debug_force_full_skin(force)
+            m = OptimizeModel(_make_opt(B, epoch=6, save_mid_freq=2))     # (a fresh instance: the stage graphs are captured under the switch)
+            m.set_input(batch); m.init_optimize(); m.optimize()
+            m.set_input(batch); m.init_optimize(); m.optimize()            # (a second pass replays the graphs over the first pass's stale offsets)
+            torch.cuda.synchronize()
+            outs.append((m.get_pred_result(), torch.stack(m.selected_history).cpu().numpy(), m.buf["adam_m"].cpu().numpy(),
+                         m.buf["adam_v"].cpu().numpy(), m.buf["snap_loss"].cpu().numpy()))
+    finally:
+        hip.lib().ihmr_debug_force_full_skin(0)
+    (a, sa, ma, va, la), (b, sb, mb, vb, lb) = outs
+    assert np.abs(ma).max() > 0
+    assert np.array_equal(sa, sb) and np.array_equal(ma, mb) and np.array_equal(va, vb) and np.array_equal(la, lb)
+    for k in ("pred_cam_params", "pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "pred_left_hand_verts",
+              "pred_joints_3d", "collision_loss", "collision_loss_origin_scale"):
+        assert np.array_equal(a[k], b[k]), f"{k}: kept pose offsets change the result"
+
+
 def test_candidate_lists_are_used_and_accounted_for(mano_arrays):
     """The work counters of the fused loop (`inside_voxels` = the voxels handed to the distance kernel): inside a stage most of them are
     answered from their candidate lists, every one is evaluated exactly once per iteration (list search + full search), the list search
