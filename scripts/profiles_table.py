@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ("sdf_dist_kernel", "sdf_prep_kernel", "opt_tail_kernel<true, true>", "opt_tail_kernel<true, false>", "opt_tail_kernel<false, false>",
-           "lbs_skin_kernel")
+           "lbs_skin_kernel<true, 0", "lbs_skin_kernel<true, 2")
 LABEL = {"f7": "7 batches = 448 samples: the driver's `--steps 20` run (three sequences of 7 + 7 + 6)", "f8": "8 batches = 512 samples",
          "f1": "one batch of 64 (the latency case)"}
 
@@ -32,7 +32,8 @@ def main_row(prefix, size):
         a = top(ks, k, "calls")
         if a is None:
             continue
-        s = f"`{k.replace(', ', ',')}` {float(a['avg_us']):.1f} µs"
+        label = {"lbs_skin_kernel<true, 0": "lbs_skin_kernel (both blends)", "lbs_skin_kernel<true, 2": "lbs_skin_kernel (pose offsets kept)"}.get(k, k.replace(", ", ","))
+        s = f"`{label}` {float(a['avg_us']):.1f} µs"
         b, c = top(sq, k, "launches"), top(tr, k, "launches")
         extra = []
         if b and b.get("SQ_INSTS_VALU_per_launch"):
