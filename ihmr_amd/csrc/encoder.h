@@ -129,7 +129,20 @@ void conv_igemm_kernel(ConvArgs a) {
     const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
     const int kl = lane >> 5, l31 = lane & 31;
     const int M = a.N * a.Ho * a.Wo, K = a.kh * a.kw * a.Cin, Kpad = (K + CONV_BK - 1) / CONV_BK * CONV_BK;
+    // Tile of this workgroup.  Workgroups go to the XCDs round-robin in dispatch order (x fastest), each XCD with its own L2: XCD k = L % 8
+    // takes the k-th CONTIGUOUS eighth of the tile sequence, walked with the column tiles of one row tile adjacent in time -- the row
+    // tile's A operand (and the 3 x 3 halo it shares with its neighbours) is fetched into ONE L2 once, instead of once per column tile
+    // and XCD.  (Placement is a performance assumption only: any map gives the same tiles, each computed exactly as before.)
+#ifdef CONV_NO_XCD_MAP
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+#else
+    int m0, n0;
+    {
+        const unsigned gy = gridDim.y, T = gridDim.x * gy, L = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned q = T >> 3, r = T & 7u, xcd = L & 7u, seq = xcd * q + min(xcd, r) + (L >> 3);
+        m0 = (int)(seq / gy) * BM; n0 = (int)(seq % gy) * BN;
+    }
+#endif
     // split-K: this workgroup owns K tiles [kc0, kc1)
     const int nk_all = Kpad / CONV_BK, nk_per = (nk_all + a.ksplit - 1) / a.ksplit;
     const int kc0 = blockIdx.z * nk_per, kc1 = min(nk_all, kc0 + nk_per);
