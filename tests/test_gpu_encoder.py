@@ -23,6 +23,8 @@ def _report(name, got, ref, atol, rtol):
     dict(N=3, H=30, W=34, Cin=4, Cout=64, k=7, s=2, p=3),       # the stem on a 4-channel image (CONV_C4: one pixel of one tap per 16-byte load)
     dict(N=1, H=9, W=9, Cin=4, Cout=40, k=5, s=1, p=2),         # CONV_C4, 64-row tile, taps wrapping every step (kw = 5), Cout not a tile multiple
     dict(N=1, H=6, W=5, Cin=2064, Cout=32, k=3, s=1, p=1),      # Cin beyond the zero page of the fast gather: generic path, padding still zero
+    dict(N=1, H=24, W=24, Cin=32, Cout=320, k=1, s=1, p=0),     # 5 x 3 = 15 tiles: the XCD-aware tile order with a remainder (15 = 8 + 7), last row and column tiles partial
+    dict(N=5, H=20, W=20, Cin=48, Cout=192, k=3, s=1, p=1),     # 16 x 2 = 32 tiles (last row tile partial, 1.5 column tiles): every XCD two row tiles, their column tiles adjacent
 ])
 def test_conv_igemm_matches_torch(cfg):
     from ihmr_amd.networks import _Packed, conv_igemm
