@@ -171,3 +171,13 @@ def test_one_rank_group_goes_through_the_backend(tmp_path):
     mp.spawn(_single_worker, args=(1, _free_port(), out), nprocs=1, join=True)
     got = np.load(out)
     assert np.array_equal(got[:9], np.arange(9)) and got[9] == 1.0 and np.array_equal(got[10:], np.arange(8))
+
+
+def test_numa_pinning_is_a_no_op_where_the_topology_cannot_be_read():
+    """dist.pin_to_gpu_numa_node (INTEGRATION.md "Multi-GPU launch"): without a GPU -- or without its sysfs entry -- it returns None
+    and leaves the process's CPU affinity alone."""
+    import os
+    from ihmr_amd.dist import pin_to_gpu_numa_node
+    before = os.sched_getaffinity(0)
+    assert pin_to_gpu_numa_node(0) is None
+    assert os.sched_getaffinity(0) == before
