@@ -484,6 +484,13 @@ def secondary(config, with_cpu=True):
     torch.cuda.set_device(0)
     cores = os.cpu_count() or 1
     torch.set_num_threads(min(32, cores))
+    # a clean slate between independent legs of the line: the instances of the leg before (reference cycles through their captured
+    # graphs and streams) and the allocator's cached blocks cost the NEXT leg host time -- IHMR-MLP read 123 k images/s behind the
+    # IHMR-Baseline leg and 135.7 k alone or after this (scripts/experiments/mlp_after_baseline.py)
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
 
     def timeit(fn, steps, warmup):
         for _ in range(warmup):
