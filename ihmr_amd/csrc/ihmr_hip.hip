@@ -433,8 +433,9 @@ static SdfWorkspace opt_sdf_ws(const ihmr_opt_io* io, const OptWork& wk, int B, 
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B, true);
     ws.list_mode = (lists != 0 && !io->sdf_no_candidate_lists) ? 1 : 0;
     ws.force_rebuild = lists == 2 ? 1 : 0;
-    ws.static_stage = (ws.list_mode && !io->sdf_no_static_reuse) ? static_mask : 0;
+    ws.static_stage = (ws.list_mode && io->sdf_no_static_reuse != 1) ? (static_mask & 3) : 0;
     ws.static_mask = ws.force_rebuild ? 0 : ws.static_stage;
+    ws.moving_box = (static_mask >> 2) & ws.static_stage;      // (bits 2-3 of the caller's mask: sides that only translate)
     ws.align_corners = io->sdf_align_corners ? 1 : 0;
     if (io->sdf_loss_divisor > 0.f) ws.loss_div = io->sdf_loss_divisor;
     ws.swap_xz = io->sdf_swap_xz ? 1 : 0;
@@ -500,8 +501,14 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
     // Hands whose vertices cannot change during this stage (SdfWorkspace::static_mask): the right hand when none of its own blocks is
     // refined; the left hand when neither its own blocks, nor the translation, nor the right hand's shape (the left hand is shifted by
     // trans + J_r[0] - J_l[0], optimize_model.py:217-224) is.  opt_default's translation stage: the right hands.
-    const int static_mask = ((pm & (IHMR_PB_ORIENT_R | IHMR_PB_POSE_R | IHMR_PB_SHAPE_R)) ? 0 : 1) |
-                            ((pm & (IHMR_PB_ORIENT_L | IHMR_PB_POSE_L | IHMR_PB_SHAPE_L | IHMR_PB_TRANS | IHMR_PB_SHAPE_R)) ? 0 : 2);
+    int static_mask = ((pm & (IHMR_PB_ORIENT_R | IHMR_PB_POSE_R | IHMR_PB_SHAPE_R)) ? 0 : 1) |
+                      ((pm & (IHMR_PB_ORIENT_L | IHMR_PB_POSE_L | IHMR_PB_SHAPE_L | IHMR_PB_TRANS | IHMR_PB_SHAPE_R)) ? 0 : 2);
+    // Round 5: a left hand that the stage only TRANSLATES (the translation stage of opt_default: trans alone moves) is static in its own
+    // normalised frame -- its box follows it, everything inside the box stays: treated as static with a moving box (SdfWorkspace::moving_box;
+    // bits 2-3 of the mask).  The kept grid is the first iteration's; a recomputation would differ by the rounding of the translated
+    // vertices, so unlike the static reuse this is not bit-identical to the from-scratch path (sdf_no_static_reuse = 2 switches it off).
+    if ((pm & IHMR_PB_TRANS) && !(pm & (IHMR_PB_ORIENT_L | IHMR_PB_POSE_L | IHMR_PB_SHAPE_L | IHMR_PB_SHAPE_R)) && io->sdf_no_static_reuse == 0)
+        static_mask |= 2 | (2 << 2);
     const bool pose_stage = (need_mask & 2) != 0;
     const size_t tail_lds = (size_t)opt_tail_dynamic_lds(m->nseg);
     for (int it = 0; it < sg->n_iters; ++it) {

@@ -105,6 +105,11 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
     unsigned* inside_k;        // [H][1024]
     int static_mask;           // ... this launch treats these sides as static (the stage's iterations after the first)
     int static_stage;          // ... the stage will (its first iteration records `known` / `inside_k` for them)
+    int moving_box;            // bit hnd (subset of static_mask): the hands of that side only TRANSLATE during the stage (round 5): in the hand's own
+                               // normalised frame nothing moves, so everything above is kept as for a static hand -- except the box, which is
+                               // taken from the current vertices every iteration (queries are normalised with it; the sampler reads it).  NOT an
+                               // exact acceleration: the kept geometry is the first iteration's, a recomputation differs from it by the rounding
+                               // of the translated vertices (~1e-7 m); ihmr_opt_io::sdf_no_static_reuse = 2 switches it off alone
     int list_mode, force_rebuild;
     // conventions of the upstream module that nothing in the reference pins (ihmr_sdf_options; defaults = DESIGN.md section 4)
     int align_corners;         // grid_sample(align_corners): 0 = False (the default of the reference's pinned torch 1.6.0)
@@ -164,7 +169,7 @@ static inline SdfWorkspace sdf_carve(void* ws, int H, bool lists = false) {
     w.inside_list = (unsigned*)p; p += sdf_xcd_cap(H) * sizeof(unsigned);
     w.qcell = (unsigned*)p; p += ((size_t)H * NV * sizeof(unsigned) + 255) & ~(size_t)255;
     w.vn_ref = nullptr; w.hmode = nullptr; w.run_start = nullptr; w.hdisp = nullptr; w.lnext = nullptr; w.lbits = nullptr; w.rbits = nullptr; w.lmap = nullptr; w.lists = nullptr; w.known = nullptr; w.inside_k = nullptr;
-    w.static_mask = 0; w.static_stage = 0;
+    w.static_mask = 0; w.static_stage = 0; w.moving_box = 0;
     w.inside_list_a = nullptr;
     w.list_mode = 0; w.force_rebuild = 1;
     if (lists) {
@@ -387,6 +392,8 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     const bool lists_on = !DENSE && ws.list_mode != 0;
     // a STATIC hand (see SdfWorkspace::static_mask; uniform over the workgroup): its own vertices are not even read
     const bool stat = lists_on && !ws.force_rebuild && ((ws.static_mask >> hnd) & 1);
+    // ... and one that only translates (SdfWorkspace::moving_box): static in its own frame, the box follows the current vertices
+    const bool tbox = stat && ((ws.moving_box >> hnd) & 1);
 #pragma unroll
     for (int rep = 0; rep < VPT; ++rep) {
         oq[rep][0] = oq[rep][1] = oq[rep][2] = 0.f;
@@ -394,9 +401,9 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         if (v < NV) {
             const F3 q = reinterpret_cast<const F3*>(other)[v];
             oq[rep][0] = q.x; oq[rep][1] = q.y; oq[rep][2] = q.z;
-            if (!stat) {
+            if (!stat || tbox) {
                 const F3 o = reinterpret_cast<const F3*>(own)[v];
-                vn[3 * v] = o.x; vn[3 * v + 1] = o.y; vn[3 * v + 2] = o.z;
+                if (!stat) { vn[3 * v] = o.x; vn[3 * v + 1] = o.y; vn[3 * v + 2] = o.z; }
                 mn[0] = fminf(mn[0], o.x); mn[1] = fminf(mn[1], o.y); mn[2] = fminf(mn[2], o.z);
                 mx[0] = fmaxf(mx[0], o.x); mx[1] = fmaxf(mx[1], o.y); mx[2] = fmaxf(mx[2], o.z);
             }
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
     }
 
     float4 sbox = make_float4(0.f, 0.f, 0.f, 1.f);
-    if (stat) sbox = *reinterpret_cast<const float4*>(ws.box + H * 4);
+    if (stat && !tbox) sbox = *reinterpret_cast<const float4*>(ws.box + H * 4);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float a = wave_reduce_min(mn[k]), c = wave_reduce_max(mx[k]);
@@ -459,9 +466,9 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         cz = (lo[2] + hi[2]) * 0.5f;
         sc = 0.6f * fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));  // (1 + 0.2) * 0.5 * max extent
     }
-    if (stat) { cx = sbox.x; cy = sbox.y; cz = sbox.z; sc = sbox.w; }      // (the box of the stage's first iteration: the same vertices)
+    if (stat && !tbox) { cx = sbox.x; cy = sbox.y; cz = sbox.z; sc = sbox.w; }      // (the box of the stage's first iteration: the same vertices)
     SDF_TK(pk_[1] = SDF_STAMP();)
-    if (!stat && tid < 4) ws.box[H * 4 + tid] = tid == 0 ? cx : (tid == 1 ? cy : (tid == 2 ? cz : sc));
+    if ((!stat || tbox) && tid < 4) ws.box[H * 4 + tid] = tid == 0 ? cx : (tid == 1 ? cy : (tid == 2 ? cz : sc));
     // ---- normalise own vertices into [-1,1]^3; which voxels will the other hand's vertices read?
     const SdfDivisor dsc = sdf_divisor(sc);
     // (temporal candidate lists: the displacement of this thread's vertices from the lists' reference pose is taken here, where the

@@ -155,7 +155,7 @@ class OptimizeModel:
                             sdf_loss_divisor=float(getattr(self.opt, "sdf_loss_divisor", 0.0) or 0.0),
                             sdf_swap_xz=int(bool(getattr(self.opt, "sdf_swap_xz", False))),
                             sdf_no_candidate_lists=int(bool(getattr(self.opt, "sdf_no_candidate_lists", False))),
-                            sdf_no_static_reuse=int(bool(getattr(self.opt, "sdf_no_static_reuse", False))),
+                            sdf_no_static_reuse=(1 if getattr(self.opt, "sdf_no_static_reuse", False) else (2 if getattr(self.opt, "sdf_no_translated_reuse", False) else 0)),
                             no_fused_tail=int(bool(getattr(self.opt, "no_fused_tail", False))))
         self.mano_params_weight = z(B, 2)
         self.init = {}

@@ -145,7 +145,10 @@ typedef struct ihmr_opt_io {
     /* 1 = a hand whose vertices cannot change during a stage (the right hand of a stage that refines only the translation) is
        re-evaluated from scratch every iteration instead of keeping what the stage's earlier iterations found out about its voxels
        (an exact acceleration as well: the same vertices give the same grid; this switch exists to test that).  Implied by
-       sdf_no_candidate_lists. */
+       sdf_no_candidate_lists.
+       2 = only the round-5 extension is off: a left hand that a stage merely TRANSLATES (opt_default's translation stage) is otherwise
+       treated as static in its own frame with a box that follows it -- the kept grid is the first iteration's, which a recomputation
+       reproduces only up to the rounding of the translated vertices (~1e-7 m): within the 1e-4 parity bar, not bit-identical. */
     int sdf_no_static_reuse;
     int no_fused_tail;          /* 1: every stage runs sampling + losses, the per-hand LBS backward, the optimizer step + skeletons and
                                  * (translation / orientation stages) the skinning of the stored v_posed as separate launches -- the
