@@ -150,6 +150,9 @@ class OptimizeModel:
             workspace=torch.empty(hip.lib().ihmr_opt_workspace_bytes(B), device=dev, dtype=torch.uint8),
         )
         # conventions of the collision module (include/ihmr_hip.h: ihmr_sdf_options): opt.sdf_align_corners / opt.sdf_loss_divisor / opt.sdf_swap_xz
+        # checker switches of the loop's accelerations (include/ihmr_hip.h: ihmr_opt_io): opt.sdf_no_candidate_lists, opt.sdf_no_static_reuse (exact
+        # accelerations: bit-identical either way), opt.sdf_no_translated_reuse (the kept grid of a hand that a stage only translates: rounding-level),
+        # opt.no_fused_tail
         self.io = hip.OptIO(**{k: v.data_ptr() for k, v in self.buf.items()}, norm_batch=self.norm_batch,
                             sdf_align_corners=int(bool(getattr(self.opt, "sdf_align_corners", False))),
                             sdf_loss_divisor=float(getattr(self.opt, "sdf_loss_divisor", 0.0) or 0.0),
