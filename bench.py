@@ -688,6 +688,28 @@ def secondary(config, with_cpu=True):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this file under `torch.distributed.run` as a CHILD process
+    (never an exec, and nothing in this parent has initialised the GPU: `torch.cuda.device_count()` does not on this image) and
+    return its exit code; stdout / stderr are inherited, so rank 0's JSON line is this command's JSON line.  A box with fewer
+    than N GPUs cannot give RCCL one device per rank: the ranks then share the devices round-robin over gloo (the single-GPU check
+    of the N-rank code path, `config.ranks_per_device` > 1 in the line says so) unless IHMR_DIST_BACKEND is set."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count()
+    if ndev < n:
+        env.setdefault("IHMR_DIST_BACKEND", "gloo")
+        print(f"bench.py: --gpus {n} on a box with {ndev} GPU(s): ranks share devices over {env['IHMR_DIST_BACKEND']}", file=sys.stderr)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -722,6 +744,14 @@ def main():
         print(json.dumps(secondary(args.config, with_cpu=not args.no_cpu_baseline)))
         return
 
+    # --gpus N is a guarantee, not a hint: N ranks run, or the command fails.  Under a launcher (WORLD_SIZE set: the driver's
+    # `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) the two must agree; without one and N > 1 this
+    # process becomes the launcher -- BEFORE it has touched the GPU -- and passes the ranks' one JSON line through.
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    elif args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -933,9 +963,21 @@ def main():
                 model.get_pred_result()
                 t3 = time.perf_counter()
                 loops.append(t2 - t1); totals.append(t3 - t0)
+            # per stage (a pass of its own: a synchronize between the stages): microseconds per refinement iteration
+            per_stage = [[] for _ in model.strategy]
+            for rep in range(5):
+                model.set_input(batch); model.init_optimize()
+                for si, stage in enumerate(model.strategy):
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    model.run_stage(stage)
+                    torch.cuda.synchronize()
+                    per_stage[si].append(time.perf_counter() - ts)
         loop, tot = float(np.median(loops)), float(np.median(totals))
+        stage_us = [1e6 * float(np.median(p)) / (args.epoch + 1) for p in per_stage]
         latency = dict(batch=B, streams=1, batches_per_launch=1, ms_per_refine_iter=1000.0 * loop / n_iters, ms_per_batch=1000.0 * tot,
-                       images_per_s=B / tot, note="median of 7 passes; stage loop replayed from its hipGraphs")
+                       images_per_s=B / tot, stage_us_per_refine_iter=stage_us,
+                       note="median of 7 passes; stage loop replayed from its hipGraphs; per stage: median of 5 passes of their own")
 
     # ---- the reference's own recipe (bash/optimize.sh:11,33): batch 512 per process as ONE launch sequence on one stream
     large = None
@@ -1055,7 +1097,19 @@ def main():
                                  f"save_mid_freq={freq}, batch {B}/GPU, synthetic MANO-shaped asset seed 0"
                                  + ("" if args.asset == "mitten" else f" [{args.asset} mesh, interlocked batches: NOT the headline workload]"),
                         global_batch=world * B, refine_iters=n_iters, batches_in_flight_per_gpu=S * G, launch_streams=S,
-                        max_batches_per_launch_sequence=G, distinct_batches=G,
+                        max_batches_per_launch_sequence=G,
+                        # what the timed region really ran: job sizes per stream, and how many DISTINCT synthetic batches they touched
+                        # (a launch sequence of g batches carries batches 0..g-1 of this rank's G generated ones)
+                        launch_sequences_timed=plan(args.steps), distinct_batches=max((g for q in plan(args.steps) for g in q), default=0),
+                        distinct_batches_generated=G,
+                        devices_visible=torch.cuda.device_count(), ranks_per_device=-(-world // max(torch.cuda.device_count(), 1)),
+                        dist_backend=(dist.get_backend() if dist is not None else None),
+                        # the metric's second half -- ms per refinement iteration at batch 64 with ONE batch in flight -- copied
+                        # here from `latency` because the driver's record keeps `config` (null in --no-extras / multi-rank runs)
+                        latency_ms_per_refine_iter=latency["ms_per_refine_iter"] if latency else None,
+                        latency_images_per_s=latency["images_per_s"] if latency else None,
+                        latency_stage_us_per_refine_iter=latency["stage_us_per_refine_iter"] if latency else None,
+                        translated_hand_reuse="on (default; rounding-level, DESIGN 5.0)",
                         parallelism=f"dp{world} (independent samples, no collective)"),
             roofline=roofline, cpu_baseline=cpu, latency=latency, h2d_inclusive=h2d, large_batch=large, secondary_configs=second,
             geometry=geometry,
@@ -1065,7 +1119,7 @@ def main():
                                  achieved=78e3 * B * world / (amortised * 1e-3) / 1e9, peak=6300.0, unit="GB/s",
                                  frac=78e3 * B * world / (amortised * 1e-3) / 1e9 / (6300.0 * world),
                                  note="whole-iteration rate at the bench's concurrency: the part is latency-, not bandwidth-bound"),
-            parity=dict(timed_run_mean_penetration_depth_m=float(np.mean(res["collision_loss_origin_scale"])), vs_oracle=parity),
+            parity=dict(translated_reuse="on", timed_run_mean_penetration_depth_m=float(np.mean(res["collision_loss_origin_scale"])), vs_oracle=parity),
         )
         if selftest is not None:
             out["rccl_selftest"] = selftest

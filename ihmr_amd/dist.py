@@ -43,36 +43,56 @@ def init_dist(backend: str | None = None):
     return rank, world
 
 
-def pin_to_gpu_numa_node(device_index: int):
-    """Best-effort CPU affinity for a one-process-per-GPU rank: restrict this process to the cores of the NUMA node its GPU hangs off
-    (``/sys/bus/pci/devices/<bdf>/numa_node`` -> ``/sys/devices/system/node/node<k>/cpulist``).  A rank's host work is graph launches
-    and small copies (bench.py: ``host_submit_ms_per_step``); on a two-socket node eight unpinned ranks migrate across sockets and
-    their submission latency (PCIe doorbells, pinned-buffer reads) goes through the inter-socket link.  Returns a short description,
-    or None when the topology cannot be read (nothing is changed then).  INTEGRATION.md "Multi-GPU launch" shows the equivalent
-    ``numactl`` line for launchers that prefer to pin from outside."""
+def gpu_pci_address(device_index: int):
+    """``dddd:bb:dd.0`` of a visible GPU from torch's device properties (the runtime torch itself has loaded: no second copy of
+    libamdhip64.so is opened), or None without a GPU."""
+    if not torch.cuda.is_available():
+        return None
+    p = torch.cuda.get_device_properties(int(device_index))
+    return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+
+
+def numa_cpus_of_pci_device(bdf: str, sysfs_root: str = "/sys"):
+    """(NUMA node, set of its CPUs) of the PCI device ``bdf`` as sysfs describes it -- ``<root>/bus/pci/devices/<bdf>/numa_node`` ->
+    ``<root>/devices/system/node/node<k>/cpulist`` -- or None when either file is missing, unreadable or the node is -1 (a
+    single-socket box)."""
     try:
-        import ctypes
-        hiprt = ctypes.CDLL("libamdhip64.so")
-        buf = ctypes.create_string_buffer(64)
-        if hiprt.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
-            return None
-        bdf = buf.value.decode()
-        path = f"/sys/bus/pci/devices/{str(bdf).lower()}/numa_node"
+        path = os.path.join(sysfs_root, "bus/pci/devices", str(bdf).lower(), "numa_node")
         if not os.path.isfile(path):
             return None
-        node = int(open(path).read().strip())
+        with open(path) as fh:
+            node = int(fh.read().strip())
         if node < 0:
             return None
         cpus = set()
-        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
-            a, _, b = part.partition("-")
-            cpus.update(range(int(a), int(b or a) + 1))
+        with open(os.path.join(sysfs_root, f"devices/system/node/node{node}/cpulist")) as fh:
+            for part in fh.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        return node, cpus
+    except (OSError, ValueError):
+        return None
+
+
+def pin_to_gpu_numa_node(device_index: int, sysfs_root: str = "/sys", bdf: str = None):
+    """Best-effort CPU affinity for a one-process-per-GPU rank: restrict this process to the cores of the NUMA node its GPU hangs off.
+    A rank's host work is graph launches and small copies (bench.py: ``host_submit_ms_per_step``); on a two-socket node eight
+    unpinned ranks migrate across sockets and their submission latency (PCIe doorbells, pinned-buffer reads) goes through the
+    inter-socket link.  Returns a short description, or None when the topology cannot be read (nothing is changed then).
+    ``bdf`` / ``sysfs_root`` exist for the CPU test (a fake topology under tmp_path); INTEGRATION.md "Multi-GPU launch" shows the
+    equivalent ``numactl`` line for launchers that prefer to pin from outside."""
+    try:
+        bdf = bdf or gpu_pci_address(device_index)
+        found = numa_cpus_of_pci_device(bdf, sysfs_root) if bdf else None
+        if found is None:
+            return None
+        node, cpus = found
         cpus &= os.sched_getaffinity(0)
         if not cpus:
             return None
         os.sched_setaffinity(0, cpus)
         return f"GPU {device_index} ({bdf}) -> NUMA node {node}: {len(cpus)} cores"
-    except Exception:       # (no sysfs, no permission, exotic torch build: run unpinned)
+    except Exception:       # (no permission, exotic torch build: run unpinned)
         return None
 
 

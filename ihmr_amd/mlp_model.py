@@ -117,7 +117,9 @@ class MLPModel(MLPTrainMixin):
                 (ip[:, 0:3], "init_cam"), (ip[:, 3:99], "init_pose_params"), (ip[:, 99:119], "init_shape_params"),
                 (ip[:, 119:122], "init_hand_trans"), (gp[:, 3:99], "mano_pose"), (gp[:, 99:119], "mano_betas"),
                 (self._in["index"], "index"), (self._in["img_feat"], "img_feat"), (self._in["mano_params_weight"], "mano_params_weight")]
-        srcs = self._stage_inputs({k for _, k in plan} | {"hand_trans"}, input)
+        want = {k: dst.dtype for dst, k in plan}      # a loader may yield an int32 index, float64 joints, fp16 features: converted,
+        srcs = self._stage_inputs({k for _, k in plan} | {"hand_trans"},      # as the reference's FloatTensor.copy_() / .long() do
+                                  {k: (v if k not in want or v.dtype == want[k] else v.to(want[k])) for k, v in input.items()})
         pairs = [(srcs[k].reshape(dst.shape) if dst.is_contiguous() else srcs[k].reshape(dst.shape[0], -1), dst) for dst, k in plan]
         pairs.append((srcs["hand_trans"].reshape(B, 4)[:, :3], gp[:, 119:122]))
         hip.copy_segments(pairs)
@@ -305,7 +307,10 @@ class MLPModel(MLPTrainMixin):
 
     # mlp_model.py:702-719
     def get_pred_result(self):
-        return self.get_pred_result_async().wait()
+        """Arrays the caller OWNS: the reference's loop keeps every batch's rows until it pickles them at the end (test_mlp.py:61-68,
+        evaluator.py:38-97 stores row views), so the synchronous export copies out of the two alternating pinned buffers the
+        asynchronous one hands out views of."""
+        return OrderedDict((k, np.array(v, copy=True)) for k, v in self.get_pred_result_async().wait().items())
 
     def _packed_export(self, src):
         """The export's 13 tensors gathered into ONE device buffer by one launch (``ihmr_copy_segments``) and sent to the host in ONE

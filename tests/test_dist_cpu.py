@@ -173,11 +173,50 @@ def test_one_rank_group_goes_through_the_backend(tmp_path):
     assert np.array_equal(got[:9], np.arange(9)) and got[9] == 1.0 and np.array_equal(got[10:], np.arange(8))
 
 
-def test_numa_pinning_is_a_no_op_where_the_topology_cannot_be_read():
-    """dist.pin_to_gpu_numa_node (INTEGRATION.md "Multi-GPU launch"): without a GPU -- or without its sysfs entry -- it returns None
-    and leaves the process's CPU affinity alone."""
+def _fake_sysfs(root, bdf, node, cpulist):
+    d = root / "bus/pci/devices" / bdf
+    d.mkdir(parents=True)
+    (d / "numa_node").write_text(f"{node}\n")
+    if node >= 0:
+        n = root / f"devices/system/node/node{node}"
+        n.mkdir(parents=True)
+        (n / "cpulist").write_text(cpulist + "\n")
+
+
+def test_numa_pinning_reads_the_topology_and_leaves_no_trace(tmp_path):
+    """dist.pin_to_gpu_numa_node (INTEGRATION.md "Multi-GPU launch") against a FAKE sysfs tree and a given bus id: no GPU runtime is
+    touched, and the process's affinity is restored afterwards (on a two-socket GPU box the real call narrows it for good)."""
     import os
-    from ihmr_amd.dist import pin_to_gpu_numa_node
+    from ihmr_amd import dist as D
     before = os.sched_getaffinity(0)
-    assert pin_to_gpu_numa_node(0) is None
-    assert os.sched_getaffinity(0) == before
+    try:
+        cpus = sorted(before)
+        # a node that holds two of this process's CPUs and others it does not have (ranges and singles; upper-case bus id)
+        want = {cpus[0], cpus[-1]}
+        _fake_sysfs(tmp_path / "a", "0000:c1:00.0", 1, f"{cpus[0]},{cpus[-1]},100000-100003")
+        assert D.numa_cpus_of_pci_device("0000:C1:00.0", str(tmp_path / "a")) == (1, want | set(range(100000, 100004)))
+        msg = D.pin_to_gpu_numa_node(3, sysfs_root=str(tmp_path / "a"), bdf="0000:C1:00.0")
+        assert msg is not None and "NUMA node 1" in msg and f"{len(want)} cores" in msg
+        assert os.sched_getaffinity(0) == want
+        os.sched_setaffinity(0, before)
+        # nothing is changed: node -1 (single socket), a missing device, a node without any of our CPUs, a garbled file
+        _fake_sysfs(tmp_path / "b", "0000:05:00.0", -1, "")
+        _fake_sysfs(tmp_path / "c", "0000:05:00.0", 0, "100000-100007")
+        _fake_sysfs(tmp_path / "d", "0000:05:00.0", 0, "x-y")
+        for root, bdf in ((tmp_path / "b", "0000:05:00.0"), (tmp_path / "b", "0000:06:00.0"), (tmp_path / "c", "0000:05:00.0"),
+                          (tmp_path / "d", "0000:05:00.0"), (tmp_path / "nowhere", "0000:05:00.0")):
+            assert D.pin_to_gpu_numa_node(0, sysfs_root=str(root), bdf=bdf) is None
+            assert os.sched_getaffinity(0) == before
+    finally:
+        os.sched_setaffinity(0, before)
+
+
+def test_bench_refuses_a_launcher_whose_world_size_differs_from_gpus():
+    """`--gpus N` is a guarantee: under a launcher with another WORLD_SIZE bench.py exits non-zero (before anything touches a GPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and not r.stdout.strip()

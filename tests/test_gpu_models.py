@@ -62,6 +62,50 @@ def test_mlp_model_matches_reference_golden_and_oracle(mano_arrays):
     _report("mlp collision_loss vs reference", res["collision_loss"], g["out_collision_loss"], atol=1e-4, rtol=1e-4)
 
 
+def test_mlp_sync_export_owns_its_arrays_and_inputs_are_cast(mano_arrays):
+    """The reference's loop keeps `get_pred_result()` of EVERY batch until the end (test_mlp.py:61-68; evaluator.py stores row
+    views): three exports from one instance, the first must not change under the later ones.  And a loader that yields an int32
+    index, float64 joints or fp16 features is converted as the reference's FloatTensor.copy_() / .long() do, not refused."""
+    from helpers import seeded_state_dict
+    from ihmr_amd.mlp_model import MLPModel
+    from ihmr_amd.strategies import make_mlp_strategy
+    g = dict(np.load(os.path.join(GOLD, "mlp_test.npz")))
+    batch = {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("in_")}
+    B = batch["init_cam"].shape[0]
+    strategy = make_mlp_strategy()
+    model = MLPModel(_opt(B))
+    model.set_update_info(strategy, 10)
+    from oracle.mlp_ref import MLPRef
+    orc = MLPRef(*mano_arrays, B, strategy, num_data=10)
+    for sid in range(len(strategy)):
+        model.add_new_network(sid)
+        model.sub_network_list[sid].load_state_dict(seeded_state_dict(orc.nets[sid], 900 + sid, last_scale=0.02))
+    model.eval()
+
+    def run(b):
+        model.set_input(b); model.test(); torch.cuda.synchronize()
+        return model.get_pred_result()
+    first = run(batch)
+    keep = {k: v.copy() for k, v in first.items()}
+    other = {k: v.clone() for k, v in batch.items()}
+    other["init_pose_params"] = other["init_pose_params"] + 0.05
+    other["init_hand_trans"] = other["init_hand_trans"] + 0.01
+    second, third = run(other), run(other)
+    assert not np.array_equal(second["pred_right_hand_verts"], keep["pred_right_hand_verts"])
+    for k in keep:
+        assert np.array_equal(first[k], keep[k]), f"{k}: the first export changed under a later one"
+        assert not np.shares_memory(first[k], third[k])
+    # dtype conversion at the boundary
+    cast = {k: v.clone() for k, v in batch.items()}
+    cast["index"] = cast["index"].to(torch.int32)
+    cast["joints_3d"] = cast["joints_3d"].double()
+    cast["img_feat"] = cast["img_feat"].half().float().half()
+    ref_in = dict(batch, img_feat=batch["img_feat"].half().float())
+    a, b = run(cast), run(ref_in)
+    for k in keep:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_mlp_test_graph_is_recaptured_when_its_baked_in_state_changes(mano_arrays):
     """test() is replayed from one captured graph; what the capture bakes in (the "prev" tables' addresses, the strategy's update
     columns / filter percentages / select losses) may change between calls: a second set_update_info() -- new tables, another
@@ -206,7 +250,7 @@ def test_baseline_test_graph_replays_equal_eager_launches(mano_arrays):
             assert np.array_equal(np.asarray(outs[0][k]), np.asarray(outs[1][k])), (round_, k)
 
 
-@pytest.mark.parametrize("B", [2, 64])
+@pytest.mark.parametrize("B", [2, 4, 64])       # 4 = BASELINE.json configs[0]'s batch
 def test_baseline_model_matches_oracle(mano_arrays, B):
     """InterHandModel.test(): encoder -> separate right/left MANO -> shift -> projection -> collision metric.
     B = 64 is BASELINE.json's IHMR-Baseline configuration: the 128 x 128 tiles without split-K that the measured

@@ -32,6 +32,41 @@ def test_bench_with_two_ranks_prints_one_line():
     assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["frac"] > 0
 
 
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python3 bench.py --gpus 2 ...` as the driver's 1-GPU command is shaped, with NO launcher around it: bench.py itself must start
+    two ranks (a child `torch.distributed.run`, before the parent touches the GPU) and pass their one line through -- n_gpus 2, the
+    whole job's batch.  On this one-GPU box the two ranks share the device over gloo and the line says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IHMR_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "8", "--warmup", "4"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["steps"] == 8 and d["warmup"] == 4 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert d["config"]["ranks_per_device"] == 2 and d["config"]["dist_backend"] == "gloo"
+    else:
+        assert d["config"]["ranks_per_device"] == 1 and d["config"]["dist_backend"] == "nccl"
+
+
+def test_bench_line_keeps_the_latency_figures_in_config():
+    """The metric's second half (ms per refinement iteration at batch 64, one batch in flight) and the per-stage figures sit in
+    `config`, which the driver's record keeps."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-work-counters"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["config"]
+    assert c["latency_ms_per_refine_iter"] == d["latency"]["ms_per_refine_iter"] and 0.0 < c["latency_ms_per_refine_iter"] < 0.2
+    assert c["latency_images_per_s"] == d["latency"]["images_per_s"] > 1000.0
+    assert len(c["latency_stage_us_per_refine_iter"]) == 4 and all(10.0 < x < 300.0 for x in c["latency_stage_us_per_refine_iter"])
+    assert c["distinct_batches"] == max(g for q in c["launch_sequences_timed"] for g in q) == 2 and d["parity"]["translated_reuse"] == "on"
+    print(f"[bench] latency {c['latency_ms_per_refine_iter']:.4f} ms per iteration, stages {c['latency_stage_us_per_refine_iter']}")
+
+
 def test_run_optimize_two_ranks_equals_one_process():
     from ihmr_amd import run_optimize
     two = _run(["-m", "ihmr_amd.run_optimize", "--num_samples", "128", "--batchSize", "32", "--opt_epoch", "9"])[-1]
