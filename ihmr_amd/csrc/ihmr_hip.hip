@@ -1122,6 +1122,46 @@ extern "C" int ihmr_debug_stamps(long long* host, int zero) {
 }
 #endif
 
+#ifdef SDF_QMASK_CHECK
+// device pointers of the collision workspace of a fused-loop io: qcell, inside_bits, box, phi
+extern "C" int ihmr_debug_sdf_ptrs(const ihmr_opt_io* io, int B, void** out4) {
+    SdfWorkspace ws = sdf_carve(opt_carve(io->workspace, B).sdf_ws, 2 * B, true);
+    out4[0] = ws.qcell; out4[1] = ws.inside_bits; out4[2] = ws.box; out4[3] = ws.phi;
+    return 0;
+}
+extern "C" int ihmr_debug_qmask(unsigned* host8) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_qmask_bad), 32);
+}
+#endif
+
+#ifdef SDF_HANDLOG
+// experiment builds only: cap > 0 -- allocate a log of `cap` records and start; cap == 0 -- copy the records out ([n][4] uint32: hand,
+// voxels with a candidate list, voxels for the full search, bit 0 lists reused | bit 1 static hand), n = return value
+extern "C" long ihmr_debug_handlog(unsigned* host, long cap) {
+    static uint4* buf = nullptr;
+    static unsigned cap_now = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (cap > 0) {
+        if (buf) (void)hipFree(buf);
+        if (hipMalloc(&buf, (size_t)cap * 16) != hipSuccess) return -1;
+        cap_now = (unsigned)cap;
+        const unsigned zero = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_handlog_n), &zero, 4) != hipSuccess) return -1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_handlog_cap), &cap_now, 4) != hipSuccess) return -1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_handlog), &buf, 8) != hipSuccess) return -1;
+        return 0;
+    }
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_handlog_n), 4) != hipSuccess) return -1;
+    if (n > cap_now) n = cap_now;
+    if (n && hipMemcpy(host, buf, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    uint4* null = nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_handlog), &null, 8);
+    return (long)n;
+}
+#endif
+
 #ifdef CONV_STAMPS
 // experiment builds only (scripts/experiments/conv_stamps.py): zero = 1 clears, zero = 0 copies the 1024 x 10 phase sums of conv_streamk_kernel out
 extern "C" int ihmr_debug_conv_stamps(long long* host, int zero) {

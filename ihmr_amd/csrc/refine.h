@@ -81,10 +81,8 @@ struct LossShared {
 
 // gj_lds (fused tail): the joint gradients go straight to the LBS backward's LDS records -- bw[hand].gj, raw hand frame: x of the left
 // hand negated, what lbs_bwd1_hand's staging does with the values it reads back from global memory -- instead of wk.g_joints
-template <class AfterMid = SdfNoHook>
 __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWork& wk, int B, const ihmr_opt_weights& w,
-                                              LossShared& sh, int b, int j, int need_cam, LbsBwdShared* gj_lds = nullptr,
-                                              bool mid_barrier = false, AfterMid after_mid = AfterMid()) {
+                                              LossShared& sh, int b, int j, int need_cam, LbsBwdShared* gj_lds = nullptr) {
     const bool act = j < 42;
     const int Bn = io.norm_batch > 0 ? io.norm_batch : B;   // the batch the reference's means run over
     // ---- every global input of this sample first, in one batch (the stores below may alias them as far as the
@@ -108,9 +106,6 @@ __device__ __forceinline__ void opt_loss_wave(const ihmr_opt_io& io, const OptWo
         for (int k = 0; k < 3; ++k) tr3[k] = io.trans[b * 3 + k];
     }
     __builtin_amdgcn_sched_barrier(0);
-    // (fused tail: the sampling waves' workgroup barrier -- the inside-voxel bitmaps have landed in LDS, sdf_sample_block -- which
-    // this wave has to join; it stands where the wave would wait for its loads anyway)
-    if (mid_barrier) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); after_mid(); }
     if (act) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) sh.raw[j][k] = r[k];
@@ -411,8 +406,8 @@ __device__ long long g_tail_stamps[3][4096][8];
 #else
 #define TAIL_TK(k)
 #endif
-// dynamic LDS of opt_tail_kernel: [2][nseg][12] floats of the LBS backward; phase 1 parks the two inside-voxel bitmaps in it (2 x 4 KB)
-static inline int opt_tail_dynamic_lds(int nseg) { const int a = 2 * nseg * 12 * (int)sizeof(float), b = 2 * SDF_NCOL * 4; return a > b ? a : b; }
+// dynamic LDS of opt_tail_kernel: [2][nseg][12] floats of the LBS backward
+static inline int opt_tail_dynamic_lds(int nseg) { return 2 * nseg * 12 * (int)sizeof(float); }
 template <bool STEP, bool SKIN = false>
 __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_mano m, ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w,
                                                                          VertLayout vl, SdfWorkspace ws, int need_cam, int need_mask,
@@ -427,11 +422,10 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
     long long tk_prev_ = (long long)__builtin_readcyclecounter();
     if (tid == 0 && blockIdx.x < 4096) g_tail_stamps[STEP + SKIN][blockIdx.x][7] += 1;
 #endif
-    // ---- phase 0: global -> LDS by DMA (no registers held).  First the inside-voxel bitmaps of both hands (2 x 4 KB, into the part of
-    //      the dynamic LDS that phase 2 uses later): the samplers read a cell's bitmap words from LDS instead of paying a global round
-    //      trip between the vertex loads and the phi loads.  Then -- behind phase 1's first barrier, so that nobody waits for it there --
-    //      what the LBS backward (phase 2) needs from the forward of this iteration, v_posed and the skeleton record of both hands:
-    //      it lands while phase 1 runs
+    // ---- phase 0: global -> LDS by DMA (no registers held): what the LBS backward (phase 2) needs from the forward of this iteration,
+    //      v_posed and the skeleton record of both hands; it lands while phase 1 runs.  (Rounds 4-5 also staged the two inside-voxel
+    //      bitmaps here and published them with a workgroup barrier in the middle of phase 1: since round 6 the prep kernel puts the
+    //      corner mask of every query into its cell word, and phase 1 has no barrier before the block sum.)
     const int hl = tid / LBS_THREADS;
     auto dma_backward_inputs = [&]() {
         if ((need_mask & 7) != 0) {
@@ -441,24 +435,20 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
             lds_dma_dwords(wk.lbs.skel + (size_t)(hl * B + b) * SK_STRIDE, bw[hl].sk, SK_STRIDE, tid % LBS_THREADS, LBS_THREADS);
         }
     };
-    unsigned* const bits_lds = reinterpret_cast<unsigned*>(tail_part);
-    lds_dma_dwords(reinterpret_cast<const float*>(ws.inside_bits + (size_t)(hl * B + b) * SDF_NCOL), tail_part + hl * SDF_NCOL, SDF_NCOL,
-                   tid % LBS_THREADS, LBS_THREADS);
+    dma_backward_inputs();
     // ---- phase 1: collision sampling (waves 0-6) + joint / translation / finger losses (wave 7).  Their gradients -- d L / d vertices,
-    //      d L / d joints -- are handed to phase 2 through its LDS records, not through global memory (the same values).  Two workgroup
-    //      barriers inside, at the same places for both kinds of wave: after the first batch of loads (the bitmaps are in LDS) and
-    //      after the block sum
+    //      d L / d joints -- are handed to phase 2 through its LDS records, not through global memory (the same values).  One workgroup
+    //      barrier inside, at the same place for both kinds of wave: the block sum
     const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
     const float gs = w.collision * mask / (ws.loss_div * (float)(io.norm_batch > 0 ? io.norm_batch : B));
     if (tid >= OPT_SAMPLE_WORKERS) {
-        opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS, need_cam, bw, true, dma_backward_inputs);
+        opt_loss_wave(io, wk, B, w, sh, b, tid - OPT_SAMPLE_WORKERS, need_cam, bw);
         if (tid == OPT_SAMPLE_WORKERS) red16[OPT_SAMPLE_WORKERS / WAVE] = 0.f;       // (its share of the block sum)
         __syncthreads();
     } else {
         // (inside the loop nobody reads the per-vertex depths: the 12 KB per sample and iteration are not written -- the forward that
         // closes optimize(), opt_sample_loss_kernel, writes the ones that are exported)
-        sdf_sample_fused(vl, ws, io.loss_batch + 2 * B, B, gs, io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS, bw[0].g, bw[1].g, bits_lds,
-                         dma_backward_inputs);
+        sdf_sample_fused(vl, ws, io.loss_batch + 2 * B, B, gs, io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS, bw[0].g, bw[1].g);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (this wave's DMA writes to LDS have landed; the barrier publishes them)
     __syncthreads();         // the gradients of this sample and the DMA'd records: written above by this workgroup, read below by it

@@ -73,8 +73,9 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
                                //             every other voxel is 0 by definition and is never written or read (round 4: was 128-byte rows of zeros)
     unsigned* qcell;           // [B][2][778] per sampling entry (hand, query vertex of the OTHER hand): the grid cell the query falls into, as the
                                //            prep kernel computed it while forming the needed-voxel mask -- SDF_QCELL_IN | (i0 + 1) | (j0 + 1) << 6 |
-                               //            (k0 + 1) << 12, or 0 for a query outside the grid.  The fused sampler starts from these words instead
-                               //            of redoing the normalisation of all 1556 queries (most of which touch no inside voxel)
+                               //            (k0 + 1) << 12 | (inside mask of the cell's eight corners) << 18 (round 6), or 0 for a query outside
+                               //            the grid.  The fused sampler starts from these words instead of redoing the normalisation of all
+                               //            1556 queries (most of which touch no inside voxel) and of reading the bitmap
     unsigned* inside_list;     // [xcd_cap] inside voxels of the whole batch: (hand << 16) | voxel id, 16-aligned run per hand
     int* inside_count;         // [SDF_NCTR] [0] entries in inside_list, [1] in inside_list_a; [SDF_CURSOR] the distance kernel's work cursor, on a
                                //            128-byte line of its own (the counters are read while the cursor is hammered)
@@ -119,6 +120,7 @@ struct SdfWorkspace {          // carved from the caller's workspace; H = 2B han
 };
 
 #define SDF_QCELL_IN 0x80000000u
+#define SDF_QCELL_MASK_SHIFT 18      // bits 18-25 of a cell word: which of the cell's eight corners are inside voxels (phi holds a distance)
 #define SDF_ENT_REFUSED 0x80000000u  // inside_list entry: (hand << 16) | voxel, hand < 32768; 0xffffffff = padding
 #define SDF_MAX_HANDS 32768          // ... so a launch takes at most 16384 samples (every entry point checks: ihmr_hip.hip)
 #define SDF_NCTR 64
@@ -298,6 +300,13 @@ __device__ long long g_sdf_prep[4096][8];             // sdf_prep_kernel: phase 
 #define SDF_STAMP() 0ll
 #endif
 
+#ifdef SDF_QMASK_CHECK
+__device__ unsigned g_qmask_bad[8];
+#endif
+#ifdef SDF_HANDLOG
+__device__ uint4* g_handlog = nullptr;
+__device__ unsigned g_handlog_n = 0, g_handlog_cap = 0;
+#endif
 // ------------------------------------------------------------------------------------- prep + parity
 // grid = 2B (block id = hand id H = hnd*B + b, so both hands of sample b sit on XCD b % 8 when B % 8 == 0),
 // block = PT (512 or 1024, see above).  Everything up to the inside/outside decision of a hand happens here, out of LDS:
@@ -362,8 +371,12 @@ __device__ __forceinline__ unsigned sdf_ray_hits(unsigned need, bool tri_safe, f
     return hits;
 }
 
+#ifndef SDF_PREP_MIN_WAVES
+#define SDF_PREP_MIN_WAVES 8       // 64 vector registers.  The kernel must not SPILL at this budget (scripts/isa.sh; tests/test_host_cpu.py checks the
+#endif                             // built code object): round 6 found the 512-thread form with scratch spills faulting behind the tail launch
+
 template <bool DENSE, int PT>
-__global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, const int32_t* __restrict__ faces_r,
+__global__ __launch_bounds__(PT, SDF_PREP_MIN_WAVES) void sdf_prep_kernel(VertLayout vl, int B, const int32_t* __restrict__ faces_r,
                                                                     const int32_t* __restrict__ faces_l, SdfWorkspace ws,
                                                                     int collect_stats) {
     TL_SCOPE(1);
@@ -431,11 +444,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         }
     }
 #pragma unroll
-    for (int rep = 0; rep < CPT; ++rep)
-    {
-        lb2[rep] = (lists_on && !ws.force_rebuild && !stat) ? ws.lbits[(size_t)H * SDF_NCOL + CPT * tid + rep] : 0u;
-        rb2[rep] = (lists_on && !ws.force_rebuild && !stat) ? ws.rbits[(size_t)H * SDF_NCOL + CPT * tid + rep] : 0u;
-    }
+    for (int rep = 0; rep < CPT; ++rep) lb2[rep] = rb2[rep] = 0u;       // (loaded at the end of the ray-parity phase: round 6, see there)
 
     float4 sbox = make_float4(0.f, 0.f, 0.f, 1.f);
     if (stat && !tbox) sbox = *reinterpret_cast<const float4*>(ws.box + H * 4);
@@ -497,6 +506,7 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
             const bool in_grid = fx >= -1.0f && fx <= (float)(SDF_G - 1) && fy >= -1.0f && fy <= (float)(SDF_G - 1) && fz >= -1.0f &&
                                  fz <= (float)(SDF_G - 1);
             // the query's cell for the fused sampler (entry hnd * 778 + v of sample b)
+            // (the inside mask of the cell's eight corners is added at the end of the kernel, when the inside words are known)
             ws.qcell[((size_t)b * 2 + hnd) * NV + v] =
                 in_grid ? (SDF_QCELL_IN | (unsigned)((int)fx + 1) | ((unsigned)((int)fy + 1) << 6) | ((unsigned)((int)fz + 1) << 12)) : 0u;
             if (in_grid) {
@@ -554,10 +564,6 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
             for (int rep = 0; rep < CPT; ++rep) { ws.lbits[(size_t)H * SDF_NCOL + tid + rep * PT] = 0u; ws.rbits[(size_t)H * SDF_NCOL + tid + rep * PT] = 0u; }
         }
         if (tid == 0) ws.hmode[H] = reuse ? 1 : 0;
-        if (!reuse) {
-#pragma unroll
-            for (int rep = 0; rep < CPT; ++rep) { lb2[rep] = 0u; rb2[rep] = 0u; }
-        }
     }
     // ---- a static hand: which needed voxels are needed for the FIRST time in this stage?  Only those go through the ray test (their
     //      masks replace `needed` there: `nmask`); none (common once the other hand has settled): the test is skipped altogether.
@@ -702,6 +708,17 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
             }
         }
     }
+    // which voxels of this thread's columns have a candidate list / were refused one: needed by the publish phase only, so requested
+    // here, behind the ray-parity phase -- rounds 3-5 requested the words at the top of the kernel and carried them in 2 CPT registers
+    // through every phase (the 512-thread form then spilled to scratch at its 64-register budget).  A hand that starts over has just
+    // cleared its words (other threads' stores): nothing is read, the words are zero.
+    if (lists_reused) {
+#pragma unroll
+        for (int rep = 0; rep < CPT; ++rep) {
+            lb2[rep] = ws.lbits[(size_t)H * SDF_NCOL + CPT * tid + rep];
+            rb2[rep] = ws.rbits[(size_t)H * SDF_NCOL + CPT * tid + rep];
+        }
+    }
     SDF_LDS_BARRIER();
     SDF_TK(pk_[5] = SDF_STAMP();)
     // ---- publish: a thread owns CPT adjacent columns; phi = 0 for the outside voxels a sample reads, inside voxels
@@ -733,6 +750,8 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         }
         // inside voxels with a candidate list (low half) / without (high half): one scan for both
         cur[col] = __popc(pub2[rep] & lb2[rep]) | (__popc(pub2[rep] & ~lb2[rep]) << 16);
+        // (the parity word has been consumed: from here on the LDS array holds the column's INSIDE word, for the query masks below)
+        if (!DENSE) parity[col] = inside2[rep];
     }
     // which voxels hold a distance: one word per column, a thread's CPT adjacent words in one store
     if (CPT == 2) *reinterpret_cast<uint2*>(ws.inside_bits + (size_t)H * SDF_NCOL + 2 * tid) = make_uint2(inside2[0], inside2[CPT - 1]);
@@ -760,6 +779,12 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
         }
     }
     if (tid == WAVE) blk_base_a = n_a > 0 ? atomicAdd(&ws.inside_count[1], pad_a) : 0;
+#ifdef SDF_HANDLOG       // experiment builds only (scripts/experiments/hand_work_log.py): per launch and hand, how many voxels go to which search
+    if (tid == 2 * WAVE && g_handlog) {
+        const unsigned i = atomicAdd(&g_handlog_n, 1u);
+        if (i < g_handlog_cap) g_handlog[i] = make_uint4((unsigned)H, (unsigned)n_a, (unsigned)n_b, (lists_reused ? 1u : 0u) | (stat ? 2u : 0u));
+    }
+#endif
     SDF_LDS_BARRIER();
     unsigned* const run_b = ws.inside_list + blk_base;
     unsigned* const run_a = ws.inside_list_a + blk_base_a;     // (never touched when n_a == 0: null for single-shot callers)
@@ -777,6 +802,35 @@ __global__ __launch_bounds__(PT, 8) void sdf_prep_kernel(VertLayout vl, int B, c
             const unsigned ent = ((unsigned)H << 16) | (unsigned)(col * SDF_G + i);
             if ((lb2[rep] >> i) & 1u) run_a[oa++] = ent;
             else run_b[ob++] = ent | (((rb2[rep] >> i) & 1u) ? SDF_ENT_REFUSED : 0u);
+        }
+    }
+    // ---- the fused sampler's cell words (round 6): the query's cell AND which of its eight corners hold a distance (bits 18-25: corner
+    //      2 c4 + di, c4 = (j - j0) + 2 (k - k0)) -- the inside words of the four columns are in LDS here (the scan's barriers have
+    //      published them).  The sampler of the tail launch then needs neither the hand's 4 KB bitmap nor a workgroup barrier before
+    //      it can request the phi values: one dependent round trip fewer per iteration.  The cell word is read back from where the
+    //      normalise phase stored it (this thread's own store, program order) instead of a register held across the ray-parity phase.
+    if (!DENSE) {
+        unsigned* const qc = ws.qcell + ((size_t)b * 2 + hnd) * NV;
+#pragma unroll
+        for (int rep = 0; rep < VPT; ++rep) {
+            const int v = tid + rep * PT;
+            if (v < NV) {
+                const unsigned c = qc[v];
+                unsigned m = 0u;
+                if (c & SDF_QCELL_IN) {
+                    const int i0 = (int)(c & 63u) - 1, j0 = (int)((c >> 6) & 63u) - 1, k0 = (int)((c >> 12) & 63u) - 1;
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const int j = j0 + (c4 & 1), k = k0 + (c4 >> 1);
+                        if (j >= 0 && j < SDF_G && k >= 0 && k < SDF_G) {
+                            const unsigned wbits = parity[k * SDF_G + j];
+                            const unsigned b0 = i0 >= 0 ? ((wbits >> (i0 & 31)) & 1u) : 0u, b1 = i0 + 1 < SDF_G ? ((wbits >> ((i0 + 1) & 31)) & 1u) : 0u;
+                            m |= (b0 << (2 * c4)) | (b1 << (2 * c4 + 1));
+                        }
+                    }
+                    qc[v] = c | (m << SDF_QCELL_MASK_SHIFT);
+                }
+            }
         }
     }
     // ---- lane = triangle: records for the distance kernel (minimum enclosing circle + normal), LAST: only the distance kernel reads them,
@@ -1712,20 +1766,18 @@ __device__ __forceinline__ void sdf_sample_block(const VertLayout& vl, const Sdf
     }
 }
 
-struct SdfNoHook { __device__ __forceinline__ void operator()() const {} };
 // The sampler of the fused tail (opt_tail_kernel): the same values as sdf_sample_block, bit for bit, from what the collision kernels
 // of the iteration have already worked out.
 //   * the prep kernel stored every query's grid cell (SdfWorkspace::qcell) while forming the needed-voxel mask: the 1556 normalisations
 //     (a third of the old sampler's instructions) are not redone;
-//   * the inside-voxel bitmaps of the sample's two hands (2 x 4 KB) are on their way into LDS by DMA, requested by the whole workgroup
-//     before this call: after the first batch of loads every wave waits for its own requests and a workgroup barrier publishes the
-//     pieces (EVERY wave of the workgroup has to arrive there: the caller's loss wave does, opt_loss_wave); after_mid() = the caller's
-//     further DMA requests, issued behind that barrier so that nobody waits for them here;
+//   * ... and, since round 6, which of the cell's eight corners are inside voxels (bits 18-25 of the cell word: the prep kernel had the
+//     bitmap in LDS when it wrote the word) -- rounds 4-5 staged both hands' 4 KB bitmaps in LDS and needed a workgroup barrier before the
+//     phi values could be requested;
 //   * a query none of whose eight cell corners is an inside voxel -- 94 % of them -- has value 0 and gradient 0: the old code computed
 //     exactly +0 for it (0 * w sums), so it loads nothing more and skips the arithmetic; the others load their
 //     vertex, box and phi values in ONE round trip (the phi addresses follow from the cell word) and run sdf_sample_block's
 //     expressions.  A degenerate hand (box scale outside [1e-6, 1e6]: the oracle's infinities / NaNs) takes the full path for every entry.
-// Two dependent global round trips instead of three, and a fraction of the arithmetic.
+// Two dependent global round trips (cell words, then vertex + phi of the few entries that need them) and no barrier before the block sum.
 #ifdef TAIL_STAMPS
 __device__ long long g_samp_stamps[4096][8];
 #define SAMP_TK(k) do { samp_t_[k] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -1734,10 +1786,9 @@ __device__ long long g_samp_stamps[4096][8];
 #define SAMP_TK(k)
 #define SAMP_DRAIN()
 #endif
-template <class AfterMid>
 __device__ __forceinline__ void sdf_sample_fused(const VertLayout& vl, const SdfWorkspace& ws, float* __restrict__ loss, int B, float gs,
                                                  const float* __restrict__ hand_type, float* red16, int b, int nworkers,
-                                                 float* g_lds_r, float* g_lds_l, const unsigned* bits_lds, AfterMid after_mid) {
+                                                 float* g_lds_r, float* g_lds_l) {
     const int tid = threadIdx.x;
     float acc = 0.f;
 #ifdef TAIL_STAMPS
@@ -1759,31 +1810,36 @@ __device__ __forceinline__ void sdf_sample_fused(const VertLayout& vl, const Sdf
     const float4 box0 = *reinterpret_cast<const float4*>(ws.box + (size_t)b * 4), box1 = *reinterpret_cast<const float4*>(ws.box + ((size_t)B + b) * 4);
     __builtin_amdgcn_sched_barrier(0);
     SAMP_TK(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    after_mid();
+    SAMP_DRAIN();
     SAMP_TK(2);
-    // ---- which of a cell's eight corners hold a distance (bitmap words from LDS)
+    // ---- which of a cell's eight corners hold a distance: bits 18-25 of the cell word (the prep kernel had the bitmap in LDS)
     const bool fast0 = box0.w >= 1e-6f && box0.w <= 1e6f, fast1 = box1.w >= 1e-6f && box1.w <= 1e6f;
     unsigned m8[SDF_SAMPLE_NIT];
     bool nz[SDF_SAMPLE_NIT];
 #pragma unroll
     for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
-        const unsigned c = cw[it];
-        const int i0 = (int)(c & 63u) - 1, j0 = (int)((c >> 6) & 63u) - 1, k0 = (int)((c >> 12) & 63u) - 1;
-        unsigned m = 0u;
-        if (on[it] && (c & SDF_QCELL_IN)) {
-            const unsigned* ib = bits_lds + hn[it] * SDF_NCOL;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const int j = j0 + (c4 & 1), k = k0 + (c4 >> 1);
-                if (j >= 0 && j < SDF_G && k >= 0 && k < SDF_G) {
-                    const unsigned wbits = ib[k * SDF_G + j];
-                    const unsigned b0 = i0 >= 0 ? ((wbits >> (i0 & 31)) & 1u) : 0u, b1 = i0 + 1 < SDF_G ? ((wbits >> ((i0 + 1) & 31)) & 1u) : 0u;
-                    m |= (b0 << (2 * c4)) | (b1 << (2 * c4 + 1));
+        unsigned m = (on[it] && (cw[it] & SDF_QCELL_IN)) ? ((cw[it] >> SDF_QCELL_MASK_SHIFT) & 0xffu) : 0u;
+#ifdef SDF_QMASK_CHECK      // experiment builds only: the mask recomputed from the hand's bitmap in global memory; mismatches counted, the bitmap's used
+        {
+            const unsigned c = cw[it];
+            const int i0 = (int)(c & 63u) - 1, j0 = (int)((c >> 6) & 63u) - 1, k0 = (int)((c >> 12) & 63u) - 1;
+            unsigned mr = 0u;
+            if (on[it] && (c & SDF_QCELL_IN)) {
+                const unsigned* ib = ws.inside_bits + (size_t)(hn[it] * B + b) * SDF_NCOL;
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const int j = j0 + (c4 & 1), k = k0 + (c4 >> 1);
+                    if (j >= 0 && j < SDF_G && k >= 0 && k < SDF_G) {
+                        const unsigned wbits = ib[k * SDF_G + j];
+                        const unsigned b0 = i0 >= 0 ? ((wbits >> (i0 & 31)) & 1u) : 0u, b1 = i0 + 1 < SDF_G ? ((wbits >> ((i0 + 1) & 31)) & 1u) : 0u;
+                        mr |= (b0 << (2 * c4)) | (b1 << (2 * c4 + 1));
+                    }
                 }
             }
+            if (mr != m) { atomicAdd(&g_qmask_bad[0], 1u); if (c >> 26 & 31u) atomicAdd(&g_qmask_bad[1], 1u); g_qmask_bad[2] = c; g_qmask_bad[3] = mr; }
+            atomicAdd(&g_qmask_bad[4], 1u);
+            m = mr;
         }
+#endif
         m8[it] = m;
         nz[it] = on[it] && (m != 0u || !(hn[it] ? fast1 : fast0));
     }
