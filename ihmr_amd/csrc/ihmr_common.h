@@ -52,8 +52,7 @@ struct TlScope {
 #define TL_SCOPE(k)
 #endif
 
-// dot product in the fixed order of the SDF arithmetic spec: fma(z, fma(y, x*x'))
-#define DOT3(ax, ay, az, bx, by, bz) __builtin_fmaf((az), (bz), __builtin_fmaf((ay), (by), (ax) * (bx)))
+#include "ihmr_pure.h"        // the pure arithmetic helpers (host-compilable): DOT3, SDF rays / distances, Rodrigues, chain, optimizer step
 
 
 struct ihmr_mano {

@@ -732,6 +732,15 @@ extern "C" int ihmr_opt_sdf_counters(const ihmr_opt_io* io, int B, unsigned long
     return 0;
 }
 
+extern "C" int ihmr_opt_sdf_inside_bits(const ihmr_opt_io* io, int B, unsigned* out, float* box) {
+    if (!io || B <= 0 || 2 * B > SDF_MAX_HANDS || (!out && !box)) return -1;
+    SdfWorkspace ws = sdf_carve(opt_carve(io->workspace, B).sdf_ws, 2 * B, true);
+    HIP_TRY(hipDeviceSynchronize());
+    if (out) HIP_TRY(hipMemcpy(out, ws.inside_bits, (size_t)2 * B * SDF_NCOL * sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (box) HIP_TRY(hipMemcpy(box, ws.box, (size_t)2 * B * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ encoder
 extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias, const float* residual, float* y, int N, int H,
                                int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int ldx, int ldw,

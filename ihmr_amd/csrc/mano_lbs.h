@@ -70,63 +70,6 @@ static inline LbsWork lbs_carve(void* ws, int N) {
     return w;
 }
 
-// smplx batch_rodrigues: angle = ||r + 1e-8||, R = I + sin K + (1 - cos) K^2, K = skew(r / angle)
-__device__ __forceinline__ void rodrigues_fwd(const float* r, float* R) {
-    const float ex = r[0] + 1e-8f, ey = r[1] + 1e-8f, ez = r[2] + 1e-8f;
-    const float a = sqrtf(ex * ex + ey * ey + ez * ez);
-    const float nx = r[0] / a, ny = r[1] / a, nz = r[2] / a;
-    const float s = sinf(a), c1 = 1.0f - cosf(a);
-    const float nn = nx * nx + ny * ny + nz * nz;
-    // K^2 = n n^T - (n.n) I
-    R[0] = 1.0f + c1 * (nx * nx - nn);
-    R[1] = -s * nz + c1 * (nx * ny);
-    R[2] = s * ny + c1 * (nx * nz);
-    R[3] = s * nz + c1 * (ny * nx);
-    R[4] = 1.0f + c1 * (ny * ny - nn);
-    R[5] = -s * nx + c1 * (ny * nz);
-    R[6] = -s * ny + c1 * (nz * nx);
-    R[7] = s * nx + c1 * (nz * ny);
-    R[8] = 1.0f + c1 * (nz * nz - nn);
-}
-
-// gradient of rodrigues_fwd: dR (3x3 row-major) -> dr (3)
-__device__ __forceinline__ void rodrigues_bwd(const float* r, const float* dR, float* dr) {
-    const float ex = r[0] + 1e-8f, ey = r[1] + 1e-8f, ez = r[2] + 1e-8f;
-    const float a = sqrtf(ex * ex + ey * ey + ez * ez);
-    const float inva = 1.0f / a;
-    const float n[3] = {r[0] * inva, r[1] * inva, r[2] * inva};
-    const float s = sinf(a), c = cosf(a), c1 = 1.0f - c;
-    const float nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
-    const float K[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
-    float ds = 0.f, dc1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            ds += dR[3 * i + j] * K[3 * i + j];
-            const float k2 = n[i] * n[j] - (i == j ? nn : 0.f);
-            dc1 += dR[3 * i + j] * k2;
-        }
-    // d/dn of  s*K(n) + c1*(n n^T - (n.n) I)
-    float dn[3];
-    dn[0] = s * (dR[7] - dR[5]);
-    dn[1] = s * (dR[2] - dR[6]);
-    dn[2] = s * (dR[3] - dR[1]);
-    const float tr = dR[0] + dR[4] + dR[8];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc += (dR[3 * i + j] + dR[3 * j + i]) * n[j];
-        dn[i] += c1 * (acc - 2.0f * tr * n[i]);
-    }
-    const float ndn = n[0] * dn[0] + n[1] * dn[1] + n[2] * dn[2];
-    const float da = c * ds + s * dc1 - ndn * inva;
-    dr[0] = dn[0] * inva + da * ex * inva;
-    dr[1] = dn[1] * inva + da * ey * inva;
-    dr[2] = dn[2] * inva + da * ez * inva;
-}
-
 // ------------------------------------------------------------------------------------- skeleton
 // 192 threads per hand h (tid = 0..191; every thread of the workgroup must call it: block-wide barriers inside; threads that own
 // no hand call it with active = false and only take part in the barriers).
@@ -184,22 +127,13 @@ __device__ __forceinline__ void lbs_skel_hand(const ihmr_mano& m, const float* _
         const int j = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
         if (my_depth == d) {
             const int p = my_parent;
-            const float* Gp = sG + 12 * p;
-            float acc;
-            if (c < 3) {
-                acc = Gp[4 * r + 0] * sR[9 * j + c] + Gp[4 * r + 1] * sR[9 * j + 3 + c] + Gp[4 * r + 2] * sR[9 * j + 6 + c];
-            } else {
-                const float rx = sJ[3 * j] - sJ[3 * p], ry = sJ[3 * j + 1] - sJ[3 * p + 1], rz = sJ[3 * j + 2] - sJ[3 * p + 2];
-                acc = Gp[4 * r + 0] * rx + Gp[4 * r + 1] * ry + Gp[4 * r + 2] * rz + Gp[4 * r + 3];
-            }
-            sG[12 * j + e] = acc;
+            sG[12 * j + e] = lbs_chain_elem(sG + 12 * p, sR + 9 * j, sJ + 3 * j, sJ + 3 * p, r, c);
         }
         __syncthreads();
     }
     if (active) {
         const int j = tid / 12, e = tid % 12, r = e / 4, c = e % 4;
-        const float* G = sG + 12 * j;
-        sA[12 * j + e] = c < 3 ? G[e] : G[4 * r + 3] - (G[4 * r + 0] * sJ[3 * j] + G[4 * r + 1] * sJ[3 * j + 1] + G[4 * r + 2] * sJ[3 * j + 2]);
+        sA[12 * j + e] = lbs_rel_elem(sG + 12 * j, sJ + 3 * j, r, c);
     }
     __syncthreads();
     for (int i = tid; i < SK_STRIDE; i += 192) skel[(size_t)h * SK_STRIDE + i] = sk[i];
@@ -1107,32 +1041,35 @@ __global__ __launch_bounds__(320) void lbs_bwd2_lds_kernel(ihmr_mano m, LbsWork 
 // finger-pose gradients: dR_j = chain part + pose-feature part (K-group sums in fixed order), through Rodrigues.
 // grid = N, block = 64: the wave first reduces the LBS_KG partial rows (coalesced, all loads in flight at once),
 // then lanes 1..15 = joints.
+// The work of one hand h by 64 threads j = 0..63 (a workgroup barrier inside: every thread of the workgroup calls it, threads that own
+// no hand with active = false); dpf = 192 floats of LDS of this hand.  (Rounds 5 and 6 each tried running it inside the next iteration's
+// opt_adam_skel_kernel, one launch fewer in the finger-pose stage: -1.2 % throughput with three sequences in flight, and 87.8 -> 87.3 us
+// per iteration at one batch of 64 -- the chain it adds in front of the step is as long as the launch it removes.  docs/experiments.md)
 template <bool TWO_HAND>
-__global__ __launch_bounds__(64) void lbs_bwd3_kernel(LbsWork wk, int N, int B, float* __restrict__ d_pose) {
-    TL_SCOPE(9);
-    __shared__ float dpf[192];
-    const int h = blockIdx.x, j = threadIdx.x;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int e = j + 64 * t;
-        if (e >= 136) break;
-        float part[LBS_KG];
-#pragma unroll
-        for (int c = 0; c < LBS_KG; ++c) part[c] = wk.dpf_part[((size_t)c * N + h) * 136 + e];
-        __builtin_amdgcn_sched_barrier(0);
-        float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < LBS_KG; ++c) acc += part[c];
-        dpf[e] = acc;
-    }
+__device__ __forceinline__ void lbs_bwd3_hand(const LbsWork& wk, int N, int B, float* __restrict__ d_pose, int h, int j, float* dpf, bool active = true) {
     float r[3] = {0.f, 0.f, 0.f}, chain[9];
     const int jj = min(max(j, 1), NJ - 1);
+    if (active) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) r[k] = wk.skel[(size_t)h * SK_STRIDE + SK_POSE + 3 * jj + k];
+        for (int t = 0; t < 3; ++t) {
+            const int e = j + 64 * t;
+            if (e >= 136) break;
+            float part[LBS_KG];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) chain[e] = wk.chain[(size_t)h * 192 + 9 * jj + e];
+            for (int c = 0; c < LBS_KG; ++c) part[c] = wk.dpf_part[((size_t)c * N + h) * 136 + e];
+            __builtin_amdgcn_sched_barrier(0);
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < LBS_KG; ++c) acc += part[c];
+            dpf[e] = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) r[k] = wk.skel[(size_t)h * SK_STRIDE + SK_POSE + 3 * jj + k];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) chain[e] = wk.chain[(size_t)h * 192 + 9 * jj + e];
+    }
     __syncthreads();
-    if (j < 1 || j >= NJ) return;
+    if (!active || j < 1 || j >= NJ) return;
     const bool left = TWO_HAND && h >= B;
     float dR[9], dr[3];
 #pragma unroll
@@ -1141,4 +1078,10 @@ __global__ __launch_bounds__(64) void lbs_bwd3_kernel(LbsWork wk, int N, int B, 
     if (left) { dr[1] = -dr[1]; dr[2] = -dr[2]; }
     float* dst = d_pose + (size_t)h * 45 + 3 * (j - 1);
     dst[0] = dr[0]; dst[1] = dr[1]; dst[2] = dr[2];
+}
+template <bool TWO_HAND>
+__global__ __launch_bounds__(64) void lbs_bwd3_kernel(LbsWork wk, int N, int B, float* __restrict__ d_pose) {
+    TL_SCOPE(9);
+    __shared__ float dpf[192];
+    lbs_bwd3_hand<TWO_HAND>(wk, N, B, d_pose, (int)blockIdx.x, (int)threadIdx.x, dpf);
 }

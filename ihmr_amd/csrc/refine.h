@@ -56,15 +56,6 @@ static inline OptWork opt_carve(void* ws, int B) {
 // finger table of loss_utils.py:139-145: [a, b, c, tip] for index, middle, little, ring, thumb
 __constant__ int c_finger_ids[20] = {1, 2, 3, 17, 4, 5, 6, 18, 7, 8, 9, 20, 10, 11, 12, 19, 13, 14, 15, 16};
 
-__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
-}
-
-// root of loss_utils.py:90-98: weight > 0.5 -> joint 0, weight < 1e-7 -> joint 21, else no alignment
-__device__ __forceinline__ int align_root(float w) { return w > 0.5f ? 0 : (w < 1e-7f ? 21 : -1); }
-
 // ONE wave per sample: lane j < 42 owns joint j (the steps are separated by wave-level barriers only, so the
 // wave can run beside the collision sampling of the same workgroup, see opt_sample_loss_kernel).
 struct LossShared {
@@ -343,20 +334,15 @@ __device__ __forceinline__ void opt_param_apply(const ihmr_opt_io& io, const Opt
     if (st.snap_idx >= 0) io.snap_params[((size_t)st.snap_idx * B + b) * OPT_NPARAM + e] = x;
     float m = io.adam_m[b * OPT_NPARAM + e];
     if (st.sgd) {
-        m = m * 0.9f;                        // buf.mul_(momentum).add_(grad); the first step's buf = grad (state zeroed)
-        m = m + g;
+        *p = opt_sgd_update(x, g, m, st.step_size);
         io.adam_m[b * OPT_NPARAM + e] = m;
-        *p = x + (-st.step_size) * m;        // param.add_(buf, alpha = -lr)
         return;
     }
     float v = io.adam_v[b * OPT_NPARAM + e];
-    m = m + 0.1f * (g - m);                  // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * 0.999f;                          // exp_avg_sq.mul_(beta2)
-    v = v + (0.001f * g) * g;                //            .addcmul_(grad, grad, value = 1 - beta2)
-    const float denom = sqrtf(v) / st.bc2_sqrt + 1e-8f;
+    const float xn = opt_adam_update(x, g, m, v, st.step_size, st.bc2_sqrt);       // (ihmr_pure.h: torch's operation order)
     io.adam_m[b * OPT_NPARAM + e] = m;
     io.adam_v[b * OPT_NPARAM + e] = v;
-    *p = x + (-st.step_size) * (m / denom);  // param.addcdiv_(exp_avg, denom, value = -step_size)
+    *p = xn;
 }
 // the three per-sample losses a stage may filter / select on (IHMR_LOSS_* = rows 0..2 of loss_batch), kept per snapshot
 __device__ __forceinline__ void opt_snapshot_losses(const ihmr_opt_io& io, int B, const ParamStep& st, int b, int e) {
@@ -398,6 +384,10 @@ __global__ __launch_bounds__(384) void opt_adam_skel_kernel(ihmr_mano m, ihmr_op
 // SKIN (with STEP, stages that keep v_posed -- neither finger pose nor shape moves): a fourth phase skins the stored v_posed of both
 // hands with the skeletons just computed (= lbs_skin_kernel<true, REUSE>, the same operations in the same order: the same bits), so
 // the next iteration starts at the collision kernels: 3 launches per iteration.
+// (Round 6 tried a third form for the shape stage -- the fourth phase rebuilding v_posed = (v_template + shapedirs . beta) + P from the stored
+// pose offsets, no skinning launch: bit-identical, and slower in both regimes, 52.6 us against 40.0 + 10.3 us per 448 samples and 73.8
+// against 71.1 us per iteration at one batch of 64 -- a thread's four vertices are four dependent gathers of eleven basis rows, where the
+// skinning launch streams each row once for 4 - 8 hands.  docs/experiments.md)
 // Phase stamps (experiment builds only, -DTAIL_STAMPS; scripts/tail_stamps.py): shader-clock time of each phase of a sample's workgroup,
 // summed per sample and kernel form
 #ifdef TAIL_STAMPS

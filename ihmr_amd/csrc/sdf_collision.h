@@ -35,7 +35,8 @@
 #define SDF_PREP_SMALL_MAX_HANDS 128     // up to this many hands per launch (one batch of 64) the 1024-thread form is used; at 256 hands (IHMR-MLP, batch 128) the 512-thread form is 11 % faster end to end
 #endif
 #define SDF_NCOL (SDF_G * SDF_G)   // 1024 columns (k,j)
-#define SDF_RAYQ 4096               // (triangle, needed column) pairs per window of the prep kernel's ray-parity queue (a hand has ~1000)
+#define SDF_RAYQ 3072               // (triangle, needed column) pairs per window of the prep kernel's ray-parity queue (a hand has ~440, the largest
+                                    // seen 2 900; more take a second window).  Round 6: 4096 -> 3072, the 4 KB hold the queries' cell words
 #define SDF_NXCD 8                 // MI355X: 8 XCDs, workgroup b runs on XCD b % 8 (speed only, never correctness)
 #ifndef SDF_DIST_WG_PER_CU
 #define SDF_DIST_WG_PER_CU 4          // sdf_dist_kernel: 40 KB LDS, <= 128 VGPRs; its grid is persistent: this many workgroups per CU
@@ -204,25 +205,6 @@ struct VertLayout {
     __device__ __forceinline__ const float* hand(int b, int hnd) const { return base + b * stride_b + hnd * stride_h; }
 };
 
-// grid_sample un-normalisation: align_corners = False: ((x + 1) * G - 1) / 2;  True: (x + 1) / 2 * (G - 1)   (torch's expressions)
-__device__ __forceinline__ float sdf_unnorm(float x, int align_corners) {
-    return align_corners ? ((x + 1.0f) / 2.0f) * (float)(SDF_G - 1) : ((x + 1.0f) * (float)SDF_G - 1.0f) / 2.0f;
-}
-
-// a / b, correctly rounded (the bits of the IEEE division the oracle's `(v - c) / s` performs), for MANY numerators over ONE divisor:
-// with y = RN(1 / b) (one IEEE division per hand), q0 = RN(a y), r = a - b q0 (exact in one fma), RN(q0 + r y) is the correctly rounded
-// quotient (Markstein's theorem; checked against exact rational arithmetic on 2 x 10^5 random pairs, scripts/experiments/markstein_division.py)
-// -- three instructions instead of the ~10 of the division expansion, six times per vertex pair.  Needs b and the results in the normal
-// range: the caller takes this path only for a box scale in [1e-6, 1e6] (else the plain division: degenerate hands keep the oracle's infs / NaNs).
-struct SdfDivisor { float b, y; bool fast; };
-__device__ __forceinline__ SdfDivisor sdf_divisor(float b) { return SdfDivisor{b, 1.0f / b, b >= 1e-6f && b <= 1e6f}; }
-__device__ __forceinline__ float sdf_div(float a, const SdfDivisor& d) {
-    if (!d.fast) return a / d.b;             // (uniform per hand)
-    const float q0 = a * d.y;
-    const float r = __builtin_fmaf(-d.b, q0, a);
-    return __builtin_fmaf(r, d.y, q0);
-}
-
 // Workgroup barrier for phases that hand over LDS data only: waits for this wave's LDS operations, NOT for its global
 // stores (a __syncthreads() carries a workgroup-scope release fence, i.e. s_waitcnt vmcnt(0): every barrier of the prep
 // kernel would wait a full L2 round trip for the triangle records / phi stores issued before it)
@@ -276,17 +258,6 @@ __device__ __forceinline__ int block_excl_scan_1024(int* data, int* scratch /* >
     return total;
 }
 
-__device__ __forceinline__ void tri_col_range(float y0, float y1, float y2, float z0, float z1, float z2, int& j0, int& j1,
-                                              int& k0, int& k1) {
-    // columns whose ray (py, pz) can cross the triangle: centres inside the yz bounding box (+ margin)
-    const float ymin = fminf(y0, fminf(y1, y2)) - 1e-4f, ymax = fmaxf(y0, fmaxf(y1, y2)) + 1e-4f;
-    const float zmin = fminf(z0, fminf(z1, z2)) - 1e-4f, zmax = fmaxf(z0, fmaxf(z1, z2)) + 1e-4f;
-    j0 = max(0, (int)ceilf((ymin + 1.0f) * 16.0f - 0.5f));
-    j1 = min(SDF_G - 1, (int)floorf((ymax + 1.0f) * 16.0f - 0.5f));
-    k0 = max(0, (int)ceilf((zmin + 1.0f) * 16.0f - 0.5f));
-    k1 = min(SDF_G - 1, (int)floorf((zmax + 1.0f) * 16.0f - 0.5f));
-}
-
 // Phase stamps (experiment builds only: -DSDF_STAMPS=1 list search, =2 full search; scripts/sdf_stamps.py): shader-clock time per
 // phase of a work item, summed per wave into the spare counter slots 9..15
 #ifdef SDF_STAMPS
@@ -316,61 +287,6 @@ __device__ unsigned g_handlog_n = 0, g_handlog_cap = 0;
 //      column's needed voxels, XOR-ed into the column's parity word (LDS atomic; XOR is order-free)
 //   -> phi = 0 for outside voxels, inside voxels appended to the batch-wide list.
 // Triangle-parallel on purpose: no per-column triangle lists, no dependent LDS chains, balanced lanes.
-// t of the +x ray from voxel centre i of a column against one triangle (already known to pass the (u,v) test).
-// Same operation order as oracle/sdf_grid.c ray_hit_px.
-__device__ __forceinline__ float sdf_ray_t(int i, float ax, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
-                                           float inv, float sy, float sz, float qx) {
-    const float px = (float)(2 * i + 1) / (float)SDF_G - 1.0f;
-    const float sx = px - ax;
-    const float qy = __builtin_fmaf(sz, e1x, -(sx * e1z));
-    const float qz = __builtin_fmaf(sx, e1y, -(sy * e1x));
-    return DOT3(e2x, e2y, e2z, qx, qy, qz) * inv;
-}
-
-// t > 0 test of the needed voxels of one column; returns the hit mask, bit for bit what evaluating sdf_ray_t for
-// every needed voxel gives -- without the per-voxel loop.  In real arithmetic t_i = x* - px_i: it falls by exactly
-// 1/16 per voxel (up to the rounding of det and 1/det, delta below), so one evaluation at the lowest needed
-// voxel places the crossing index ic = lo + 16 t_lo.  Voxels a whole index away from ic have |t| >= 1/16, far
-// above the rounding error E of the float expression (bounded per triangle by sdf_ray_tri_safe), so their sign is known;
-// the (at most two) voxels next to the crossing are evaluated with the exact expression.  Whenever the bound
-// does not hold (near-degenerate triangles: huge 1/det) every needed voxel is evaluated.
-// Per-triangle part of the error bound of sdf_ray_hits: true iff, for EVERY column and voxel of the grid, the float
-// expression of t differs from the real one by well under a voxel step.  |float t - real t| <= E = 16 u S |1/det| with
-// S the sum of the magnitudes of the terms (|s| <= 2 anywhere in the [-1,1]^3 grid), and the real slope of t
-// along x is -(1 + delta)/16 with |delta| <= 4 u (|e1z e2y| + |e1y e2z|) |1/det| + 4 u  (rounding of det and 1/det).
-__device__ __forceinline__ bool sdf_ray_tri_safe(float e1x, float e1y, float e1z, float e2x, float e2y, float e2z, float inv) {
-    const float U = 5.9604645e-8f;   // 2^-24
-    const float ainv = fabsf(inv), smax = 2.0f;
-    const float qx_max = smax * (fabsf(e1z) + fabsf(e1y));
-    const float S = fabsf(e2x) * qx_max + fabsf(e2y) * smax * (fabsf(e1x) + fabsf(e1z)) + fabsf(e2z) * smax * (fabsf(e1y) + fabsf(e1x));
-    const float E = 16.0f * U * S * ainv;
-    const float delta = 4.0f * U * (fabsf(e1z * e2y) + fabsf(e1y * e2z)) * ainv + 4.0f * U;
-    return E + 2.0f * delta < (1.0f / 64.0f);
-}
-
-__device__ __forceinline__ unsigned sdf_ray_hits(unsigned need, bool tri_safe, float ax, float e1x, float e1y, float e1z, float e2x,
-                                                 float e2y, float e2z, float inv, float sy, float sz, float qx) {
-    const int lo = __ffs((int)need) - 1;
-    const float t_lo = sdf_ray_t(lo, ax, e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx);
-    if (!tri_safe) {
-        unsigned hits = 0, rem = need;
-        while (rem) {
-            const int i = __ffs((int)rem) - 1;
-            rem &= rem - 1;
-            if (sdf_ray_t(i, ax, e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx) > 0.0f) hits |= 1u << i;
-        }
-        return hits;
-    }
-    const float ic = fminf(fmaxf((float)lo + 16.0f * t_lo, -2.0f), 34.0f);
-    const int i1 = (int)floorf(ic), i2 = i1 + 1;
-    unsigned hits = need & (i1 <= 0 ? 0u : (i1 >= 32 ? 0xffffffffu : ((1u << i1) - 1u)));   // voxels below the crossing: t > 0
-    if (i1 >= 0 && i1 < SDF_G && ((need >> i1) & 1u) &&
-        sdf_ray_t(i1, ax, e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx) > 0.0f) hits |= 1u << i1;
-    if (i2 >= 0 && i2 < SDF_G && ((need >> i2) & 1u) &&
-        sdf_ray_t(i2, ax, e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx) > 0.0f) hits |= 1u << i2;
-    return hits;
-}
-
 #ifndef SDF_PREP_MIN_WAVES
 #define SDF_PREP_MIN_WAVES 8       // 64 vector registers.  The kernel must not SPILL at this budget (scripts/isa.sh; tests/test_host_cpu.py checks the
 #endif                             // built code object): round 6 found the 512-thread form with scratch spills faulting behind the tail launch
@@ -392,6 +308,8 @@ __global__ __launch_bounds__(PT, SDF_PREP_MIN_WAVES) void sdf_prep_kernel(VertLa
     __shared__ int scratch[PT / WAVE];
     __shared__ unsigned rayq[SDF_RAYQ];            // (triangle | column << 11) pairs of the ray-parity phase (carrying the packed corner
                                                    // ids instead of the triangle, 8 bytes per pair, is slower: 44.0 -> 47.1 us per 1024 hands)
+    __shared__ unsigned cellw[DENSE ? 1 : SDF_NV4];   // the grid cell of every query (the other hand's vertices), kept from the normalise phase to the
+                                                      // end of the kernel, where the inside mask of the cell's corners is known (qcell)
     __shared__ int blk_inside, blk_base, blk_base_a;
     const int H = blockIdx.x, hnd = H / B, b = H % B, tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
     SDF_TK(long long pk_[8]; pk_[0] = SDF_STAMP();)
@@ -505,10 +423,9 @@ __global__ __launch_bounds__(PT, SDF_PREP_MIN_WAVES) void sdf_prep_kernel(VertLa
             // completely outside the grid (or non-finite): contributes nothing
             const bool in_grid = fx >= -1.0f && fx <= (float)(SDF_G - 1) && fy >= -1.0f && fy <= (float)(SDF_G - 1) && fz >= -1.0f &&
                                  fz <= (float)(SDF_G - 1);
-            // the query's cell for the fused sampler (entry hnd * 778 + v of sample b)
-            // (the inside mask of the cell's eight corners is added at the end of the kernel, when the inside words are known)
-            ws.qcell[((size_t)b * 2 + hnd) * NV + v] =
-                in_grid ? (SDF_QCELL_IN | (unsigned)((int)fx + 1) | ((unsigned)((int)fy + 1) << 6) | ((unsigned)((int)fz + 1) << 12)) : 0u;
+            // the query's cell for the fused sampler (entry hnd * 778 + v of sample b): parked in LDS; written to qcell at the end of
+            // the kernel together with the inside mask of the cell's eight corners
+            cellw[v] = in_grid ? (SDF_QCELL_IN | (unsigned)((int)fx + 1) | ((unsigned)((int)fy + 1) << 6) | ((unsigned)((int)fz + 1) << 12)) : 0u;
             if (in_grid) {
                 const int i0 = (int)fx, j0 = (int)fy, k0 = (int)fz;
                 unsigned mi = 0;
@@ -687,22 +604,11 @@ __global__ __launch_bounds__(PT, SDF_PREP_MIN_WAVES) void sdf_prep_kernel(VertLa
                 const float a[3] = {vn[3 * fa], vn[3 * fa + 1], vn[3 * fa + 2]};
                 const float bb[3] = {vn[3 * fb], vn[3 * fb + 1], vn[3 * fb + 2]};
                 const float c[3] = {vn[3 * fc], vn[3 * fc + 1], vn[3 * fc + 2]};
-                const float e1x = bb[0] - a[0], e1y = bb[1] - a[1], e1z = bb[2] - a[2];
-                const float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
-                const float det = __builtin_fmaf(e1z, e2y, -(e1y * e2z));
-                const float inv = 1.0f / det;
-                const int j = col & (SDF_G - 1), k = col >> 5;
-                const float py = (float)(2 * j + 1) / (float)SDF_G - 1.0f;
-                const float pz = (float)(2 * k + 1) / (float)SDF_G - 1.0f;
                 const unsigned need = nmask[col];
-                const float sy = py - a[1], sz = pz - a[2];
-                const float uu = __builtin_fmaf(sz, e2y, -(sy * e2z)) * inv;
-                const float qx = __builtin_fmaf(sy, e1z, -(sz * e1y));
-                const float vv = qx * inv;
+                bool uv_pass;
+                const unsigned hits = sdf_ray_column_hits(a, bb, c, col, need, uv_pass);       // (ihmr_pure.h)
                 st_tests += 1;
-                if (!((uu >= 0.0f) && (uu <= 1.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f))) continue;
-                const bool tri_safe = sdf_ray_tri_safe(e1x, e1y, e1z, e2x, e2y, e2z, inv);
-                const unsigned hits = sdf_ray_hits(need, tri_safe, a[0], e1x, e1y, e1z, e2x, e2y, e2z, inv, sy, sz, qx);
+                if (!uv_pass) continue;
                 st_tests += __popc(need);
                 if (hits) atomicXor(&parity[col], hits);
             }
@@ -807,15 +713,15 @@ __global__ __launch_bounds__(PT, SDF_PREP_MIN_WAVES) void sdf_prep_kernel(VertLa
     // ---- the fused sampler's cell words (round 6): the query's cell AND which of its eight corners hold a distance (bits 18-25: corner
     //      2 c4 + di, c4 = (j - j0) + 2 (k - k0)) -- the inside words of the four columns are in LDS here (the scan's barriers have
     //      published them).  The sampler of the tail launch then needs neither the hand's 4 KB bitmap nor a workgroup barrier before
-    //      it can request the phi values: one dependent round trip fewer per iteration.  The cell word is read back from where the
-    //      normalise phase stored it (this thread's own store, program order) instead of a register held across the ray-parity phase.
+    //      it can request the phi values: one dependent round trip fewer per iteration.  The cell word waited in LDS (this thread's
+    //      own slot) instead of a register held across the ray-parity phase.
     if (!DENSE) {
         unsigned* const qc = ws.qcell + ((size_t)b * 2 + hnd) * NV;
 #pragma unroll
         for (int rep = 0; rep < VPT; ++rep) {
             const int v = tid + rep * PT;
             if (v < NV) {
-                const unsigned c = qc[v];
+                const unsigned c = cellw[v];
                 unsigned m = 0u;
                 if (c & SDF_QCELL_IN) {
                     const int i0 = (int)(c & 63u) - 1, j0 = (int)((c >> 6) & 63u) - 1, k0 = (int)((c >> 12) & 63u) - 1;
@@ -828,8 +734,8 @@ __global__ __launch_bounds__(PT, SDF_PREP_MIN_WAVES) void sdf_prep_kernel(VertLa
                             m |= (b0 << (2 * c4)) | (b1 << (2 * c4 + 1));
                         }
                     }
-                    qc[v] = c | (m << SDF_QCELL_MASK_SHIFT);
                 }
+                qc[v] = c | (m << SDF_QCELL_MASK_SHIFT);
             }
         }
     }
@@ -908,53 +814,6 @@ __global__ __launch_bounds__(PT, SDF_PREP_MIN_WAVES) void sdf_prep_kernel(VertLa
     }
 }
 
-// squared distance point -> triangle, closest point by Voronoi region.  Same values, operation for
-// operation, as oracle/sdf_grid.c point_tri_dist2 -- but branch-free: the region is a priority select, the
-// (at most one) quotient every region needs goes through ONE IEEE division, and the closest point is
-// q = fma(dir2, t2, fma(dir1, t1, base)) with zeros where a region has fewer terms (fma(x, 0, y) == y exactly).
-__device__ __forceinline__ float sdf_point_tri_dist2(const float* a, const float* b, const float* c, float px, float py,
-                                                     float pz) {
-    const float abx = b[0] - a[0], aby = b[1] - a[1], abz = b[2] - a[2];
-    const float acx = c[0] - a[0], acy = c[1] - a[1], acz = c[2] - a[2];
-    const float apx = px - a[0], apy = py - a[1], apz = pz - a[2];
-    const float d1 = DOT3(abx, aby, abz, apx, apy, apz);
-    const float d2 = DOT3(acx, acy, acz, apx, apy, apz);
-    const float bpx = px - b[0], bpy = py - b[1], bpz = pz - b[2];
-    const float d3 = DOT3(abx, aby, abz, bpx, bpy, bpz);
-    const float d4 = DOT3(acx, acy, acz, bpx, bpy, bpz);
-    const float vc = __builtin_fmaf(d1, d4, -(d3 * d2));
-    const float cpx = px - c[0], cpy = py - c[1], cpz = pz - c[2];
-    const float d5 = DOT3(abx, aby, abz, cpx, cpy, cpz);
-    const float d6 = DOT3(acx, acy, acz, cpx, cpy, cpz);
-    const float vb = __builtin_fmaf(d5, d2, -(d1 * d6));
-    const float va = __builtin_fmaf(d3, d6, -(d5 * d4));
-    const float d43 = d4 - d3, d56 = d5 - d6;
-    const bool r0 = (d1 <= 0.0f) && (d2 <= 0.0f);
-    const bool r1 = !r0 && (d3 >= 0.0f) && (d4 <= d3);
-    const bool r2 = !r0 && !r1 && (vc <= 0.0f) && (d1 >= 0.0f) && (d3 <= 0.0f);
-    const bool r3 = !r0 && !r1 && !r2 && (d6 >= 0.0f) && (d5 <= d6);
-    const bool r4 = !r0 && !r1 && !r2 && !r3 && (vb <= 0.0f) && (d2 >= 0.0f) && (d6 <= 0.0f);
-    const bool r5 = !r0 && !r1 && !r2 && !r3 && !r4 && (va <= 0.0f) && (d43 >= 0.0f) && (d56 >= 0.0f);
-    const bool r6 = !(r0 || r1 || r2 || r3 || r4 || r5);
-    const float num = r2 ? d1 : (r4 ? d2 : (r5 ? d43 : (r6 ? 1.0f : 0.0f)));
-    const float den = r2 ? (d1 - d3) : (r4 ? (d2 - d6) : (r5 ? (d43 + d56) : (r6 ? (va + vb + vc) : 1.0f)));
-    const float t = num / den;
-    const float t1 = r6 ? vb * t : ((r2 || r4 || r5) ? t : 0.0f);
-    const float t2 = r6 ? vc * t : 0.0f;
-    const bool base_b = r1 || r5, base_c = r3;
-    const float bx = base_b ? b[0] : (base_c ? c[0] : a[0]);
-    const float by = base_b ? b[1] : (base_c ? c[1] : a[1]);
-    const float bz = base_b ? b[2] : (base_c ? c[2] : a[2]);
-    const float d1x = r4 ? acx : (r5 ? c[0] - b[0] : abx);
-    const float d1y = r4 ? acy : (r5 ? c[1] - b[1] : aby);
-    const float d1z = r4 ? acz : (r5 ? c[2] - b[2] : abz);
-    const float qx = __builtin_fmaf(acx, t2, __builtin_fmaf(d1x, t1, bx));
-    const float qy = __builtin_fmaf(acy, t2, __builtin_fmaf(d1y, t1, by));
-    const float qz = __builtin_fmaf(acz, t2, __builtin_fmaf(d1z, t1, bz));
-    const float dx = px - qx, dy = py - qy, dz = pz - qz;
-    return DOT3(dx, dy, dz, dx, dy, dz);
-}
-
 // ------------------------------------------------------------------------------------- distance kernel: shared pieces
 // Both searches of sdf_dist_kernel work the same way on a wave's current voxels (slots): conservative culling against the hand's
 // table in LDS -> dense (slot, triangle) pairs in the wave's queue -> sdf_refine_pairs (plane + circle bound) -> sdf_exact_pairs
@@ -975,11 +834,6 @@ __device__ __forceinline__ SdfWaveLds sdf_wave_lds(char* smem, int wave) {
     char* p = smem + NFP * 16 + SDF_NRM_N * 4 + wave * SDF_WAVE_LDS;
     return SdfWaveLds{reinterpret_cast<unsigned*>(p), reinterpret_cast<unsigned long long*>(p + SDF_QCAP * 4),
                       reinterpret_cast<unsigned short*>(p + SDF_QCAP * 4 + SDF_VSLOTS * 8)};
-}
-__device__ __forceinline__ void sdf_vox_centre(int id, float& x, float& y, float& z) {
-    x = (float)(2 * (id & 31) + 1) / (float)SDF_G - 1.0f;
-    y = (float)(2 * ((id >> 5) & 31) + 1) / (float)SDF_G - 1.0f;
-    z = (float)(2 * (id >> 10) + 1) / (float)SDF_G - 1.0f;
 }
 // LDS hand-off between the lanes of one wave (DS operations of a wave execute in order; the fences only pin the compiler)
 #define SDF_WAVE_SYNC()                                              \

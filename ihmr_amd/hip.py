@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "ihmr_mano_create", "ihmr_mano_destroy", "ihmr_mano_update_shapedirs", "ihmr_mano_workspace_bytes", "ihmr_mano_lbs_fwd",
     "ihmr_mano_lbs_bwd",
     "ihmr_sdf_workspace_bytes", "ihmr_sdf_collision", "ihmr_sdf_collision_ex", "ihmr_sdf_dense_grid", "ihmr_opt_workspace_bytes",
-    "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_opt_sdf_stats", "ihmr_opt_sdf_counters", "ihmr_opt_stage_graph_create",
+    "ihmr_opt_run_stage", "ihmr_opt_forward_losses", "ihmr_opt_sdf_stats", "ihmr_opt_sdf_counters", "ihmr_opt_sdf_inside_bits", "ihmr_opt_stage_graph_create",
     "ihmr_opt_forward_graph_create", "ihmr_graph_launch", "ihmr_graph_destroy", "ihmr_opt_set_params", "ihmr_eval_metrics", "ihmr_eval_mpvpe", "ihmr_conv_igemm", "ihmr_maxpool3x3s2",
     "ihmr_avgpool_relu", "ihmr_preprocess_images", "ihmr_mlp_train_grad", "ihmr_transpose", "ihmr_relu_backward", "ihmr_colsum",
     "ihmr_adam_step", "ihmr_bn_workspace_bytes", "ihmr_bn_train_forward", "ihmr_bn_train_backward", "ihmr_conv_wgrad",
@@ -292,6 +292,7 @@ def lib():
         L.ihmr_preprocess_images.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp]
         L.ihmr_opt_sdf_stats.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), vp, vp]
         L.ihmr_opt_sdf_counters.argtypes = [C.POINTER(OptIO), i, vp, i]
+        L.ihmr_opt_sdf_inside_bits.argtypes = [C.POINTER(OptIO), i, vp, vp]
         L.ihmr_set_kernel_timer.argtypes = [C.POINTER(KernelTimer)]
         L.ihmr_flush_kernel_timer.argtypes = []
         L.ihmr_copy_segments.argtypes = [C.POINTER(CopySeg), i, vp]

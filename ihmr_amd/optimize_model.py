@@ -246,6 +246,14 @@ class OptimizeModel:
         self._drop_graphs()
         return {k: int(out[i]) for i, k in enumerate(self.SDF_COUNTERS)}
 
+    def sdf_inside_bits(self):
+        """Diagnostics (synchronises): the inside-voxel bitmaps (2, B, 1024) uint32 and boxes (2, B, 4) the collision kernels of the
+        last launch left in the workspace (``ihmr_opt_sdf_inside_bits``)."""
+        B = self.batch_size
+        bits, box = np.zeros((2, B, 1024), np.uint32), np.zeros((2, B, 4), np.float32)
+        hip.check(hip.lib().ihmr_opt_sdf_inside_bits(C.byref(self.io), B, bits.ctypes.data, box.ctypes.data), "ihmr_opt_sdf_inside_bits")
+        return bits, box
+
     def run_stage(self, stage):
         sg = stage_to_args(stage, self.optimizer, self.save_mid_freq)
         if (sg.n_iters - 1) // sg.save_freq + 1 > self.S_max:

@@ -226,6 +226,13 @@ int ihmr_opt_sdf_stats(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_o
  * 6 unused}. */
 int ihmr_opt_sdf_counters(const ihmr_opt_io* io, int B, unsigned long long* out16, int enable);
 
+/* diagnostics of the fused loop (synchronises): the inside-voxel bitmaps the collision kernels of the LAST launch left in the
+ * workspace -- out (host) [2][B][1024] words, hand-major (right hands first), bit i of word (k * 32 + j): voxel (k, j, i) of that
+ * hand's grid is read by its sample AND lies inside the mesh -- and the hands' boxes, box (host) [2][B][4] = centre xyz, scale.
+ * What tests/test_gpu_parity.py counts when it puts numbers on the kept grid of a translated hand: voxels whose
+ * inside / outside status differs between the kept grid and a from-scratch evaluation.  (No counterpart in the reference.) */
+int ihmr_opt_sdf_inside_bits(const ihmr_opt_io* io, int B, unsigned* out, float* box);
+
 /* ------------------------------------------------------------------ image encoder (ResNet-50 + heads) */
 /* One Conv2d / Linear of `InterHandEncoder.forward` (models/networks.py:66-80, models/resnet.py:138-156) as an
  * implicit GEMM on the fp32 matrix cores: y[M = N*Ho*Wo][Cout] = act(A(x) . w + bias (+ residual)).

@@ -1156,6 +1156,67 @@ def _translated_reuse_diff(batch, B, epoch, strategy):
     return worst
 
 
+@pytest.mark.parametrize("asset", ["mitten", "fingers"])
+@pytest.mark.parametrize("B,epoch", [(16, 39), (64, 49)])
+def test_translated_hand_reuse_in_numbers(mano_arrays, finger_arrays, asset, B, epoch):
+    """Round 6 (review item 5): numbers on the one default-on acceleration that is not exact.  Sixteen batches per asset (the blob and
+    the five-finger mesh with interlocked hands) and size (16 ragged, 64): the full schedule + a camera + translation stage with the kept
+    grid (default) against `opt.sdf_no_translated_reuse`, counting
+      * (stage, sample) pairs that select another snapshot,
+      * stored snapshot losses that differ at all, and by how much (relative),
+      * after the translation stage alone (its 50th iteration: the kept grid is then 49 iterations old) the voxels of the left hands'
+        grids whose inside / outside status differs from the from-scratch evaluation of the same iteration (`ihmr_opt_sdf_inside_bits`).
+    A rounding-level change of the normalised vertices can in principle move a voxel centre across the surface, and a 1-ulp snapshot
+    loss can flip a `<=` filter: asserted here that on these 64 batches neither happens (0 flips, 0 voxels), and that every export stays
+    within 5e-6; the counts are printed for DESIGN.md section 5.0."""
+    from helpers import ragged_opt_batch
+    from ihmr_amd.optimize_model import OptimizeModel
+    from ihmr_amd.strategies import make_opt_strategy
+    arrays = finger_arrays if asset == "fingers" else mano_arrays
+    base = make_opt_strategy(epoch)
+    st = dict(base[0]); st["update_params"] = ["pred_cam_params", "pred_hand_trans"]
+    models = []
+    for off in (False, True):
+        opt = _make_opt(B, epoch=epoch, save_mid_freq=5, model_root="synthetic:fingers" if asset == "fingers" else "")
+        opt.sdf_no_translated_reuse = off
+        m = OptimizeModel(opt)
+        m.strategy = base + [st]
+        models.append(m)
+    flips = pairs = loss_diff = loss_n = vox_diff = vox_n = 0
+    worst_ulp, worst, worst_abs = 0.0, 0.0, 0.0
+    for seed in range(9000, 9016):
+        _, batch = _two_hand_verts(arrays, B, seed + B, interlock=asset == "fingers")
+        if B == 16:
+            batch = ragged_opt_batch(batch)
+        res = []
+        for m in models:
+            m.set_input(batch); m.init_optimize(); m.run_stage(m.strategy[0])
+            bits, box = m.sdf_inside_bits()
+            m.set_input(batch); m.init_optimize(); m.optimize()
+            torch.cuda.synchronize()
+            res.append((m.get_pred_result(), torch.stack(m.selected_history).cpu().numpy(), m.buf["snap_loss"].cpu().numpy().copy(), bits, box))
+        (a, sa, la, ba, xa), (b, sb, lb, bb, xb) = res
+        flips += int((sa != sb).sum()); pairs += sa.size
+        d = np.abs(la.astype(np.float64) - lb.astype(np.float64))
+        loss_diff += int((d != 0).sum()); loss_n += d.size
+        worst_ulp = max(worst_ulp, float((d / np.maximum(np.abs(la), 1e-30)).max()))      # (relative, not in units of the last place: see below)
+        worst_abs = max(worst_abs, float(d.max()))
+        x = ba ^ bb
+        vox_diff += int(sum(bin(int(w)).count("1") for w in x[x != 0])); vox_n += int(sum(bin(int(w)).count("1") for w in (ba | bb)[(ba | bb) != 0]))
+        assert np.array_equal(xa[0], xb[0]) and np.abs(xa[1] - xb[1]).max() <= 1e-6          # (right hands: static either way; left boxes: rounding)
+        for k in ("pred_cam_params", "pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "pred_left_hand_verts",
+                  "pred_joints_3d", "collision_loss_origin_scale"):
+            worst = max(worst, float(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max()))
+    print(f"[parity] translated-hand reuse in numbers ({asset}, B {B}, 16 batches): selection flips {flips} of {pairs} (stage, sample) pairs; "
+          f"stored snapshot losses that differ {loss_diff} of {loss_n} (worst relative difference {worst_ulp:.1e}, absolute {worst_abs:.1e}); inside / outside "
+          f"status after the translation stage: {vox_diff} of {vox_n} inside voxels differ; worst export difference {worst:.2e}")
+    # the stored collision losses of the translation stages are sums of penetration depths (normalised units) evaluated from coordinates
+    # that differ in their last bits: every depth moves by ~1e-7, the voxel SET is the same
+    # (bound, in the loss's own units -- normalised grid lengths: 5e-6, i.e. ~50 sampled depths each off by one rounding of a coordinate;
+    # relative to a loss that is itself ~1e-4 for a pair that barely touches this can be percents)
+    assert flips == 0 and vox_diff == 0 and worst <= 5e-6 and worst_abs <= 5e-6, (flips, vox_diff, worst, worst_abs, worst_ulp)
+
+
 @pytest.mark.parametrize("B,optimizer", [(16, "adam"), (64, "adam"), (9, "sgd")])
 def test_fused_tail_launch_does_not_change_a_bit(mano_arrays, B, optimizer):
     """The stages that do not move the finger pose run the tail of an iteration -- collision sampling + losses, the LBS backward of
