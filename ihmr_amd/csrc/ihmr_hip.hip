@@ -309,6 +309,24 @@ extern "C" int ihmr_mano_lbs_bwd(const ihmr_mano* m, int N, const void* workspac
 
 // ------------------------------------------------------------------------------------------ seam B
 // (tail: the SoA and the packed copies of the caller's two face arrays)
+// Compute units of the CURRENT device, cached per device id in relaxed atomics (concurrent first calls store the same value: no lock, no
+// data race).  The persistent grid of sdf_dist_kernel and the Stream-K worker count of ihmr_conv_igemm derive from it; the latter fixes
+// the K partition, so results are bit-stable per device MODEL (same CU count), not across models.
+#include <atomic>
+static int device_cu_count(int* cus_out) {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    int cus = cache[dev & 63].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (cus <= 0) cus = 256;
+        cache[dev & 63].store(cus, std::memory_order_relaxed);
+    }
+    *cus_out = cus;
+    return 0;
+}
+
 extern "C" size_t ihmr_sdf_workspace_bytes(int B) { return sdf_ws_bytes(2 * B) + (size_t)2 * NFP * 4 * 4 + 256; }
 
 static int g_collect_stats = 0;
@@ -335,15 +353,9 @@ static int sdf_launch(const VertLayout& vl, const int32_t* faces_r_soa, const in
         hipLaunchKernelGGL((sdf_prep_kernel<false, SDF_PREP_THREADS_LARGE>), dim3(2 * B), dim3(SDF_PREP_THREADS_LARGE), 0, st, vl, B, faces_r_soa,
                            faces_l_soa, ws, g_collect_stats);
     // persistent grid: as many workgroups as the GPU holds at once; they pull work units from a queue (sdf_collision.h)
-    static int dist_blocks_dev[64] = {0};         // per device id (a process may drive GPUs with different CU counts)
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    int& dist_blocks = dist_blocks_dev[dev & 63];
-    if (dist_blocks == 0) {
-        int cus = 0;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        dist_blocks = SDF_DIST_WG_PER_CU * (cus > 0 ? cus : 256);
-    }
+    int cus = 0;
+    if (int rc = device_cu_count(&cus)) return rc;
+    const int dist_blocks = SDF_DIST_WG_PER_CU * cus;
     if (timed) { if (int rc = timed_next(&tcur, IHMR_TIMED_SDF_PREP, st)) return rc; }
     int nblk = dist_blocks;
 #ifdef IHMR_TUNING_BUILD
@@ -796,15 +808,9 @@ extern "C" int ihmr_conv_igemm(const float* x, const float* w, const float* bias
     // 90-155 -> 77-141 us; with 32 K steps the fix-up's traffic eats the gain (85 -> 88 us), so those keep one workgroup per tile.
     // Workers: two per CU of THIS device, a multiple of 8 (conv_streamk_kernel numbers them by XCD), at most 512 (the workspace
     // contract of include/ihmr_hip.h: two 64 KB tile slots per worker = 64 MiB)
-    static int sk_workers_dev[64] = {0};
-    int sk_dev = 0;
-    HIP_TRY(hipGetDevice(&sk_dev));
-    if (sk_workers_dev[sk_dev & 63] == 0) {
-        int cus = 0;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sk_dev));
-        sk_workers_dev[sk_dev & 63] = std::max(8, std::min(512, 2 * (cus > 0 ? cus : 256) / 8 * 8));
-    }
-    int sk_workers = sk_workers_dev[sk_dev & 63], sk_max_tiles = 768, sk_min_nk = 64;
+    int sk_cus = 0;
+    if (int rc = device_cu_count(&sk_cus)) return rc;
+    int sk_workers = std::max(8, std::min(512, 2 * sk_cus / 8 * 8)), sk_max_tiles = 768, sk_min_nk = 64;
 #ifdef IHMR_TUNING_BUILD
     if (const char* f = getenv("IHMR_CONV_SK")) {   // "<max tiles> <min K steps> <workers>"
         sscanf(f, "%d %d %d", &sk_max_tiles, &sk_min_nk, &sk_workers);

@@ -247,7 +247,8 @@ int ihmr_opt_sdf_inside_bits(const ihmr_opt_io* io, int B, unsigned* out, float*
  * workspace_bytes >= workers x 128 KiB (two 64 KB tile slots per worker; workers = two per CU of the device, a multiple of 8, at most
  * 512: 64 MiB on an MI355X -- exactly what the launcher checks): the workers share tiles x K steps evenly and a fix-up launch adds
  * a tile's pieces in ascending K order.  A caller with a smaller workspace gets the split-K form (different last bits, see below).  Every form sums in a fixed order: results are bit-identical from run to run; they differ between
- * forms (i.e. with and without a workspace) in the last bits. */
+ * forms (i.e. with and without a workspace) in the last bits -- and, because the worker count follows the device's CU count and fixes
+ * the K partition, between device MODELS: bit-stable per model, not across them. */
 int ihmr_conv_igemm(const float* x, const float* w, const float* bias, const float* residual, float* y, int N, int H, int W,
                     int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int ldx, int ldw, int ldy, int ldr,
                     int act, void* workspace, size_t workspace_bytes, void* stream);
@@ -377,8 +378,8 @@ int ihmr_preprocess_images(const uint8_t* pixels, const int64_t* offsets, const 
                            int B, int final_size, float* img_out, uint8_t* img_u8, const float* joints_in,
                            float* joints_out, void* stream);
 
-/* per-kernel timing hook for bench.py -- the ONE piece of PROCESS-GLOBAL state of this library (everything else is stateless apart
- * from the model handle): the timer pointer and the pending event pairs are shared by every stream and every thread of the process
+/* per-kernel timing hook for bench.py -- the ONE piece of mutable PROCESS-GLOBAL state of this library (everything else is stateless
+ * apart from the model handle and a per-device cache of the CU count, relaxed atomics: concurrent first calls store the same value): the timer pointer and the pending event pairs are shared by every stream and every thread of the process
  * (a mutex makes concurrent callers safe, it does not separate their measurements); callers that do not set a timer never touch it.
  * When non-NULL, the library records hipEvents on the launch stream around the three
  * large kernels of a refinement iteration and accumulates here (host pointer, read after ihmr_flush_kernel_timer()):

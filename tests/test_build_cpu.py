@@ -50,6 +50,17 @@ def test_loop_collision_kernels_do_not_spill(tmp_path):
         get = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", body).group(1))
         seen[name] = (get("vgpr_count"), get("vgpr_spill_count"), get("private_segment_fixed_size"))
     assert len(seen) >= 3, list(seen)
+    # the staging wait of sdf_list_item (SDF_STAGE_CLOSE_KEEP1: `s_waitcnt vmcnt(1)` + barrier) is correct only while the wave's YOUNGEST
+    # vector-memory operation at that point is the map-word prefetch -- a plain load issued after the table's LDS-DMA pieces -- and not
+    # a DMA piece, a spill reload or a store (advisor, round 5): in the built code the nearest memory instruction before every such
+    # wait must be that 8-byte global load
+    body = text[text.index("_Z15sdf_dist_kernelILb0EEv12SdfWorkspace:"):]
+    body = body[:body.index("s_endpgm")].splitlines()
+    waits = [i for i, l in enumerate(body) if "s_waitcnt vmcnt(1)" in l and any("s_barrier" in x for x in body[i + 1:i + 6])]
+    assert waits, "no vmcnt(1) staging wait found in sdf_dist_kernel"
+    for i in waits:
+        prev = next(l for l in reversed(body[:i]) if re.search(r"\b(global_|scratch_|buffer_|flat_)(load|store|atomic)", l))
+        assert "global_load_dwordx2" in prev and "lds" not in prev, prev
     for name, (vgpr, spill, scratch) in seen.items():
         print(f"[build] {name[:60]}: {vgpr} VGPRs, {spill} spilled, {scratch} B scratch")
         assert spill == 0 and scratch == 0, (name, vgpr, spill, scratch)
