@@ -248,21 +248,26 @@ def kernel_models(kernel, hands, st):
         return (hands * HAND_TABLE_BYTES + st["inside_voxels"] * (4 + 8 + 384 + 4),
                 11.0 * st["sphere_tests"] + 30.0 * st["plane_tests"] + 75.0 * st["dist_evals"])
     if kernel == "sdf_prep_kernel":
-        # reads both hands' vertices (own: box + normalisation, other: needed-voxel mask) and the lists' reference pose + bitmap
-        # (9.3 + 4 KB); writes the hand's tables and box and (round 5) the 778 cell words of the other hand's queries; per needed voxel
-        # 4 B (phi = 0 or a work-list entry);
+        # a hand that is rebuilt reads both hands' vertices (own: box + normalisation, other: needed-voxel mask) and the lists' reference
+        # pose + bitmap (9.3 + 4 KB), writes its tables and box and the 778 cell words of the other hand's queries; per needed voxel
+        # 4 B (phi = 0 or a work-list entry).  Round 6: the model follows what opt_default really asks of the kernel (round 5 charged
+        # every hand the full set, 78 KB, and the counters came out BELOW the model): in the translation stage -- a quarter of the
+        # iterations -- both hands are static in their own frames and move only the other hand's vertices, the cell words and the box
+        # (12.5 KB); in the other stages 22 % of the hands hand the distance kernel no voxel and skip their triangle records (30.8 KB)
         # flops: ~20 per vertex pair (normalisation, voxel index), ~130 per triangle record, 14 per (triangle, column) ray test
         # + 20 per hit-mask evaluation (counted together in ray_tests: (u, v) tests + needed voxels of the hit columns)
-        return (hands * (2 * HAND_VERT_BYTES + 9336 + 4096 + HAND_TABLE_BYTES + 16 + 778 * 4) + st["needed_voxels"] * 4,
+        full = 2 * HAND_VERT_BYTES + 9336 + 4096 + HAND_TABLE_BYTES + 16 + 778 * 4
+        static = HAND_VERT_BYTES + 16 + 778 * 4
+        return (hands * (0.25 * static + 0.75 * (full - 0.22 * 1538 * 20)) + st["needed_voxels"] * 4,
                 hands * (778 * 20.0 + 1538 * 130.0) + st["ray_tests"] * 17.0)
-    # opt_tail_kernel, per sample: sampling reads the 1556 cell words, the two inside-voxel bitmaps (2 x 4 KB) and -- for the queries that
+    # opt_tail_kernel, per sample: sampling reads the 1556 cell words (round 6: they carry the corner masks; the two 4 KB bitmaps are no longer read) and -- for the queries that
     # touch an inside voxel: priced as all of them, the model of round 4 -- both hands' vertices + one phi value per needed voxel; the LBS backward reads v_posed of
     # both hands (+ the 3 KB skeleton records); the translation / orientation form also skins the next vertices (vertices out).  The
     # gradients between the phases stay in LDS and the per-vertex depths are not written inside the loop: no bytes.  flops: 60 per
     # sampled vertex (trilinear value + gradient), LBS backward over the four non-zero weights (778 x 4 x 24 x 2 per hand), skinning
     # 778 x 4 x 24 per hand
     skin = 0.5            # the translation / orientation stages (half the iterations of opt_default) also skin: vertices out
-    return (samples * (2 * HAND_VERT_BYTES + 1556 * 4 + 2 * 4096 + 2 * (HAND_VERT_BYTES + 3136) + skin * 2 * HAND_VERT_BYTES) + st["needed_voxels"] * 4,
+    return (samples * (2 * HAND_VERT_BYTES + 1556 * 4 + 2 * (HAND_VERT_BYTES + 3136) + skin * 2 * HAND_VERT_BYTES) + st["needed_voxels"] * 4,
             samples * (1556 * 60.0 + 2 * 778 * 4 * 24 * 2.0 + skin * 2 * 778 * 4 * 24))
 
 
