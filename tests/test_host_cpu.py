@@ -286,3 +286,26 @@ def test_committed_profile_carries_what_the_bench_line_quotes():
     assert 2e7 < traffic < 5e8 and 10.0 < us < 200.0 and 1e6 < inst < 1e8
     # issue slots at the peak clock (bench.py: roofline.valu.issue_slots): a fraction of one
     assert 0.05 < inst * 3.0 / (1024.0 * us * 1e-6 * 2.4e9) < 1.0
+
+
+def test_design_section_6_is_generated_from_the_committed_bench_line():
+    """DESIGN.md section 6 quotes the round's measurements; round 5's section still carried round 4's numbers.  Its figures are now a
+    block generated from the committed bench line of the committed sources (scripts/design_numbers.py, profiles/<series>_bench_line.json)
+    and must stand in DESIGN.md verbatim; the line itself must be a line of the driver's command with the contract's keys."""
+    import json as _json
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import design_numbers
+    from ihmr_amd import hip
+    cur = hip._source_hash()
+    prof = os.path.join(ROOT, "profiles")
+    series = sorted(f[:-len("_f7_meta.json")] for f in os.listdir(prof) if f.endswith("_f7_meta.json")
+                    and _json.load(open(os.path.join(prof, f)))["srchash"] == cur)
+    assert series, "no profile series of the committed sources"
+    line = os.path.join(prof, f"{series[-1]}_bench_line.json")
+    assert os.path.isfile(line), line
+    d = _json.loads([l for l in open(line).read().splitlines() if l.startswith("{")][-1])
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["config"]["latency_ms_per_refine_iter"] == d["latency"]["ms_per_refine_iter"]
+    assert d["roofline"]["traffic"] and d["cpu_baseline"]["value"] > 0 and d["parity"]["vs_oracle"]["within_tolerance"]
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for row in design_numbers.block(line):
+        assert row in design, row[:160]
