@@ -765,7 +765,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local_rank %= max(torch.cuda.device_count(), 1)     # one rank per GPU on the driver's node; ranks may share a GPU in the
         torch.cuda.set_device(local_rank)                   # single-GPU check of this code path (IHMR_DIST_BACKEND=gloo)
-        backend = os.environ.get("IHMR_DIST_BACKEND", "nccl")
+        # RCCL needs a device per rank; more ranks than devices (a one-GPU box checking the N-rank code path) share them over gloo
+        backend = os.environ.get("IHMR_DIST_BACKEND") or ("gloo" if world > max(torch.cuda.device_count(), 1) else "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
