@@ -576,7 +576,9 @@ extern "C" int ihmr_opt_set_params(const ihmr_opt_io* io, const float* final_par
 }
 
 // ------------------------------------------------------------------------------------------ IHMR-MLP inference glue (mlp_infer.h)
-extern "C" size_t ihmr_mlp_workspace_bytes(int B) { return ((size_t)B * (512 + 256 + 128) * sizeof(float) + 256 + 255) & ~(size_t)255; }
+// [256 B header | hidden activations (B, 512 + 256 + 128) | raw joints of every sample's accepted state (B, 42, 3)]
+extern "C" size_t ihmr_mlp_workspace_bytes(int B) { return ((size_t)B * (512 + 256 + 128 + 126) * sizeof(float) + 256 + 255) & ~(size_t)255; }
+static float* mlp_acc_joints(void* workspace, int B) { return (float*)((char*)workspace + 256) + (size_t)B * (512 + 256 + 128); }
 
 static int mlp_fill_select(MlpSelect& s, const ihmr_mlp_tables* t, const ihmr_mlp_stage* stage, int mode, void* workspace) {
     memset(&s, 0, sizeof(s));
@@ -625,16 +627,35 @@ extern "C" int ihmr_mlp_stage_head(const ihmr_mlp_net* net, const ihmr_mlp_table
 
 extern "C" int ihmr_mlp_forward_select(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, const ihmr_opt_weights* w,
                                        const ihmr_mlp_tables* t, const ihmr_mlp_stage* stage, int mode, void* workspace, void* stream) {
-    if (!m || !io || !w || !workspace || B <= 0 || 2 * B > SDF_MAX_HANDS || mode < 0 || mode > 2 || (mode && !t)) return -1;
+    if (!m || !io || !w || !workspace || B <= 0 || 2 * B > SDF_MAX_HANDS || mode < 0 || mode > 3 || (mode && !t)) return -1;
     MlpSelect sel;
     memset(&sel, 0, sizeof(sel));
+    // mode 3 (round 6) = mode 2 for a stage that moves neither finger pose nor shape while the workspace still holds v_posed of exactly
+    // these finger poses and shapes (the caller's bookkeeping: ihmr_amd/mlp_model.py): the skinning launch skips both blends
+    // (lbs_skin_kernel MODE REUSE: the stored values are the bits a recomputation gives)
+    const int skin_mode = mode == 3 ? LBS_SKIN_REUSE : LBS_SKIN_FULL;
+    if (mode == 3) mode = 2;
     if (mode) { if (int rc = mlp_fill_select(sel, t, stage, mode, workspace)) return rc; }
     OptWork wk = opt_carve(io->workspace, B);
+    if (mode) { sel.joints_now = wk.joints_raw; sel.acc_joints = mlp_acc_joints(workspace, B); }
     // The evaluations of one test() call move the hands by a stage's residual at a time: the collision kernels keep their per-voxel
     // candidate lists from one evaluation to the next (valid while a hand stays within the slack of the pose its lists were built at,
     // checked per hand and evaluation; rebuilt otherwise) -- started over by the evaluation that opens the batch.  No static-hand
     // reuse here: a rejected update falls back to parameters the vertex buffers no longer hold.
-    return opt_forward(m, m_left, io, wk, B, *w, kNoStep, (hipStream_t)stream, 0, LBS_SKIN_FULL, mode == 1 ? 2 : 1, true, true, 0, mode ? &sel : nullptr);
+    return opt_forward(m, m_left, io, wk, B, *w, kNoStep, (hipStream_t)stream, 0, skin_mode, mode == 1 ? 2 : 1, true, true, 0, mode ? &sel : nullptr);
+}
+
+// the evaluation of a stage that moved ONLY the camera: one small launch (mlp_camera_select_kernel, refine.h)
+extern "C" int ihmr_mlp_camera_select(const ihmr_opt_io* io, int B, const ihmr_opt_weights* w, const ihmr_mlp_tables* t,
+                                      const ihmr_mlp_stage* stage, void* workspace, void* stream) {
+    if (!io || !w || !t || !stage || !workspace || B <= 0) return -1;
+    MlpSelect sel;
+    if (int rc = mlp_fill_select(sel, t, stage, 2, workspace)) return rc;
+    OptWork wk = opt_carve(io->workspace, B);
+    sel.joints_now = nullptr; sel.acc_joints = nullptr;          // (the accepted joints do not change: the camera moves no joint)
+    wk.joints_raw = mlp_acc_joints(workspace, B);                 // the loss wave reads the accepted state's raw joints
+    hipLaunchKernelGGL(mlp_camera_select_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *io, wk, B, *w, sel);
+    return (int)hipGetLastError();
 }
 
 // skeletons + skinning of the parameters in `io` only (no collision term, no losses): the annotation's meshes of the export

@@ -164,6 +164,11 @@ struct MlpSelect {
     float* prev_loss;                // (num_data,3)
     float* final_out;                // (B,122) the batch's state after this stage
     unsigned char* kept;             // (B) this stage's decision
+    // round 6: the raw joints (B,42,3) of every sample's ACCEPTED state, kept per batch so that a stage that moves only the camera can be
+    // judged without re-evaluating the hands (mlp_camera_select_kernel): joints_now = what the forward of this evaluation produced,
+    // copied to acc_joints for a sample that keeps the update (or is saved for the first time)
+    const float* joints_now;
+    float* acc_joints;
 };
 
 // called by all threads of the sample's workgroup after the losses of sample b are in loss_batch
@@ -196,6 +201,8 @@ __device__ __forceinline__ void mlp_select_sample(const MlpSelect& s, const floa
     } else if (tid == 125) {
         s.kept[b] = ok ? 1 : 0;
         s.data_idxs_all[r] = 1;
+    } else if (tid >= 128 && tid < 128 + 126 && ok && s.acc_joints && s.joints_now) {
+        s.acc_joints[(size_t)b * 126 + (tid - 128)] = s.joints_now[(size_t)b * 126 + (tid - 128)];
     }
     if (s.mode == 1)
         for (int k = tid; k < 1024; k += (int)blockDim.x) s.img_feat_all[(size_t)r * 1024 + k] = s.img_feat[(size_t)b * 1024 + k];

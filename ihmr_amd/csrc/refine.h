@@ -278,8 +278,13 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void opt_sample_loss_kernel(ihm
     // collision gradient scale: weight * [two-hand sample] / (loss divisor [num_hands^2] * B)   (loss_utils.py:186-188)
     const float mask = (io.hand_type_array[b * 2] + io.hand_type_array[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
     const float gs = w.collision * mask / (ws.loss_div * (float)(io.norm_batch > 0 ? io.norm_batch : B));
-    sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, io.coll_per_vert, io.coll_origin_scale, nullptr, wk.g_verts, B, gs,
-                     io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
+    // (an IHMR-MLP evaluation -- a keep / reject decision follows, no backward -- takes the values from the prep kernel's cell words:
+    // the same bits, no gradient; round 6)
+    if (sel.mode)
+        sdf_sample_cells(vl, ws, io.loss_batch + 2 * B, io.coll_per_vert, io.coll_origin_scale, B, io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
+    else
+        sdf_sample_block(vl, ws, 0.f, io.loss_batch + 2 * B, io.coll_per_vert, io.coll_origin_scale, nullptr, wk.g_verts, B, gs,
+                         io.hand_type_array, red16, b, OPT_SAMPLE_WORKERS);
     // IHMR-MLP: keep / reject the stage's update of this sample and store it to the "prev" tables (mlp_infer.h)
     if (sel.mode) mlp_select_sample(sel, io.loss_batch, B, b);
 }
@@ -550,6 +555,23 @@ __global__ __launch_bounds__(SDF_SAMPLE_THREADS, 4) void opt_tail_kernel(ihmr_ma
             }
     }
     TAIL_TK(4);
+}
+
+// IHMR-MLP, a stage that moves ONLY the camera (mlp_default's last: `pred_cam_params`, filter and select on joints_2d_loss_p;
+// strategies/mlp_default.py) -- round 6.  The reference re-evaluates everything for it (mlp_model.py:504-511: MANO of both hands, the
+// collision term), but no vertex, no 3-D joint and no penetration depth depends on the camera: the hands of the state the stage starts
+// from -- every sample's ACCEPTED state -- are what they were when that state was evaluated.  So the evaluation is one launch of one wave
+// per sample: the joint losses (opt_loss_wave, the same function, hence the same bits as a full evaluation) on the accepted state's raw
+// joints (MlpSelect::acc_joints) with the new camera, the collision loss taken over from the "prev" table (what a re-evaluation of the
+// same vertices returns bit for bit: the kernels are deterministic), then the keep / reject decision.  grid = B, block = 256.
+__global__ __launch_bounds__(256) void mlp_camera_select_kernel(ihmr_opt_io io, OptWork wk, int B, ihmr_opt_weights w, MlpSelect sel) {
+    __shared__ LossShared sh;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < WAVE) {
+        opt_loss_wave(io, wk, B, w, sh, b, tid, 0);          // (wk.joints_raw = the accepted joints: set by the launcher)
+        if (tid == 0) io.loss_batch[(size_t)2 * B + b] = sel.prev_loss[(size_t)sel.idx[b] * 3 + 2];
+    }
+    mlp_select_sample(sel, io.loss_batch, B, b);
 }
 
 // The reference's packed prediction vector final_params (B,122) = [cam 3 | R orient 3 | R pose 45 | L orient 3 |

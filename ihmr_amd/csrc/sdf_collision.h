@@ -1791,6 +1791,115 @@ __device__ __forceinline__ void sdf_sample_fused(const VertLayout& vl, const Sdf
 #endif
 }
 
+// The sampler of IHMR-MLP's evaluations (opt_sample_loss_kernel with a keep / reject decision behind it; round 6): sdf_sample_block's
+// values -- loss, per-vertex depth, origin-scale depth -- from the prep kernel's cell words, as sdf_sample_fused takes them: an entry none
+// of whose eight cell corners is an inside voxel (94 %) is the exact +0 the full arithmetic gives and costs one word; the others load
+// vertex, box and phi in one round trip and run sdf_sample_block's expressions.  No gradient: an evaluation of MLPModel.test() has no
+// backward (the training step and every other caller go through sdf_sample_block).  Called by ALL threads of the workgroup; threads
+// tid >= nworkers (the loss wave) take part in the block sum only.
+__device__ __forceinline__ void sdf_sample_cells(const VertLayout& vl, const SdfWorkspace& ws, float* __restrict__ loss,
+                                                 float* __restrict__ per_vert, float* __restrict__ origin, int B,
+                                                 const float* __restrict__ hand_type, float* red16, int b, int nworkers) {
+    const int tid = threadIdx.x;
+    float acc = 0.f;
+    unsigned cw[SDF_SAMPLE_NIT];
+    bool on[SDF_SAMPLE_NIT];
+    int hn[SDF_SAMPLE_NIT], vx[SDF_SAMPLE_NIT];
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        const int e = tid + it * nworkers;
+        on[it] = e < 2 * NV && tid < nworkers;
+        const int ee = on[it] ? e : 0;
+        hn[it] = ee / NV; vx[it] = ee % NV;
+        cw[it] = ws.qcell[(size_t)b * 2 * NV + ee];
+    }
+    const float4 box0 = *reinterpret_cast<const float4*>(ws.box + (size_t)b * 4), box1 = *reinterpret_cast<const float4*>(ws.box + ((size_t)B + b) * 4);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool fast0 = box0.w >= 1e-6f && box0.w <= 1e6f, fast1 = box1.w >= 1e-6f && box1.w <= 1e6f;
+    unsigned m8[SDF_SAMPLE_NIT];
+    bool nz[SDF_SAMPLE_NIT];
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        const unsigned m = (on[it] && (cw[it] & SDF_QCELL_IN)) ? ((cw[it] >> SDF_QCELL_MASK_SHIFT) & 0xffu) : 0u;
+        m8[it] = m;
+        nz[it] = on[it] && (m != 0u || !(hn[it] ? fast1 : fast0));
+    }
+    float qv[SDF_SAMPLE_NIT][3], pv[SDF_SAMPLE_NIT][8];
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        qv[it][0] = qv[it][1] = qv[it][2] = 0.f;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) pv[it][c8] = 0.f;
+        if (nz[it]) {
+            const float* q = vl.hand(b, 1 - hn[it]) + 3 * vx[it];
+            qv[it][0] = q[0]; qv[it][1] = q[1]; qv[it][2] = q[2];
+            const unsigned c = cw[it];
+            const int i0 = (int)(c & 63u) - 1, j0 = (int)((c >> 6) & 63u) - 1, k0 = (int)((c >> 12) & 63u) - 1;
+            const float* phi = ws.phi + (size_t)(hn[it] * B + b) * SDF_NVOX;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int j = j0 + (c4 & 1), k = k0 + (c4 >> 1);
+                const bool b0 = (m8[it] >> (2 * c4)) & 1u, b1 = (m8[it] >> (2 * c4 + 1)) & 1u;
+                const float* row = phi + (k * SDF_G + j) * SDF_G;
+                if (b0 && b1) {
+                    typedef float sdf_f2u __attribute__((ext_vector_type(2), aligned(4)));
+                    const sdf_f2u two = *reinterpret_cast<const sdf_f2u*>(row + i0);
+                    pv[it][2 * c4] = two.x; pv[it][2 * c4 + 1] = two.y;
+                } else if (b0) {
+                    pv[it][2 * c4] = row[i0];
+                } else if (b1) {
+                    pv[it][2 * c4 + 1] = row[i0 + 1];
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < SDF_SAMPLE_NIT; ++it) {
+        if (!on[it]) continue;
+        const int e = tid + it * nworkers, hnd = hn[it];
+        const float sc = (hnd ? box1 : box0).w;
+        float val = 0.f;
+        if (nz[it]) {           // sdf_sample_block's expressions, operation for operation (value only)
+            const float4 bx = hnd ? box1 : box0;
+            const SdfDivisor dsc = sdf_divisor(sc);
+            const float nx0 = sdf_div(qv[it][0] - bx.x, dsc), nz0 = sdf_div(qv[it][2] - bx.z, dsc);
+            const float ix = sdf_unnorm(ws.swap_xz ? nz0 : nx0, ws.align_corners), iy = sdf_unnorm(sdf_div(qv[it][1] - bx.y, dsc), ws.align_corners),
+                        iz = sdf_unnorm(ws.swap_xz ? nx0 : nz0, ws.align_corners);
+            const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+            const bool inr = x0 >= -1.0f && x0 <= (float)(SDF_G - 1) && y0 >= -1.0f && y0 <= (float)(SDF_G - 1) && z0 >= -1.0f && z0 <= (float)(SDF_G - 1);
+            if (inr) {
+                const int i0 = (int)x0, j0 = (int)y0, k0 = (int)z0;
+                const float fx = ix - x0, fy = iy - y0, fz = iz - z0;
+                const float wx1 = fx, wx0 = (x0 + 1.0f) - ix, wy1 = fy, wy0 = (y0 + 1.0f) - iy, wz1 = fz, wz0 = (z0 + 1.0f) - iz;
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const int di = c8 & 1, dj = (c8 >> 1) & 1, dk = c8 >> 2;
+                    const int i = i0 + di, j = j0 + dj, k = k0 + dk;
+                    if (i >= 0 && i < SDF_G && j >= 0 && j < SDF_G && k >= 0 && k < SDF_G) {
+                        const float wx = di ? wx1 : wx0, wy = dj ? wy1 : wy0, wz = dk ? wz1 : wz0;
+                        val += pv[it][c8] * (wx * wy * wz);
+                    }
+                }
+            }
+        }
+        per_vert[(size_t)b * 2 * NV + e] = val;
+        origin[(size_t)b * 2 * NV + e] = val * sc;
+        acc += val;
+    }
+    // fixed-order block sum: DPP inside each wave, the wave totals through LDS (as sdf_sample_block)
+    const float wsum = wave_reduce_sum_dpp(acc);
+    if (tid % WAVE == 0) red16[tid / WAVE] = wsum;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int wv = 0; wv < SDF_SAMPLE_THREADS / WAVE; ++wv) tot += red16[wv];
+        float mask = 1.0f;
+        if (hand_type) mask = (hand_type[b * 2] + hand_type[b * 2 + 1]) > 1.5f ? 1.f : 0.f;
+        loss[b] = tot / ws.loss_div * mask;
+    }
+}
+
 // seam B: grid = B, block = SDF_SAMPLE_THREADS (512)
 __global__ __launch_bounds__(SDF_SAMPLE_THREADS) void sdf_sample_kernel(VertLayout vl, SdfWorkspace ws, float robustifier,
                                                                  float* __restrict__ loss, float* __restrict__ per_vert,

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "ihmr_avgpool_relu", "ihmr_preprocess_images", "ihmr_mlp_train_grad", "ihmr_transpose", "ihmr_relu_backward", "ihmr_colsum",
     "ihmr_adam_step", "ihmr_bn_workspace_bytes", "ihmr_bn_train_forward", "ihmr_bn_train_backward", "ihmr_conv_wgrad",
     "ihmr_dilate2", "ihmr_interleave2", "ihmr_pack_dgrad_weight", "ihmr_maxpool3x3s2_backward", "ihmr_avgpool_relu_backward", "ihmr_set_kernel_timer", "ihmr_flush_kernel_timer",
-    "ihmr_mlp_workspace_bytes", "ihmr_mlp_stage_head", "ihmr_mlp_forward_select", "ihmr_opt_forward_verts",
+    "ihmr_mlp_workspace_bytes", "ihmr_mlp_stage_head", "ihmr_mlp_forward_select", "ihmr_mlp_camera_select", "ihmr_opt_forward_verts",
     "ihmr_debug_force_lbs_bwd2_streaming", "ihmr_debug_force_full_skin", "ihmr_version", "ihmr_copy_segments", "ihmr_root_align_joints",
 ]
 
@@ -267,6 +267,7 @@ def lib():
         L.ihmr_mlp_workspace_bytes.restype = C.c_size_t
         L.ihmr_mlp_stage_head.argtypes = [C.POINTER(MlpNet), C.POINTER(MlpTables), C.POINTER(OptIO), i, vp, vp]
         L.ihmr_mlp_forward_select.argtypes = [vp, vp, C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(MlpTables), C.POINTER(MlpStage), i, vp, vp]
+        L.ihmr_mlp_camera_select.argtypes = [C.POINTER(OptIO), i, C.POINTER(OptWeights), C.POINTER(MlpTables), C.POINTER(MlpStage), vp, vp]
         L.ihmr_opt_forward_verts.argtypes = [vp, C.POINTER(OptIO), i, vp]
         L.ihmr_eval_metrics.argtypes = [vp, vp, vp, vp, vp, i, vp, vp]
         L.ihmr_eval_mpvpe.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, vp]

@@ -218,6 +218,12 @@ class MLPModel(MLPTrainMixin):
                 st.filter_factor[f] = float(np.float32(1 + float(pct) / 100))        # torch multiplies the float32 loss by this scalar
             g["nets"].append(net); g["stages"].append(st); g["tables"].append(tab(g["new"], g["kept"][sid]))
             g.setdefault("keep", []).append(pk)
+            # a stage that moves nothing but the camera (mlp_default's last) changes no vertex, no 3-D joint and no penetration depth:
+            # judged by ONE small launch on the accepted state's joints (ihmr_mlp_camera_select; opt.mlp_no_camera_shortcut = the
+            # reference's full re-evaluation, the checker)
+            g.setdefault("cam_only", []).append(all(c < 3 for c in cols) and not getattr(self.opt, "mlp_no_camera_shortcut", False))
+            # does the stage touch a column v_posed depends on -- finger pose (6..50, 54..98 of the 122-vector) or shape (99..118)?
+            g.setdefault("moves_vposed", []).append(any(6 <= c < 51 or 54 <= c < 119 for c in cols))
         self._glue_cache = g
         return g
 
@@ -268,9 +274,20 @@ class MLPModel(MLPTrainMixin):
         # mlp_model.py:204-216: [cam | pose 96 | shape 20 | trans] in the reference's order = self._init_packed (filled by set_input)
         hip.check(L.ihmr_opt_set_params(io, self._init_packed.data_ptr(), B, st), "ihmr_opt_set_params")
         hip.check(L.ihmr_mlp_forward_select(mr, ml, io, B, C.byref(w), C.byref(g["first"]), None, 1, g["ws"].data_ptr(), st), "ihmr_mlp_forward_select")
+        # v_posed (blend shapes applied, before skinning) depends on finger pose and shape only.  The evaluation that opens test() skins
+        # the backbone's prediction in full; until a stage proposes new finger poses or shapes every row of every evaluated state --
+        # kept or fallen back -- still has the prediction's, i.e. the workspace's v_posed is the bits a recomputation would give and
+        # the skinning launch may skip both blends (mode 3; opt.mlp_no_vposed_reuse: the checker).  From the first such stage on the
+        # stored v_posed is a PROPOSAL's, which a sample may have rejected: full skinning.
+        vposed_ok = not getattr(self.opt, "mlp_no_vposed_reuse", False)
         for sid in range(len(self.strategy)):
             hip.check(L.ihmr_mlp_stage_head(C.byref(g["nets"][sid]), C.byref(g["tables"][sid]), io, B, g["ws"].data_ptr(), st), "ihmr_mlp_stage_head")
-            hip.check(L.ihmr_mlp_forward_select(mr, ml, io, B, C.byref(w), C.byref(g["tables"][sid]), C.byref(g["stages"][sid]), 2,
+            vposed_ok = vposed_ok and not g["moves_vposed"][sid]
+            if g["cam_only"][sid]:
+                hip.check(L.ihmr_mlp_camera_select(io, B, C.byref(w), C.byref(g["tables"][sid]), C.byref(g["stages"][sid]), g["ws"].data_ptr(), st),
+                          "ihmr_mlp_camera_select")
+                continue
+            hip.check(L.ihmr_mlp_forward_select(mr, ml, io, B, C.byref(w), C.byref(g["tables"][sid]), C.byref(g["stages"][sid]), 3 if vposed_ok else 2,
                                                 g["ws"].data_ptr(), st), "ihmr_mlp_forward_select")
         final = g["final"]
         hip.check(L.ihmr_opt_set_params(io, final.data_ptr(), B, st), "ihmr_opt_set_params")

@@ -411,7 +411,12 @@ int ihmr_flush_kernel_timer(void);
  *                            mode 1: the evaluation of the backbone's prediction that opens test(): nothing to compare, everything
  *                            saved (+ img_feat -> img_feat_all, data_idxs_all); mode 0: evaluate only (the final state).  The
  *                            collision kernels carry their candidate lists from one call to the next (exact: checked per hand against
- *                            the pose the lists were built at); mode 1 starts them over.
+ *                            the pose the lists were built at); mode 1 starts them over.  mode 3 (round 6) = mode 2 for a stage that
+ *                            moves neither finger pose nor shape while io's workspace still holds v_posed of exactly these finger poses
+ *                            and shapes (the last call that skinned in full evaluated the same pose / shape columns for EVERY row; the
+ *                            caller keeps that book): the skinning launch skips both blends, bit for bit the same vertices.  An
+ *                            evaluation (mode 1-3) takes its penetration depths from the prep kernel's cell words and writes no
+ *                            vertex gradient (test() has no backward).
  * Weights: K-major [Kpad][ldw] as ihmr_conv_igemm takes them (layer 0: Kpad = 1152 rows, zeros beyond 1146).  Loss indices: IHMR_LOSS_*
  * (0 joints_2d_loss_p, 1 joints_3d_loss_p, 2 collision_loss).  workspace: ihmr_mlp_workspace_bytes(B) (the hidden activations).
  * All pointers device pointers. */
@@ -434,6 +439,15 @@ size_t ihmr_mlp_workspace_bytes(int B);
 int ihmr_mlp_stage_head(const ihmr_mlp_net* net, const ihmr_mlp_tables* t, const ihmr_opt_io* io, int B, void* workspace, void* stream);
 int ihmr_mlp_forward_select(const ihmr_mano* m, const ihmr_mano* m_left, const ihmr_opt_io* io, int B, const ihmr_opt_weights* w,
                             const ihmr_mlp_tables* t, const ihmr_mlp_stage* stage, int mode, void* workspace, void* stream);
+/* The evaluation + keep / reject decision of a stage that moved ONLY the camera (mlp_default's last stage: update `pred_cam_params`, filter
+ * and select on joints_2d_loss_p; mlp_model.py:504-511,592-637) -- round 6.  The reference re-runs MANO and the collision term for it; no
+ * vertex, 3-D joint or penetration depth depends on the camera, so this entry evaluates the joint losses on the raw joints of every
+ * sample's ACCEPTED state (kept in `workspace` by the ihmr_mlp_forward_select calls of the same batch) with the camera in `io`, takes the
+ * collision loss over from the "prev" table (what a re-evaluation returns bit for bit) and decides: one launch of one workgroup per
+ * sample.  PRECONDITION: an ihmr_mlp_forward_select(mode 1) for this batch and workspace came first, and the stage's sub-network
+ * touched only columns 0..2 of the 122-vector; the caller (ihmr_amd/mlp_model.py) checks the latter. */
+int ihmr_mlp_camera_select(const ihmr_opt_io* io, int B, const ihmr_opt_weights* w, const ihmr_mlp_tables* t, const ihmr_mlp_stage* stage,
+                           void* workspace, void* stream);
 /* skeletons + skinning of the parameters held in io (no collision term, no losses): io->verts (2,B,778,3).  Used for the
  * annotation's meshes of the export (mlp_model.py:497-501). */
 int ihmr_opt_forward_verts(const ihmr_mano* m, const ihmr_opt_io* io, int B, void* stream);

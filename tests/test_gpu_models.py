@@ -223,6 +223,68 @@ def test_mlp_model_batch128_matches_oracle(mano_arrays):
     _report("mlp128 penetration depth, oracle on the product's own vertices [m]", res["collision_loss_origin_scale"], own.numpy(), atol=1e-6)
 
 
+def test_mlp_camera_stage_shortcut_does_not_change_a_bit(mano_arrays):
+    """Round 6: a stage that moves ONLY the camera (mlp_default's last) is judged by one small launch on the accepted state's joints
+    (`ihmr_mlp_camera_select`: no MANO, no collision kernels -- nothing of either depends on the camera); `opt.mlp_no_camera_shortcut`
+    re-evaluates everything as the reference does; and the stages before the first finger-pose / shape stage skin the stored v_posed
+    (`ihmr_mlp_forward_select` mode 3; `opt.mlp_no_vposed_reuse` = both blends every time).  Bit for bit the same decisions, "prev" tables and exports, over two test() calls
+    (the second compares against the tables the first one left) on a batch with both decisions in the camera stage -- and a
+    strategy whose FIRST stage is the camera one (the accepted joints are then the first evaluation's)."""
+    from helpers import seeded_state_dict
+    from ihmr_amd.mlp_model import MLPModel
+    from ihmr_amd.strategies import make_mlp_strategy
+    from ihmr_amd.synthetic import synthetic_opt_batch
+    from oracle.mlp_ref import MLPRef
+    from oracle.opt_ref import OptimizeRef
+    right, left = mano_arrays
+    B = 32
+    helper = OptimizeRef(right, left, B, [], save_mid_freq=1)
+
+    def fwd(pose, shape, trans):
+        helper.pred_right_orient, helper.pred_left_orient = pose[:, :3], pose[:, 48:51]
+        helper.pred_right_pose_params, helper.pred_left_pose_params = pose[:, 3:48], pose[:, 51:]
+        helper.pred_right_shape_params, helper.pred_left_shape_params = shape[:, :10], shape[:, 10:]
+        helper.pred_hand_trans = trans.view(-1, 1, 3)
+        return helper.get_mano_output()[2]
+
+    batches = []
+    for seed in (3232, 3233):
+        b = synthetic_opt_batch(B, fwd, seed=seed, with_feat=True)
+        b["init_hand_trans"] = b["init_hand_trans"][:, 0, :3].contiguous()
+        b["img"] = torch.zeros(B, 3, 8, 8)
+        b.pop("init_hand_trans_j")
+        batches.append(b)
+    base = make_mlp_strategy()
+    for strategy in (base, [base[5]] + base[:5]):
+        orc = MLPRef(right, left, B, strategy, num_data=B)
+        outs = []
+        for off in (False, True):
+            m = MLPModel(_opt(B, mlp_no_camera_shortcut=off, mlp_no_vposed_reuse=off))
+            m.set_update_info(strategy, B)
+            for sid in range(len(strategy)):
+                m.add_new_network(sid)
+                m.sub_network_list[sid].load_state_dict(seeded_state_dict(orc.nets[sid], 700 + sid, last_scale=0.05))
+            m.eval()
+            got = []
+            for b in batches + batches[:1]:
+                m.set_input(b); m.test(); torch.cuda.synchronize()
+                got.append((m.get_pred_result(), torch.stack(m.kept_history).cpu().numpy(), m.prev_final.cpu().numpy().copy(), m.prev_loss.cpu().numpy().copy()))
+                # the collision loss an EVALUATION stored for a sample's accepted state (the cell-word sampler, sdf_sample_cells; taken over
+                # unchanged by the camera stage) = the one the final forward computes for the same state (sdf_sample_block): bit for bit
+                idx = m.data_idxs.cpu().numpy()
+                assert np.array_equal(got[-1][3][idx, 2], m.collision_loss_batch.cpu().numpy()), "evaluation vs final forward collision loss"
+                assert float(m.collision_loss_batch.max()) > 0
+            outs.append(got)
+        cam = [i for i, st in enumerate(strategy) if st["update_params"] == ["pred_cam_params"]][0]
+        kept_cam = np.concatenate([g[1][cam] for g in outs[0]])
+        print(f"[parity] camera stage at position {cam}: kept {int(kept_cam.sum())} of {kept_cam.size}")
+        assert 0 < kept_cam.sum() < kept_cam.size, "the camera stage must exercise both decisions"
+        for (ra, ka, fa, la), (rb, kb, fb, lb) in zip(*outs):
+            assert np.array_equal(ka, kb) and np.array_equal(fa, fb) and np.array_equal(la, lb)
+            for k in ra:
+                assert np.array_equal(ra[k], rb[k]), k
+
+
 def test_baseline_test_graph_replays_equal_eager_launches(mano_arrays):
     """InterHandModel.test() is replayed from one captured graph (opt.use_test_graph): the replay over NEW inputs in the static buffers and
     after a change of the encoder's weights (re-capture) must give the bits of eager launches."""
