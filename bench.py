@@ -665,7 +665,8 @@ def secondary(config, with_cpu=True):
         hbm_binds = flops / abytes < RIDGE_FLOP_PER_BYTE        # the roof is fixed by arithmetic intensity
         out = dict(metric="images/sec, IHMR-MLP refinement head batch=128 inference", value=B / dt, unit="images/s", n_gpus=1, ms_per_step=dt * 1e3,
                    dtype="f32", data="synthetic", higher_is_better=True,
-                   config=dict(workload="BASELINE.json configs[2]: MLPModel.test() (6 stages: 8 MANO + SDF evaluations, 6 MLPs) + export, batch 128; "
+                   config=dict(workload="BASELINE.json configs[2]: MLPModel.test() (6 stages, 6 MLPs; of the reference's 8 MANO + SDF evaluations the camera-only stage's is "
+                                        "replaced by its exact shortcut, ihmr_mlp_camera_select) + export, batch 128; "
                                         "test() replayed as one captured hipGraph per instance"),
                    runs_images_per_s=[B / r for r in runs], spread_images_per_s=[B / max(runs), B / min(runs)],
                    gpu_ms_per_batch=gpu_ms, wall_ms_per_batch=dt * 1e3,
