@@ -28,14 +28,6 @@ for rep in range(2):
     ptr = (C.c_void_p * 4)()
     L.ihmr_debug_sdf_ptrs.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ihmr_debug_sdf_ptrs(C.byref(m.io), BB, ptr)
-    def rd(p, n, dt):
-        t = torch.empty(n, dtype=dt, device="cuda")
-        hiprt = torch.cuda
-        C.memmove  # (unused)
-        from ihmr_amd import hip as H
-        # device -> device copy through torch: wrap the raw pointer
-        src = torch.empty(0)
-        return t
     import ctypes
     rt = ctypes.CDLL("libamdhip64.so")
     def dl(p, nbytes):
