@@ -438,15 +438,17 @@ extern "C" size_t ihmr_opt_workspace_bytes(int B) { return opt_ws_bytes(B); }
 // `prev` = the Adam step of the previous iteration (group < 0: none), applied at the head of the skeleton kernel
 static const ParamStep kNoStep{0, 0.f, 0.f, 1.f, -1, 0, 0};
 // skin_mode: LBS_SKIN_REUSE = the workspace holds v_posed of the current pose and shape parameters (see lbs_skin_kernel); < 0: no skin launch
-// lists: temporal candidate lists of the collision kernels -- 0 off (single-shot callers), 1 reuse while valid, 2 rebuild now
-// the collision workspace of the fused loop with the switches of this call (lists: 0 off, 1 reuse while valid, 2 rebuild now)
+// lists: temporal candidate lists of the collision kernels -- 0 off (single-shot callers), 1 reuse while valid, 2 rebuild now, 3 = the first
+// iteration of a stage whose caller vouches for the lists of the previous stage (ihmr_opt_stage::keep_lists): the static-hand bookkeeping
+// starts over, a hand's lists stay while its own displacement test passes
+// the collision workspace of the fused loop with the switches of this call
 // static_mask: bit 0 / 1 = the right / left hands have had bit-identical vertices since the stage's first iteration (SdfWorkspace::static_mask)
 static SdfWorkspace opt_sdf_ws(const ihmr_opt_io* io, const OptWork& wk, int B, int lists, int static_mask = 0) {
     SdfWorkspace ws = sdf_carve(wk.sdf_ws, 2 * B, true);
     ws.list_mode = (lists != 0 && !io->sdf_no_candidate_lists) ? 1 : 0;
     ws.force_rebuild = lists == 2 ? 1 : 0;
     ws.static_stage = (ws.list_mode && io->sdf_no_static_reuse != 1) ? (static_mask & 3) : 0;
-    ws.static_mask = ws.force_rebuild ? 0 : ws.static_stage;
+    ws.static_mask = lists >= 2 ? 0 : ws.static_stage;
     ws.moving_box = (static_mask >> 2) & ws.static_stage;      // (bits 2-3 of the caller's mask: sides that only translate)
     ws.align_corners = io->sdf_align_corners ? 1 : 0;
     if (io->sdf_loss_divisor > 0.f) ws.loss_div = io->sdf_loss_divisor;
@@ -523,9 +525,12 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
         static_mask |= 2 | (2 << 2);
     const bool pose_stage = (need_mask & 2) != 0;
     const size_t tail_lds = (size_t)opt_tail_dynamic_lds(m->nseg);
+    const int lists_first = sg->keep_lists ? 3 : 2;
     for (int it = 0; it < sg->n_iters; ++it) {
-        // the first iteration of a stage starts the candidate lists over: the select step of the previous stage may have moved
-        // the parameters by more than one optimizer step
+        // the first iteration of a stage starts the candidate lists over (the workspace is the caller's memory: whatever it holds, a stage
+        // is self-contained) -- unless the caller vouches for them (keep_lists): then a hand keeps its lists while the prep kernel's
+        // displacement test against the reference pose they were built at passes, whether an optimizer step or the previous stage's
+        // select step moved the hand
         const double t = (double)(it + 1);
         const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
         const ParamStep next{pm, w->shape_reg, sgd ? sg->lr : (float)((double)sg->lr / bc1), (float)sqrt(bc2),
@@ -534,10 +539,10 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
             // head (optimizer step of the previous iteration + skeletons): stand-alone in the first iteration (zero the optimizer state,
             // first skeletons) and in the finger-pose stage; otherwise the tail of iteration it - 1 has done it
             // ... and in a stage that keeps v_posed (translation, orientation) the tail has skinned the next vertices as well: 3 launches
-            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? first_mode : (vposed_fixed ? -1 : keep_mode), it == 0 ? 2 : 1,
+            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? first_mode : (vposed_fixed ? -1 : keep_mode), it == 0 ? lists_first : 1,
                                  /*head=*/it == 0 || pose_stage, /*tail=*/false, static_mask);
             if (rc) return rc;
-            SdfWorkspace ws = opt_sdf_ws(io, wk, B, it == 0 ? 2 : 1, static_mask);
+            SdfWorkspace ws = opt_sdf_ws(io, wk, B, it == 0 ? lists_first : 1, static_mask);
             VertLayout vl{io->verts, (long)NV3, (long)B * NV3};
             hipEvent_t tcur;
             const bool timed = g_timer != nullptr;
@@ -556,7 +561,7 @@ extern "C" int ihmr_opt_run_stage(const ihmr_mano* m, const ihmr_mano* m_left, c
                 lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,
                                     wk.lbs, st, /*bwd1_done=*/true);
         } else {
-            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? first_mode : keep_mode, it == 0 ? 2 : 1, true, true, static_mask);   // applies the step of iteration it - 1 first
+            int rc = opt_forward(m, m_left, io, wk, B, *w, step, st, need_cam, it == 0 ? first_mode : keep_mode, it == 0 ? lists_first : 1, true, true, static_mask);   // applies the step of iteration it - 1 first
             if (rc) return rc;
             if (need_mask)
                 lbs_backward_launch(m, true, 2 * B, B, wk.g_verts, wk.g_joints, wk.g_orient, wk.g_pose, wk.g_shape, wk.g_trans, need_mask,

@@ -103,7 +103,7 @@ class SdfOptions(C.Structure):
 
 class OptStage(C.Structure):
     _fields_ = [("param_mask", C.c_int), ("optimizer", C.c_int), ("lr", C.c_float), ("n_iters", C.c_int), ("save_freq", C.c_int),
-                ("use_filter", C.c_int * 3), ("filter_factor", C.c_float * 3), ("select_loss", C.c_int)]
+                ("use_filter", C.c_int * 3), ("filter_factor", C.c_float * 3), ("select_loss", C.c_int), ("keep_lists", C.c_int)]
 
 
 class OptWeights(C.Structure):

@@ -73,7 +73,7 @@ def stage_to_args(stage, optimizer="adam", save_mid_freq=1) -> hip.OptStage:
 
 
 def _stage_key(sg: hip.OptStage):
-    return (sg.param_mask, sg.optimizer, sg.lr, sg.n_iters, sg.save_freq, tuple(sg.use_filter), tuple(sg.filter_factor), sg.select_loss)
+    return (sg.param_mask, sg.optimizer, sg.lr, sg.n_iters, sg.save_freq, tuple(sg.use_filter), tuple(sg.filter_factor), sg.select_loss, sg.keep_lists)
 
 
 def _weights(w) -> hip.OptWeights:
@@ -162,11 +162,13 @@ class OptimizeModel:
                             no_fused_tail=int(bool(getattr(self.opt, "no_fused_tail", False))))
         self.mano_params_weight = z(B, 2)
         self.init = {}
+        self._lists_live = False          # run_stage: the workspace holds the candidate lists of this batch's previous stage
 
     # optimize_model.py:120-168
     def set_input(self, input):
         B = self.batch_size
         dev = self.device
+        self._lists_live = False
         g = lambda k: input[k].to(dev, dtype=torch.float32, non_blocking=True)
         assert input["init_cam"].shape[0] == B, "batch size is fixed at construction (opt.batchSize x opt.fuse_batches)"
         self.buf["hand_type_array"].copy_(g("hand_type_array"))
@@ -185,6 +187,7 @@ class OptimizeModel:
     # optimize_model.py:235-251
     def init_optimize(self):
         b, i = self.buf, self.init
+        self._lists_live = False
         b["cam"].copy_(i["cam"])
         b["trans"].copy_(i["trans"])
         b["orient"][0].copy_(i["pose"][:, 0:3])
@@ -202,6 +205,7 @@ class OptimizeModel:
         lw = loss_weights or self.default_loss_weights
         w = _weights(lw)
         mr, ml = self._mano_handles()
+        self._lists_live = False          # (a single-shot collision launch on the same workspace)
         if self.use_graphs:
             key = ("fwd",) + tuple(sorted(lw.items()))
             if key not in self._graphs:
@@ -218,6 +222,7 @@ class OptimizeModel:
         """Work counters of one ``sdf_prep_kernel`` + ``sdf_dist_kernel`` launch pair at the current parameters (diagnostics)."""
         w = _weights(loss_weights or self.default_loss_weights)
         mr, ml = self._mano_handles()
+        self._lists_live = False
         out = (C.c_ulonglong * 4)()
         hip.check(hip.lib().ihmr_opt_sdf_stats(mr, ml, C.byref(self.io), self.batch_size, C.byref(w), out, hip.stream_ptr()),
                   "ihmr_opt_sdf_stats")
@@ -258,6 +263,11 @@ class OptimizeModel:
         sg = stage_to_args(stage, self.optimizer, self.save_mid_freq)
         if (sg.n_iters - 1) // sg.save_freq + 1 > self.S_max:
             raise ValueError("stage takes more snapshots than the ring allocated at construction holds")
+        # ihmr_opt_stage.keep_lists: the collision kernels' candidate lists of the previous stage stay valid across the stage boundary when
+        # THIS instance ran that stage on THIS batch and has launched nothing else on its workspace since (set_input, init_optimize and
+        # every other launch on the workspace clear the flag).  An exact acceleration: opt.sdf_no_stage_list_reuse is the checker switch
+        sg.keep_lists = int(self._lists_live and not getattr(self.opt, "sdf_no_stage_list_reuse", False))
+        self._lists_live = True
         w = _weights(stage["loss_weights"])
         mr, ml = self._mano_handles()
         if self.use_graphs:

@@ -182,6 +182,11 @@ typedef struct ihmr_opt_stage {
     float filter_factor[3];  /* float32(1 + (float(criterion) + 0.1) / 100): keep snapshots with loss <= origin * factor
                                 (utils/opt_utils.py:104-114); several criteria on one loss = the smallest factor */
     int select_loss;         /* IHMR_LOSS_*: stage['select_loss'], per-sample first argmin over the kept snapshots */
+    int keep_lists;          /* 0: the stage rebuilds the collision kernels' candidate lists in its first iteration (self-contained whatever
+                                io->workspace holds).  Non-zero = the caller's guarantee that the previous call on this io->workspace was an
+                                ihmr_opt_run_stage (or its graph) of the SAME batch and B and that nothing has written the workspace since:
+                                a hand then keeps its lists while its displacement test passes.  Same bits either way (the lists are an
+                                exact acceleration); ~20 % fewer rebuilt voxels over opt_default */
 } ihmr_opt_stage;
 
 size_t ihmr_opt_workspace_bytes(int B);

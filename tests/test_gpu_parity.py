@@ -1106,6 +1106,60 @@ def test_static_hand_reuse_does_not_change_a_bit(mano_arrays, B, epoch):
     assert float(a["collision_loss_origin_scale"].max()) > 0
 
 
+@pytest.mark.parametrize("B,epoch,translated", [(16, 29, False), (64, 14, False), (160, 9, True)])
+def test_lists_kept_across_stage_boundaries_do_not_change_a_bit(mano_arrays, B, epoch, translated):
+    """Round 6: `OptimizeModel.run_stage` tells the library (`ihmr_opt_stage.keep_lists`) when the workspace still holds the candidate
+    lists of the SAME batch's previous stage; the stage's first iteration then resets only the static-hand bookkeeping and a hand keeps its
+    lists while the prep kernel's own displacement test passes -- whether an optimizer step or the previous stage's select step moved
+    it.  An exact acceleration: `opt.sdf_no_stage_list_reuse` (every stage rebuilds, rounds 1-5) must agree bit for bit, over
+    opt_default + three stages it never runs (so that every kind of stage follows every other kind), on the regular, the ragged and the
+    >128-hand batch (the 512-thread form of the prep kernel), graphs replayed twice.  The flag is the caller's guarantee about its
+    workspace: set_input / init_optimize / a single-shot forward clear it, a fresh instance never sets it in its first stage."""
+    from helpers import ragged_opt_batch
+    from ihmr_amd.optimize_model import OptimizeModel
+    from ihmr_amd.strategies import make_opt_strategy
+    _, batch = _two_hand_verts(mano_arrays, B, 4700 + B)
+    if B == 16:
+        batch = ragged_opt_batch(batch)
+    base = make_opt_strategy(epoch)
+    extra = []
+    for params, like in ((["pred_left_pose_params"], 2), (["pred_right_orient"], 1), (["pred_cam_params", "pred_hand_trans"], 0)):
+        st = dict(base[like]); st["update_params"] = params
+        extra.append(st)
+    outs, rebuilt = [], []
+    for off in (False, True):
+        opt = _make_opt(B, epoch=epoch, save_mid_freq=5)
+        opt.sdf_no_stage_list_reuse = off
+        opt.sdf_no_translated_reuse = not translated
+        m = OptimizeModel(opt)
+        m.strategy = base + extra
+        assert m._lists_live is False
+        for rep in range(2):
+            m.set_input(batch); m.init_optimize()
+            assert m._lists_live is False
+            m.optimize()                         # (ends with the single-shot final forward)
+            assert m._lists_live is False
+            torch.cuda.synchronize()
+        outs.append((m.get_pred_result(), torch.stack(m.selected_history).cpu().numpy(), m.buf["snap_loss"].cpu().numpy(), m.buf["adam_m"].cpu().numpy()))
+        m.set_input(batch); m.init_optimize()
+        m.sdf_counters_start()
+        for st in m.strategy:
+            m.run_stage(st)
+            assert m._lists_live is True
+        rebuilt.append(m.sdf_counters_stop())
+    (a, sa, la, ma), (b, sb, lb, mb) = outs
+    assert np.array_equal(sa, sb) and np.array_equal(la, lb) and np.array_equal(ma, mb)
+    for k in ("pred_cam_params", "pred_pose_params", "pred_shape_params", "pred_hand_trans", "pred_right_hand_verts", "pred_left_hand_verts",
+              "pred_joints_3d", "collision_loss", "collision_loss_origin_scale"):
+        assert np.array_equal(a[k], b[k]), f"{k}: keeping the lists across the stage boundary changed the result"
+    assert float(a["collision_loss_origin_scale"].max()) > 0
+    on, off = rebuilt
+    print(f"[stage lists] B={B}: voxels rebuilt {on['voxels_rebuilt']} (kept) vs {off['voxels_rebuilt']} (every stage rebuilds); "
+          f"full search {on['voxels_full_search']} vs {off['voxels_full_search']}; inside {on['inside_voxels']} vs {off['inside_voxels']}")
+    assert on["inside_voxels"] == off["inside_voxels"]
+    assert on["voxels_rebuilt"] < off["voxels_rebuilt"]
+
+
 @pytest.mark.parametrize("B,epoch", [(16, 39), (64, 49)])
 def test_translated_hand_reuse_stays_at_rounding_level(mano_arrays, B, epoch):
     """Round 5: a left hand that a stage only TRANSLATES (opt_default's translation stage; camera + translation) is static in its own
