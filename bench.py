@@ -1117,6 +1117,7 @@ def main():
                         latency_images_per_s=latency["images_per_s"] if latency else None,
                         latency_stage_us_per_refine_iter=latency["stage_us_per_refine_iter"] if latency else None,
                         translated_hand_reuse="on (default; rounding-level, DESIGN 5.0)",
+                        stage_list_reuse="on (default; exact: candidate lists kept across stage boundaries, ihmr_opt_stage.keep_lists)",
                         parallelism=f"dp{world} (independent samples, no collective)"),
             roofline=roofline, cpu_baseline=cpu, latency=latency, h2d_inclusive=h2d, large_batch=large, secondary_configs=second,
             geometry=geometry,

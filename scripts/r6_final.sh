@@ -1,11 +1,15 @@
 #!/bin/bash
 # round 6, final measurement series of the committed code: profiles (three launch sizes + the two secondary configs), the gap tables
 # of one batch of 64, the microbenchmark of the launch boundary, and the full bench line.
-# usage (GPU box): bash scripts/r6_final.sh <tag>      e.g. r6_v2
-tag=${1:-r6_v2}
+# usage (GPU box): bash scripts/r6_final.sh <tag>      e.g. r6_v3
+tag=${1:-r6_v3}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-mkdir -p gpurun_out
+mkdir -p gpurun_out build
+# the instrumented library of the gap table (every workgroup records kind / start / end) and the trivial-kernel chain, built from this tree
+[ build/timeline.so -nt ihmr_amd/libihmr_hip.so ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC -Iinclude -DIHMR_TIMELINE \
+    ihmr_amd/csrc/ihmr_hip.hip -o build/timeline.so > gpurun_out/${tag}_build.log 2>&1
+[ -x scripts/microbench_gaps ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/microbench_gaps.hip -o scripts/microbench_gaps >> gpurun_out/${tag}_build.log 2>&1
 for f in 7 1 8; do FUSE=$f bash scripts/profile_round.sh $tag > gpurun_out/${tag}_f${f}_profile.log 2>&1; done
 bash scripts/profile_config.sh $tag baseline > gpurun_out/${tag}_baseline_profile.log 2>&1
 bash scripts/profile_config.sh $tag mlp > gpurun_out/${tag}_mlp_profile.log 2>&1
