@@ -1041,8 +1041,8 @@ def test_sdf_convention_switches_match_oracle(mano_arrays, align_corners, loss_d
 @pytest.mark.parametrize("B,epoch", [(16, 29), (64, 9)])
 def test_candidate_lists_do_not_change_a_bit(mano_arrays, B, epoch):
     """Inside a stage the distance kernel searches, per voxel, only the candidate triangles recorded when the hand's lists were
-    last built (valid while no vertex has moved by more than the slack in the hand's normalised frame; rebuilt otherwise and at
-    every stage start).  A conservative acceleration: with `opt.sdf_no_candidate_lists` every iteration searches all 1538
+    last built (valid while no vertex has moved by more than the slack in the hand's normalised frame; rebuilt otherwise, and at
+    a stage start unless the caller vouches for its workspace: ihmr_opt_stage.keep_lists, round 6).  A conservative acceleration: with `opt.sdf_no_candidate_lists` every iteration searches all 1538
     triangles -- both runs must agree bit for bit, on the regular and on the ragged batch, through all four stages (the
     translation / shape stages reuse the lists for many iterations, the orientation / pose stages rebuild every few)."""
     from helpers import ragged_opt_batch
