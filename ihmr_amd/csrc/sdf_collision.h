@@ -134,6 +134,16 @@ __host__ __device__ inline size_t sdf_xcd_cap(int H) { return (size_t)H * (SDF_N
 #define SDF_LCAP_L 192               // triangles per list (three 64-lane chunks; a voxel whose list would be longer gets none)
 #define SDF_LIST_K 8                 // lanes that share one voxel's list in sdf_list_search; list element i is stored at (i % K) * (L / K) + i / K
 #define SDF_LIST_ITEM (4 * (WAVE / SDF_LIST_K))   // voxels per work item of sdf_list_search (4 waves)
+// which entry of a list-search item group `grp` of wave `wave` takes: INTERLEAVED over the four waves (round 6).  A hand's run is in column
+// order, so a wave that takes eight consecutive entries gets eight neighbouring voxels -- all deep or all shallow -- and a partly filled
+// item (a hand has ~1.4 items: half of the items are partial) fills waves 0 and 1 while 2 and 3 idle; the workgroup then waits for its
+// slowest wave at the next table staging (stamps: 7.3 k of a wave-item's 20 k cycles).  A voxel's result does not depend on who
+// computes it: the same bits.  -DSDF_LIST_CONTIGUOUS: rounds 3-5.
+#ifdef SDF_LIST_CONTIGUOUS
+#define SDF_LIST_ENTRY(wave, grp) ((wave) * (WAVE / SDF_LIST_K) + (grp))
+#else
+#define SDF_LIST_ENTRY(wave, grp) ((grp) * (SDF_THREADS / WAVE) + (wave))
+#endif
 #ifndef SDF_LIST_SLACK
 #define SDF_LIST_SLACK 0.04f         // lists stay valid while no vertex of the hand has moved further than this (normalised frame)
 #endif
@@ -956,7 +966,7 @@ __device__ __forceinline__ void sdf_list_pre_finish(const SdfPreLoad& l, int ite
 __device__ __forceinline__ void sdf_list_pre_sync(const SdfWorkspace& ws, int item, SdfPre& pre) {
     const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
     const unsigned* g = ws.inside_list_a + (size_t)item * SDF_LIST_ITEM;
-    const unsigned e0 = g[0], ent = g[wave * (WAVE / SDF_LIST_K) + lane / SDF_LIST_K];
+    const unsigned e0 = g[0], ent = g[SDF_LIST_ENTRY(wave, lane / SDF_LIST_K)];
     sdf_list_pre_finish(sdf_list_pre_issue(ws, e0, ent), item, pre);
 }
 
@@ -1175,7 +1185,7 @@ __device__ __forceinline__ void sdf_full_item(const SdfWorkspace& ws, int item, 
         unsigned n_e0 = 0u, n_ent = 0xffffffffu;
         if (ni >= 0) {
             const unsigned* g = ws.inside_list_a + (size_t)ni * SDF_LIST_ITEM;
-            n_e0 = g[0]; n_ent = g[wave * (WAVE / SDF_LIST_K) + lane / SDF_LIST_K];
+            n_e0 = g[0]; n_ent = g[SDF_LIST_ENTRY(wave, lane / SDF_LIST_K)];
         }
         flush();
         SdfPreLoad nl{0xffffffffu, make_uint2(0u, 0u), 0};
@@ -1236,7 +1246,7 @@ __device__ __forceinline__ void sdf_list_item(const SdfWorkspace& ws, int item, 
         asm volatile("" ::: "memory");         // (the DMA requests are the wave's oldest: SDF_STAGE_CLOSE_KEEP1 below)
         // ... then the entries of the workgroup's NEXT list item (none: this item's again -- valid addresses, nobody uses them) ...
         const int nj = ni >= 0 ? ni : item;
-        const unsigned n_e0 = glist[(size_t)nj * SDF_LIST_ITEM], n_ent = glist[(size_t)nj * SDF_LIST_ITEM + wave * SDF_LIST_VPW + grp];
+        const unsigned n_e0 = glist[(size_t)nj * SDF_LIST_ITEM], n_ent = glist[(size_t)nj * SDF_LIST_ITEM + SDF_LIST_ENTRY(wave, grp)];
         // ... then this lane's voxel (the same for the K lanes of a group) and everything it needs from memory: all of it in flight
         // while the table goes to LDS
         const unsigned ent = pre.ent;
