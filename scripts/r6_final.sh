@@ -1,8 +1,8 @@
 #!/bin/bash
 # round 6, final measurement series of the committed code: profiles (three launch sizes + the two secondary configs), the gap tables
 # of one batch of 64, the microbenchmark of the launch boundary, and the full bench line.
-# usage (GPU box): bash scripts/r6_final.sh <tag>      e.g. r6_v3
-tag=${1:-r6_v3}
+# usage (GPU box): bash scripts/r6_final.sh <tag>      e.g. r6_v4
+tag=${1:-r6_v4}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out build
